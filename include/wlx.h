@@ -1,0 +1,174 @@
+/*
+ * wlx.h — C-ABI of libwlx.so, the MI355X-native (gfx950) Whisper streaming-inference engine.
+ *
+ * This is the drop-in boundary #3 of SURVEY.md §8(b): it replaces the five call sites through
+ * which collabora/WhisperLive reaches its un-vendored numerical engines (faster-whisper /
+ * CTranslate2), each entry point citing the reference interface it stands in for
+ * (paths relative to the reference checkout):
+ *
+ *   wlx_logmel            <- faster_whisper FeatureExtractor.__call__
+ *                            (whisper_live/transcriber/transcriber_faster_whisper.py:655,862;
+ *                             whisper_live/batch_inference.py:258; recipe restated in-tree at
+ *                             whisper_live/transcriber/tensorrt_utils.py:177-190)
+ *   wlx_encode            <- ctranslate2.models.Whisper.encode
+ *                            (transcriber_faster_whisper.py:1339-1348; batch_inference.py:270-271)
+ *   wlx_generate          <- ctranslate2.models.Whisper.generate
+ *                            (transcriber_faster_whisper.py:1394-1407; batch_inference.py:355-357)
+ *   wlx_detect_language   <- ctranslate2.models.Whisper.detect_language
+ *                            (transcriber_faster_whisper.py:1140,1771; batch_inference.py:283)
+ *   wlx_features_set/get  <- ctranslate2.StorageView.from_array
+ *                            (transcriber_faster_whisper.py:1820-1823)
+ *
+ * Conventions: plain pointers and sizes only (no torch / C++ types); every function returns
+ * 0 on success and a non-zero wlx_status otherwise (no exceptions cross the boundary, no
+ * callbacks into the host language); wlx_last_error() returns a thread-local message.
+ * Threading: concurrent calls are safe on DISTINCT slots (each slot owns a HIP stream and all
+ * of its scratch); calls on the same slot must be serialised by the caller, which is what the
+ * reference does (one transcription thread per client, faster_whisper_backend.py:121; or the
+ * single batch-worker thread, batch_inference.py:155-187).
+ */
+#ifndef WLX_H
+#define WLX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define WLX_ABI_VERSION 1
+
+typedef enum {
+    WLX_OK = 0,
+    WLX_ERR_ARG = 1,      /* bad argument / shape */
+    WLX_ERR_HIP = 2,      /* a HIP runtime call failed */
+    WLX_ERR_WEIGHT = 3,   /* missing / mis-shaped weight tensor */
+    WLX_ERR_STATE = 4,    /* call order (e.g. generate before encode) */
+    WLX_ERR_NOMEM = 5
+} wlx_status;
+
+/* Whisper architecture. n_audio_ctx = 1500, n_text_ctx = 448, head_dim = 64. */
+typedef struct {
+    int32_t n_mels;       /* 80 | 128 */
+    int32_t d_model;
+    int32_t n_heads;
+    int32_t enc_layers;
+    int32_t dec_layers;
+    int32_t ffn;
+    int32_t vocab;
+    int32_t n_audio_ctx;  /* 1500 */
+    int32_t n_text_ctx;   /* 448  */
+} wlx_spec;
+
+/* One weight tensor, named with the Hugging Face Whisper state-dict key (e.g.
+ * "model.encoder.layers.0.self_attn.q_proj.weight"), fp32, C-contiguous, in host or device
+ * memory. The engine copies/repacks it into its own MFMA-fragment layout during create;
+ * the caller may free the tensor afterwards. */
+typedef struct {
+    const char* name;
+    const void* data;
+    int32_t ndim;
+    int64_t shape[4];
+    int32_t on_device;    /* 0 = host pointer, 1 = HIP device pointer on `device` */
+} wlx_tensor;
+
+typedef struct wlx_engine wlx_engine;
+
+/* Token ids the decoding rules need; resolved by NAME on the host side from tokenizer.json
+ * (never hard-coded). */
+typedef struct {
+    int32_t sot, eot, no_timestamps, timestamp_begin, no_speech, blank /* id of " " or -1 */;
+} wlx_token_ids;
+
+/* Decoding options = the keyword arguments of ctranslate2 Whisper.generate as the reference
+ * passes them (transcriber_faster_whisper.py:1380-1407). */
+typedef struct {
+    int32_t beam_size;                 /* T=0: 5 ; T>0: 1 */
+    float   patience;                  /* 1 */
+    int32_t num_hypotheses;            /* T=0: 1 ; T>0: best_of=5 */
+    float   length_penalty;            /* 1 */
+    float   repetition_penalty;        /* 1 */
+    int32_t no_repeat_ngram_size;      /* 0 */
+    int32_t max_length;                /* prompt + generated, <= 448 */
+    int32_t suppress_blank;            /* bool */
+    const int32_t* suppress_tokens;    /* may be NULL */
+    int32_t n_suppress_tokens;
+    int32_t max_initial_timestamp_index; /* 50 */
+    int32_t sampling_topk;             /* 0 = whole vocabulary (only value used by the reference for T>0); 1 = greedy */
+    float   sampling_temperature;      /* 0 -> beam search */
+    uint64_t seed;                     /* counter-based RNG seed for T>0 */
+    wlx_token_ids ids;
+} wlx_gen_opts;
+
+/* Per-stage GPU times of the last calls on a slot, milliseconds (HIP events on the slot stream). */
+typedef struct {
+    float logmel_ms, encode_ms, generate_ms;
+    int32_t decode_steps;
+} wlx_timings;
+
+int32_t wlx_abi_version(void);
+const char* wlx_last_error(void);
+
+int32_t wlx_engine_create(const wlx_spec* spec, const wlx_tensor* weights, int32_t n_weights,
+                          int32_t device, wlx_engine** out);
+void    wlx_engine_destroy(wlx_engine* e);
+int32_t wlx_engine_spec(const wlx_engine* e, wlx_spec* out);
+
+/* A slot = one unit of concurrency: its own HIP stream plus every device buffer a call needs
+ * (feature ring, encoder activations, cross-attention K/V, self-attention KV cache, beam state),
+ * sized for `max_batch` audio items and `max_rows_per_item` decoder rows (beams) per item. */
+int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max_rows_per_item, int32_t* slot_out);
+int32_t wlx_slot_destroy(wlx_engine* e, int32_t slot);
+
+/* log-mel of `n` float32 PCM samples (host pointer, 16 kHz mono) for item `item` of the slot.
+ * Result stays on the device as float32 [n_mels, n_frames], n_frames = (n+160)/160. */
+int32_t wlx_logmel(wlx_engine* e, int32_t slot, int32_t item, const float* pcm, int64_t n,
+                   int32_t* n_frames_out);
+/* Copy an item's device features to host / replace them from host (float32 [n_mels, n_frames]). */
+int32_t wlx_features_get(wlx_engine* e, int32_t slot, int32_t item, float* out, int64_t cap_floats,
+                         int32_t* n_frames_out);
+int32_t wlx_features_set(wlx_engine* e, int32_t slot, int32_t item, const float* feats,
+                         int32_t n_mels, int32_t n_frames);
+
+/* Encoder forward for items 0..batch-1. Item i uses feature frames [seek[i], seek[i]+seg[i]),
+ * zero-padded (in log-mel space) to 3000 = pad_or_trim (transcriber_faster_whisper.py:1125-1127).
+ * Leaves encoder output [batch,1500,d] and the cross-attention K/V of every decoder layer on the device. */
+int32_t wlx_encode(wlx_engine* e, int32_t slot, int32_t batch, const int32_t* seek, const int32_t* seg);
+/* float32 copy of the encoder output of one item, [1500, d_model]. */
+int32_t wlx_encoder_output_get(wlx_engine* e, int32_t slot, int32_t item, float* out, int64_t cap_floats);
+
+/* Autoregressive decode for items 0..batch-1 (item i uses prompt i). Outputs, per item and
+ * hypothesis h < num_hypotheses (best first): generated token ids (prompt and EOT excluded),
+ * their count, the CT2-style score (sum of log-probs incl. EOT / len^length_penalty), and per
+ * item the no-speech probability (softmax prob. of ids.no_speech at the sot position). */
+int32_t wlx_generate(wlx_engine* e, int32_t slot, int32_t batch,
+                     const int32_t* prompts, const int32_t* prompt_lens, int32_t prompt_stride,
+                     const wlx_gen_opts* opts,
+                     int32_t* tokens_out, int32_t tokens_stride /* per hypothesis */,
+                     int32_t* n_tokens_out, float* scores_out, float* no_speech_prob_out);
+
+/* One decoder step on [sot]; softmax restricted to `lang_ids`; probs_out[batch][n_lang]. */
+int32_t wlx_detect_language(wlx_engine* e, int32_t slot, int32_t batch, int32_t sot,
+                            const int32_t* lang_ids, int32_t n_lang, float* probs_out);
+
+int32_t wlx_timings_get(wlx_engine* e, int32_t slot, wlx_timings* out);
+int32_t wlx_sync(wlx_engine* e, int32_t slot);
+
+/* ---- test hooks (used only by tests/ and bench.py's roofline leg; not part of the drop-in) ---- */
+/* next-token logits [rows, vocab] of the last decoder step executed on the slot */
+int32_t wlx_debug_logits_get(wlx_engine* e, int32_t slot, float* out, int32_t rows, int64_t cap_floats);
+/* teacher-forced decoder pass: feed `n` tokens of one sequence (item 0), return logits [n, vocab] */
+int32_t wlx_debug_decode_logits(wlx_engine* e, int32_t slot, const int32_t* tokens, int32_t n, float* out);
+/* run the search kernels on caller-supplied logits (float32 [steps][rows][vocab], host):
+ * exercises logits processors + beam/sampling bookkeeping without the network */
+int32_t wlx_debug_search(wlx_engine* e, int32_t slot, const float* logits, int32_t steps,
+                         const int32_t* prompt, int32_t prompt_len, const wlx_gen_opts* opts,
+                         int32_t* tokens_out, int32_t tokens_stride, int32_t* n_tokens_out, float* scores_out);
+/* time `iters` replays of one full decode step (rows x vocab GEMV chain) with HIP events; returns avg ms */
+int32_t wlx_debug_time_decode_step(wlx_engine* e, int32_t slot, int32_t rows, int32_t t, int32_t iters,
+                                   float* avg_ms_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WLX_H */

@@ -1,0 +1,128 @@
+"""ctypes binding of libwlx.so (include/wlx.h). There is NO CPU fallback: if the HIP library is missing or
+fails to load, importing the engine raises and tells the user how to build it."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+CSRC = PKG_DIR / "csrc"
+LIB_PATH = PKG_DIR / "libwlx.so"
+SOURCES = ["pack.hip", "logmel.hip", "gemm.hip", "attention.hip", "decoder.hip", "search.hip", "engine.hip"]
+EXPORTS = [
+    "wlx_abi_version", "wlx_last_error", "wlx_engine_create", "wlx_engine_destroy", "wlx_engine_spec",
+    "wlx_slot_create", "wlx_slot_destroy", "wlx_logmel", "wlx_features_get", "wlx_features_set", "wlx_encode",
+    "wlx_encoder_output_get", "wlx_generate", "wlx_detect_language", "wlx_timings_get", "wlx_sync",
+    "wlx_debug_logits_get", "wlx_debug_decode_logits", "wlx_debug_search", "wlx_debug_time_decode_step",
+]
+
+
+class WlxError(RuntimeError):
+    pass
+
+
+class wlx_spec(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("n_mels", "d_model", "n_heads", "enc_layers", "dec_layers", "ffn", "vocab", "n_audio_ctx", "n_text_ctx")]
+
+
+class wlx_tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int32), ("shape", C.c_int64 * 4),
+                ("on_device", C.c_int32)]
+
+
+class wlx_token_ids(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("sot", "eot", "no_timestamps", "timestamp_begin", "no_speech", "blank")]
+
+
+class wlx_gen_opts(C.Structure):
+    _fields_ = [
+        ("beam_size", C.c_int32), ("patience", C.c_float), ("num_hypotheses", C.c_int32),
+        ("length_penalty", C.c_float), ("repetition_penalty", C.c_float), ("no_repeat_ngram_size", C.c_int32),
+        ("max_length", C.c_int32), ("suppress_blank", C.c_int32), ("suppress_tokens", C.POINTER(C.c_int32)),
+        ("n_suppress_tokens", C.c_int32), ("max_initial_timestamp_index", C.c_int32), ("sampling_topk", C.c_int32),
+        ("sampling_temperature", C.c_float), ("seed", C.c_uint64), ("ids", wlx_token_ids),
+    ]
+
+
+class wlx_timings(C.Structure):
+    _fields_ = [("logmel_ms", C.c_float), ("encode_ms", C.c_float), ("generate_ms", C.c_float), ("decode_steps", C.c_int32)]
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Compile every HIP source for gfx950 into whisperlive_amd/libwlx.so (hipcc cross-compiles without a GPU)."""
+    srcs = [CSRC / s for s in SOURCES]
+    deps = srcs + list(CSRC.glob("*.h")) + [PKG_DIR.parent / "include" / "wlx.h"]
+    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return LIB_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise WlxError("hipcc not found: cannot build libwlx.so (ROCm toolchain required)")
+    tmp = LIB_PATH.with_suffix(".so.tmp")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", str(tmp)] + [str(s) for s in srcs]
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or proc.returncode != 0:
+        print(proc.stdout, proc.stderr)
+    if proc.returncode != 0:
+        raise WlxError(f"hipcc failed ({proc.returncode}):\n{proc.stderr[-4000:]}")
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load libwlx.so and declare prototypes. Raises WlxError (never falls back) if unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not LIB_PATH.exists():
+        raise WlxError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "(hipcc --offload-arch=gfx950). whisperlive_amd has no CPU fallback.")
+    try:
+        lib = C.CDLL(str(LIB_PATH))
+    except OSError as e:  # e.g. libamdhip64 missing
+        raise WlxError(f"cannot load {LIB_PATH}: {e}") from e
+    missing = [s for s in EXPORTS if not hasattr(lib, s)]
+    if missing:
+        raise WlxError(f"libwlx.so lacks symbols {missing}")
+    i32, i64, f32p, i32p, vp = C.c_int32, C.c_int64, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_void_p
+    lib.wlx_abi_version.restype = i32
+    lib.wlx_last_error.restype = C.c_char_p
+    lib.wlx_engine_create.argtypes = [C.POINTER(wlx_spec), C.POINTER(wlx_tensor), i32, i32, C.POINTER(vp)]
+    lib.wlx_engine_destroy.argtypes = [vp]
+    lib.wlx_engine_destroy.restype = None
+    lib.wlx_engine_spec.argtypes = [vp, C.POINTER(wlx_spec)]
+    lib.wlx_slot_create.argtypes = [vp, i32, i32, i32p]
+    lib.wlx_slot_destroy.argtypes = [vp, i32]
+    lib.wlx_logmel.argtypes = [vp, i32, i32, f32p, i64, i32p]
+    lib.wlx_features_get.argtypes = [vp, i32, i32, f32p, i64, i32p]
+    lib.wlx_features_set.argtypes = [vp, i32, i32, f32p, i32, i32]
+    lib.wlx_encode.argtypes = [vp, i32, i32, i32p, i32p]
+    lib.wlx_encoder_output_get.argtypes = [vp, i32, i32, f32p, i64]
+    lib.wlx_generate.argtypes = [vp, i32, i32, i32p, i32p, i32, C.POINTER(wlx_gen_opts), i32p, i32, i32p, f32p, f32p]
+    lib.wlx_detect_language.argtypes = [vp, i32, i32, i32, i32p, i32, f32p]
+    lib.wlx_timings_get.argtypes = [vp, i32, C.POINTER(wlx_timings)]
+    lib.wlx_sync.argtypes = [vp, i32]
+    lib.wlx_debug_logits_get.argtypes = [vp, i32, f32p, i32, i64]
+    lib.wlx_debug_decode_logits.argtypes = [vp, i32, i32p, i32, f32p]
+    lib.wlx_debug_search.argtypes = [vp, i32, f32p, i32, i32p, i32, C.POINTER(wlx_gen_opts), i32p, i32, i32p, f32p]
+    lib.wlx_debug_time_decode_step.argtypes = [vp, i32, i32, i32, i32, f32p]
+    for name in EXPORTS:
+        fn = getattr(lib, name)
+        if name not in ("wlx_last_error", "wlx_engine_destroy"):
+            fn.restype = i32
+    if lib.wlx_abi_version() != 1:
+        raise WlxError("libwlx.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().wlx_last_error()
+        raise WlxError(f"libwlx error {rc}: {msg.decode() if msg else '?'}")

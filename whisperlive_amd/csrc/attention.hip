@@ -1,0 +1,139 @@
+// attention.hip — encoder self-attention (non-causal, 1500 x 1500, head_dim 64), flash-style.
+// Part of the ctranslate2 Whisper.encode replacement
+// (whisper_live/transcriber/transcriber_faster_whisper.py:1339-1348; network definition
+// HF modeling_whisper.py:267-309: q scaled by head_dim^-0.5, no bias on k).
+//
+// One 64-lane wave owns QT*16 query rows of one head and walks the keys in tiles of 32 with an
+// online softmax. The score tile is computed TRANSPOSED, S^T = K * Q^T (K rows are the MFMA A
+// operand, Q^T the B operand), so each lane holds 8 keys x ONE query: the softmax row-reduction
+// is in-lane plus two cross-lane shuffles (lanes l, l^16, l^32, l^48 share a query), and the
+// probabilities are already in the B-operand layout of the second product O^T = V^T * P^T — no
+// LDS transpose of P. V is stored transposed ([head_dim][key]) by the QKV GEMM epilogue so the
+// V^T A-fragments are two 8-byte loads per lane. Everything is read straight from L2 (K/V of a
+// head are 384 KB and stay resident), no LDS, no barriers.
+#include "kernels.h"
+
+namespace wlx {
+
+template <int QT>
+__global__ __launch_bounds__(64) void attn_encoder_kernel(const half_t* __restrict__ Q, long ldq,
+                                                          const half_t* __restrict__ K, long ldk,
+                                                          const half_t* __restrict__ Vt, long ldvt,
+                                                          half_t* __restrict__ O, long ldo, int T,
+                                                          long isq, long isk, long isv, long iso) {
+    const int lane = threadIdx.x;
+    const int c = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, item = blockIdx.z;
+    const int q0 = blockIdx.x * (QT * 16);
+    Q += (long)item * isq + h * WLX_HEAD_DIM;
+    K += (long)item * isk + h * WLX_HEAD_DIM;
+    Vt += (long)item * isv + (long)h * WLX_HEAD_DIM * ldvt;
+    O += (long)item * iso + h * WLX_HEAD_DIM;
+
+    // Q^T B-fragments: lane (j = query c, k = d = kt*32 + g*8 + e)
+    f16x8 qf[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        int row = q0 + qt * 16 + c;
+        if (row >= T) row = T - 1;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) qf[qt][kt] = ld_f16x8(Q + (long)row * ldq + kt * 32 + g * 8);
+    }
+
+    f32x4 acc[QT][4];
+    float mrun[QT], lrun[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        mrun[qt] = WLX_NEG_INF;
+        lrun[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    const half_t* kbase = K + (long)c * ldk + g * 8;          // + key*ldk + kt*32
+    const half_t* vbase = Vt + (long)c * ldvt + g * 4;        // + dt*16*ldvt + key0 (+16)
+
+    for (int key0 = 0; key0 < T; key0 += 32) {
+        // ---- S^T sub-tiles (16 keys each)
+        f16x8 kf[2][2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) kf[s][kt] = ld_f16x8(kbase + (long)(key0 + s * 16) * ldk + kt * 32);
+        // V^T fragments for this key tile (issued early so they fly under the softmax)
+        f16x8 vf[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const half_t* vp = vbase + (long)dt * 16 * ldvt + key0;
+            f16x4 lo = ld_f16x4(vp), hi = ld_f16x4(vp + 16);
+            vf[dt] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            f32x4 st[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                st[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) st[s] = mfma16(kf[s][kt], qf[qt][kt], st[s]);
+            }
+            // lane holds keys key0 + s*16 + g*4 + r for query c
+            float p[8];
+            float tmax = WLX_NEG_INF;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int key = key0 + s * 16 + g * 4 + r;
+                    float v = (key < T) ? st[s][r] : WLX_NEG_INF;
+                    p[s * 4 + r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+            tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+            const float mnew = fmaxf(mrun[qt], tmax);
+            const float alpha = __expf(mrun[qt] - mnew);
+            float psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { p[i] = __expf(p[i] - mnew); psum += p[i]; }
+            lrun[qt] = lrun[qt] * alpha + psum;   // per-lane partial; reduced over g at the end
+            mrun[qt] = mnew;
+            f16x8 pf = {(half_t)p[0], (half_t)p[1], (half_t)p[2], (half_t)p[3],
+                        (half_t)p[4], (half_t)p[5], (half_t)p[6], (half_t)p[7]};
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 a = acc[qt][dt];
+                a[0] *= alpha; a[1] *= alpha; a[2] *= alpha; a[3] *= alpha;
+                acc[qt][dt] = mfma16(vf[dt], pf, a);
+            }
+        }
+    }
+
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float l = lrun[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int row = q0 + qt * 16 + c;
+        if (row < T) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f16x4 o = {(half_t)(acc[qt][dt][0] * inv), (half_t)(acc[qt][dt][1] * inv),
+                           (half_t)(acc[qt][dt][2] * inv), (half_t)(acc[qt][dt][3] * inv)};
+                *reinterpret_cast<f16x4*>(O + (long)row * ldo + dt * 16 + g * 4) = o;
+            }
+        }
+    }
+}
+
+void launch_attn_encoder(const half_t* Q, long ldq, const half_t* K, long ldk, const half_t* Vt, long ldvt,
+                         half_t* O, long ldo, int T, int H, int items,
+                         long isq, long isk, long isv, long iso, hipStream_t s) {
+    constexpr int QT = 2;
+    dim3 grid((T + QT * 16 - 1) / (QT * 16), H, items);
+    hipLaunchKernelGGL((attn_encoder_kernel<QT>), grid, dim3(64), 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, T,
+                       isq, isk, isv, iso);
+}
+
+}  // namespace wlx

@@ -1,0 +1,57 @@
+// common.h — device-side helpers shared by the gfx950 kernels of libwlx.
+// CDNA4 only: wave = 64 lanes, MFMA 16x16x32 f16 with f32 accumulate.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef _Float16 half_t;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WLX_WAVE 64
+#define WLX_T_AUDIO 1500      // encoder positions per 30 s window
+#define WLX_T_AUDIO_PAD 1536  // key padding so 32-key tiles never read out of bounds
+#define WLX_N_FRAMES 3000     // mel frames per window
+#define WLX_T_TEXT 448
+#define WLX_HEAD_DIM 64
+
+// MFMA fragment conventions (v_mfma_f32_16x16x32_f16), lane l, c = l & 15, g = l >> 4:
+//   A operand: A[i = c][k = g*8 + e], e = 0..7      (8 halfs = 16 B per lane)
+//   B operand: B[k = g*8 + e][j = c]
+//   C/D     : D[i = g*4 + r][j = c],  r = 0..3
+// Weights W[N][K] are stored PACKED per (n-tile, k-tile): Wp[((nt*KT + kt)*64 + l)*8 + e] =
+//   W[nt*16 + c][kt*32 + g*8 + e], so one wave-load of a fragment is one contiguous 1 KiB.
+// All GEMMs use the "swapped" form D[i = n][j = m] = sum_k W[n][k] * X[m][k]: the weight
+// fragment is the A operand, the activation fragment the B operand, and every lane ends up
+// with 4 CONSECUTIVE output columns n of one activation row m (wide row-major stores).
+
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// exact (erf) GELU — Whisper's activation (HF configuration_whisper.py: activation_function="gelu")
+__device__ __forceinline__ float gelu_erf(float x) {
+    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+__device__ __forceinline__ f16x8 ld_f16x8(const half_t* p) {
+    return *reinterpret_cast<const f16x8*>(p);
+}
+__device__ __forceinline__ f16x4 ld_f16x4(const half_t* p) {
+    return *reinterpret_cast<const f16x4*>(p);
+}
+
+#define WLX_NEG_INF (-__builtin_inff())

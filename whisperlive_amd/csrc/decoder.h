@@ -1,0 +1,106 @@
+// decoder.h — launchers for the autoregressive-decoder kernels (decoder.hip, search.hip).
+#pragma once
+#include "kernels.h"
+
+namespace wlx {
+
+#define WLX_MAX_MT 4          // decoder rows are processed in up to 4 MFMA row tiles (64 rows)
+#define WLX_XSPLIT 8          // key splits of the decode cross-attention (flash-decoding)
+#define WLX_MAX_CAND 32       // 2*beam candidates per row
+#define WLX_MAX_HYP 32        // finished hypotheses kept per item
+
+// Row tables (device, int32[rows]) describing what each decoder row is in this pass:
+//   token   : token id fed at this row
+//   pos     : its position in the text context (positional embedding, KV-cache column)
+//   cache   : KV-cache row that receives this row's new K/V
+//   ancrow  : row of the ancestry table used to READ the history of this row
+// plus the ancestry table anc[cache_rows][448] (int16): anc[r][p] = KV-cache row that holds
+// position p of the hypothesis currently living in row r (beam reordering without moving the cache).
+struct RowTables {
+    const int* token; const int* pos; const int* cache; const int* ancrow;
+    const short* anc;
+    int* intok;               // [cache_rows][448] token fed by cache row r at position p
+};
+
+void launch_dec_embed(const half_t* tok_emb, const float* pos_emb, int d, const RowTables& rt, int rows,
+                      float* x, const int* done, hipStream_t s);
+
+enum GemvIn : int { GEMV_IN_LN = 0, GEMV_IN_F16 = 1, GEMV_IN_XATTN = 2 };
+enum GemvOut : int { GEMV_OUT_F16 = 0, GEMV_OUT_GELU_F16 = 1, GEMV_OUT_F32 = 2, GEMV_OUT_RESID = 3, GEMV_OUT_QKV = 4 };
+
+struct GemvParams {
+    int in_mode, out_mode;
+    int M;                                   // live rows
+    int K, KT, N;                            // K real, KT = Kpad/32, N real outputs
+    const half_t* Wp; const float* bias;
+    // GEMV_IN_LN
+    const float* X; long ldx; const float* gamma; const float* beta;
+    // GEMV_IN_F16
+    const half_t* Xh; long ldxh;
+    // GEMV_IN_XATTN: split partials of the cross attention
+    const float* part_o; const float* part_ml; int H; int R;
+    // outputs
+    half_t* Yh; long ldyh;
+    float* Y; long ldy;
+    float* Xres; long ldxres;
+    // GEMV_OUT_QKV
+    int d; float qscale; half_t* Kc; half_t* Vc; long cache_row_stride;
+    const int* row_cache; const int* row_pos;
+    const int* done;
+};
+void launch_dec_gemv(const GemvParams& p, hipStream_t s);
+
+// causal self-attention over the KV cache, one wave per (row, head)
+void launch_dec_self_attn(const half_t* q, long ldq, const half_t* Kc, const half_t* Vc, long cache_row_stride,
+                          int d, int H, const RowTables& rt, int rows, half_t* out, long ldo,
+                          const int* done, hipStream_t s);
+// cross-attention of R rows per item against the item's 1500 encoder keys, split over keys
+// groups of R (<=16) rows; group_item[g] = audio item whose K/V group g attends to
+void launch_dec_cross_attn(const half_t* q, long ldq, const half_t* Kx, long ldk, long item_stride_k,
+                           const half_t* Vtx, long ldvt, long item_stride_v,
+                           int H, int R, int groups, int rows, const int* group_item,
+                           float* part_o, float* part_ml, const int* done, hipStream_t s);
+
+// ---------------------------------------------------------------- search.hip
+struct SearchState {            // device pointers, one set per slot
+    int* step;                  // [1] decode step counter
+    int* done;                  // [1] all items finished
+    int* n_finished;            // [1]
+    int* item_done;             // [items]
+    int* plen;                  // [items] prompt length (first generated position)
+    float* cum;                 // [rows] cumulative log-prob of the hypothesis in each row
+    int* row_done;              // [rows] (sampling mode)
+    float* cand_score; int* cand_tok;  // [rows][WLX_MAX_CAND]
+    int* samp_tok; float* samp_lp;     // [rows]
+    int* hyp_tokens;            // [items][WLX_MAX_HYP][448]
+    int* hyp_len;               // [items][WLX_MAX_HYP]
+    float* hyp_score;           // [items][WLX_MAX_HYP]  (normalised)
+    int* n_hyp;                 // [items]
+    float* no_speech;           // [items]
+    int* nsp_row;               // [rows] 1 if this row's raw distribution defines no_speech_prob (-1 none)
+    // row tables (mutable here)
+    int* token; int* pos; short* anc; int* intok;
+};
+struct SearchParams {
+    int V; long ldl;
+    int items, R, rows;
+    int sampling;               // 0 beam search, 1 multinomial sampling
+    int beam, ncand, max_cand_hyp /* round(beam*patience) */, num_hyp;
+    int allow_early_exit;
+    float length_penalty, rep_penalty, temperature;
+    int no_repeat_ngram, topk;
+    int suppress_blank, apply_ts_rules, max_initial_ts;
+    int sot, eot, no_timestamps, ts_begin, no_speech, blank;
+    int max_length;
+    unsigned long long seed;
+    const unsigned* suppress_mask;   // [ceil(V/32)] bit = 1 -> suppressed
+};
+// SearchParams live in device memory (sp_dev) so a captured step graph is reusable across calls
+void launch_search_rows(const float* logits, const SearchParams* sp_dev, int rows, const SearchState& st, hipStream_t s);
+void launch_search_update(const SearchParams* sp_dev, int items, const SearchState& st, hipStream_t s);
+// softmax prob of token `tok` in given logits rows -> out[rows]
+void launch_token_prob(const float* logits, long ldl, int V, int rows, int tok, float* out, hipStream_t s);
+// softmax restricted to ids -> probs[rows][n]
+void launch_lang_probs(const float* logits, long ldl, int rows, const int* ids, int n, float* probs, hipStream_t s);
+
+}  // namespace wlx

@@ -1,0 +1,88 @@
+// engine.h — host-side state of libwlx: weights in kernel layout, per-slot device buffers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "../../include/wlx.h"
+#include "decoder.h"
+
+namespace wlx {
+
+struct EncLayerW {
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    half_t *Wqkv, *Wo, *W1, *W2;
+    float *bqkv, *bo, *b1, *b2;
+};
+struct DecLayerW {
+    float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *ln3_g, *ln3_b;
+    half_t *Wqkv, *Wo, *Wcq, *Wco, *W1, *W2;
+    float *bqkv, *bo, *bcq, *bco, *b1, *b2;
+};
+
+struct StepGraphKey {
+    int rows, R, groups;
+    bool operator<(const StepGraphKey& o) const {
+        if (rows != o.rows) return rows < o.rows;
+        if (R != o.R) return R < o.R;
+        return groups < o.groups;
+    }
+};
+
+struct Slot {
+    int B = 0, R = 0, rows_cap = 0, cache_rows = 0, groups_cap = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::vector<void*> allocs;
+    // features
+    float* pcm = nullptr; size_t pcm_cap = 0;       // [B][pcm_cap]
+    float* feats = nullptr; long feat_ld = 0;        // [B][n_mels][feat_ld]
+    std::vector<int> nframes;
+    unsigned* gmax = nullptr;
+    // encoder
+    half_t *featT = nullptr, *h1 = nullptr, *ln = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr,
+           *attn = nullptr, *h2 = nullptr, *enc16 = nullptr;
+    float *x = nullptr, *enc32 = nullptr;
+    long featT_stride = 0, h1_stride = 0;
+    half_t *ck = nullptr, *cvt = nullptr;            // cross K [L][B][TPAD][d], V^T [L][B][d][TPAD]
+    int enc_batch = 0;
+    // decoder
+    half_t *kc = nullptr, *vc = nullptr;             // self cache [L][cache_rows][448][d]
+    float* xd = nullptr; half_t *qd = nullptr, *attnd = nullptr, *hd = nullptr;
+    float *part_o = nullptr, *part_ml = nullptr, *logits = nullptr;
+    long ldl = 0;
+    int *d_token = nullptr, *d_pos = nullptr, *d_cache = nullptr, *d_ancrow = nullptr, *d_group_item = nullptr;
+    short* d_anc = nullptr; int* d_intok = nullptr;
+    SearchState st{};
+    SearchParams* d_sp = nullptr;
+    unsigned* d_suppress = nullptr;
+    int* d_lang_ids = nullptr; float* d_probs = nullptr; float* d_tokprob = nullptr;
+    // pinned host staging
+    int* h_stage = nullptr; size_t h_stage_ints = 0;
+    std::map<StepGraphKey, hipGraphExec_t> graphs;
+    wlx_timings tm{};
+};
+
+struct Engine {
+    wlx_spec spec{};
+    int device = 0;
+    int H = 0;
+    std::vector<void*> allocs;
+    LogmelConsts lm{};
+    half_t *conv1_w = nullptr, *conv2_w = nullptr;
+    float *conv1_b = nullptr, *conv2_b = nullptr, *enc_pos = nullptr, *enc_ln_g = nullptr, *enc_ln_b = nullptr;
+    int conv1_KT = 0;
+    std::vector<EncLayerW> enc;
+    half_t* Wckv = nullptr; float* bckv = nullptr;
+    half_t *tok_emb16 = nullptr, *Wvocab = nullptr;
+    float *dec_pos = nullptr, *dec_ln_g = nullptr, *dec_ln_b = nullptr;
+    std::vector<DecLayerW> dec;
+    std::mutex mu;
+    std::vector<Slot*> slots;
+    bool use_graph = true;
+};
+
+}  // namespace wlx
+
+struct wlx_engine : public wlx::Engine {};

@@ -1,0 +1,1088 @@
+// engine.hip — C-ABI (include/wlx.h) over the gfx950 kernels: weight ingestion/repacking, slots
+// (one HIP stream + all scratch per concurrent stream), and the host orchestration of
+// log-mel -> encoder -> prefill -> hipGraph-replayed decode steps.
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+using namespace wlx;
+
+static thread_local char g_err[512] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define CK(call)                                                                                       \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return fail(WLX_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define CKR(call)                                 \
+    do {                                          \
+        int r_ = (call);                          \
+        if (r_ != WLX_OK) return r_;              \
+    } while (0)
+
+extern "C" int32_t wlx_abi_version(void) { return WLX_ABI_VERSION; }
+extern "C" const char* wlx_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------
+// allocation helpers
+template <typename T>
+static int dalloc(std::vector<void*>& pool, T** out, size_t count, bool zero = true) {
+    void* p = nullptr;
+    size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) return fail(WLX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    if (zero) {
+        e = hipMemset(p, 0, bytes);
+        if (e != hipSuccess) return fail(WLX_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+    }
+    pool.push_back(p);
+    *out = reinterpret_cast<T*>(p);
+    return WLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight ingestion
+struct WeightSource {
+    std::map<std::string, const wlx_tensor*> by_name;
+    float* staging = nullptr;   // device fp32 staging for host tensors
+    size_t staging_cap = 0;
+    hipStream_t stream = nullptr;
+
+    const wlx_tensor* find(const std::string& n) const {
+        auto it = by_name.find(n);
+        return it == by_name.end() ? nullptr : it->second;
+    }
+    static size_t numel(const wlx_tensor* t) {
+        size_t n = 1;
+        for (int i = 0; i < t->ndim; ++i) n *= (size_t)t->shape[i];
+        return n;
+    }
+    // device fp32 view of a tensor (valid until the next call when the tensor lives on the host)
+    int device_f32(const wlx_tensor* t, const float** out) {
+        if (t->on_device) { *out = reinterpret_cast<const float*>(t->data); return WLX_OK; }
+        size_t n = numel(t);
+        if (n > staging_cap) {
+            if (staging) (void)hipFree(staging);
+            staging = nullptr;
+            CK(hipMalloc(reinterpret_cast<void**>(&staging), n * sizeof(float)));
+            staging_cap = n;
+        }
+        CK(hipStreamSynchronize(stream));  // previous consumer of the staging buffer
+        CK(hipMemcpy(staging, t->data, n * sizeof(float), hipMemcpyHostToDevice));
+        *out = staging;
+        return WLX_OK;
+    }
+};
+
+static int need(WeightSource& ws, const std::string& name, std::initializer_list<int64_t> shape,
+                const wlx_tensor** out) {
+    const wlx_tensor* t = ws.find(name);
+    if (!t) return fail(WLX_ERR_WEIGHT, "missing weight '%s'", name.c_str());
+    if (t->ndim != (int)shape.size()) return fail(WLX_ERR_WEIGHT, "weight '%s': ndim %d", name.c_str(), t->ndim);
+    int i = 0;
+    for (int64_t s : shape) {
+        if (t->shape[i] != s)
+            return fail(WLX_ERR_WEIGHT, "weight '%s': dim %d is %lld, expected %lld", name.c_str(), i,
+                        (long long)t->shape[i], (long long)s);
+        ++i;
+    }
+    *out = t;
+    return WLX_OK;
+}
+
+// copy an fp32 vector into engine memory at dst+offset (dst pre-allocated, zeroed)
+static int load_vec(WeightSource& ws, const std::string& name, int64_t n, float* dst) {
+    const wlx_tensor* t;
+    CKR(need(ws, name, {n}, &t));
+    if (t->on_device) CK(hipMemcpyAsync(dst, t->data, n * sizeof(float), hipMemcpyDeviceToDevice, ws.stream));
+    else CK(hipMemcpy(dst, t->data, n * sizeof(float), hipMemcpyHostToDevice));
+    return WLX_OK;
+}
+static int alloc_vec(Engine* e, WeightSource& ws, const std::string& name, int64_t n, float** out) {
+    CKR(dalloc(e->allocs, out, (size_t)n));
+    return load_vec(ws, name, n, *out);
+}
+// pack W[N][K] into a packed image (already allocated, [NT_total][KT]) at n-tile offset nt0
+static int pack_into(WeightSource& ws, const std::string& name, int64_t N, int64_t K, half_t* Wp, int KT, int nt0) {
+    const wlx_tensor* t;
+    CKR(need(ws, name, {N, K}, &t));
+    const float* src;
+    CKR(ws.device_f32(t, &src));
+    launch_pack_linear(src, (int)N, (int)K, K, Wp, KT, nt0, ws.stream);
+    CK(hipGetLastError());
+    return WLX_OK;
+}
+static int alloc_packed(Engine* e, int64_t N, int64_t K, half_t** out, int* KT_out) {
+    int KT = (int)((K + 31) / 32);
+    int NT = (int)((N + 15) / 16);
+    CKR(dalloc(e->allocs, out, (size_t)NT * KT * 512));
+    *KT_out = KT;
+    return WLX_OK;
+}
+
+// Slaney mel filterbank exactly as faster-whisper's FeatureExtractor.get_mel_filters builds it
+// (librosa.filters.mel(sr=16000, n_fft=400, n_mels, htk=False, norm="slaney"); float64 math,
+// float32 storage). Equals HF audio_utils.mel_filter_bank(201, n, 0, 8000, 16000, "slaney", "slaney").
+static void build_mel_filters(int n_mels, std::vector<float>& w, std::vector<int>& range) {
+    const int nb = 201;
+    std::vector<double> fft(nb), melf(n_mels + 2);
+    for (int i = 0; i < nb; ++i) fft[i] = (double)i * 8000.0 / 200.0;
+    const double max_mel = 45.245640471924965, f_sp = 200.0 / 3.0, min_log_hz = 1000.0;
+    const double min_log_mel = min_log_hz / f_sp, logstep = std::log(6.4) / 27.0;
+    const double step = max_mel / (double)(n_mels + 1);   // np.linspace(0, max_mel, n_mels + 2)
+    for (int i = 0; i < n_mels + 2; ++i) {
+        double m = (i == n_mels + 1) ? max_mel : (double)i * step;
+        melf[i] = (m >= min_log_mel) ? min_log_hz * std::exp(logstep * (m - min_log_mel)) : f_sp * m;
+    }
+    w.assign((size_t)n_mels * nb, 0.f);
+    range.assign((size_t)n_mels * 2, 0);
+    for (int i = 0; i < n_mels; ++i) {
+        const double fd0 = melf[i + 1] - melf[i], fd1 = melf[i + 2] - melf[i + 1];
+        const double enorm = 2.0 / (melf[i + 2] - melf[i]);
+        int lo = nb, hi = 0;
+        for (int b = 0; b < nb; ++b) {
+            const double lower = -(melf[i] - fft[b]) / fd0, upper = (melf[i + 2] - fft[b]) / fd1;
+            const double v = std::max(0.0, std::min(lower, upper));
+            const float f = (float)((double)(float)v * enorm);
+            w[(size_t)i * nb + b] = f;
+            if (f != 0.f) { lo = std::min(lo, b); hi = std::max(hi, b + 1); }
+        }
+        if (lo >= hi) { lo = 0; hi = 0; }
+        range[2 * i] = lo; range[2 * i + 1] = hi;
+    }
+}
+
+static int build_logmel_consts(Engine* e) {
+    std::vector<float> win(400), tw(800), filt;
+    std::vector<int> range;
+    const double PI2 = 6.283185307179586476925286766559;
+    for (int i = 0; i < 400; ++i) {
+        win[i] = (float)(0.5 - 0.5 * std::cos(PI2 * (double)i / 400.0));   // np.hanning(401)[:-1]
+        tw[2 * i] = (float)std::cos(PI2 * (double)i / 400.0);
+        tw[2 * i + 1] = (float)std::sin(PI2 * (double)i / 400.0);
+    }
+    build_mel_filters(e->spec.n_mels, filt, range);
+    float *dwin, *dtw, *dfilt; int* drange;
+    CKR(dalloc(e->allocs, &dwin, 400)); CKR(dalloc(e->allocs, &dtw, 800));
+    CKR(dalloc(e->allocs, &dfilt, filt.size())); CKR(dalloc(e->allocs, &drange, range.size()));
+    CK(hipMemcpy(dwin, win.data(), 400 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dtw, tw.data(), 800 * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dfilt, filt.data(), filt.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(drange, range.data(), range.size() * 4, hipMemcpyHostToDevice));
+    e->lm.window = dwin; e->lm.twiddle = dtw; e->lm.filters = dfilt; e->lm.frange = drange;
+    return WLX_OK;
+}
+
+static int load_attn_qkv(Engine* e, WeightSource& ws, const std::string& pre, int d, half_t** W, float** b) {
+    int KT;
+    CKR(alloc_packed(e, 3 * d, d, W, &KT));
+    CKR(pack_into(ws, pre + "q_proj.weight", d, d, *W, KT, 0));
+    CKR(pack_into(ws, pre + "k_proj.weight", d, d, *W, KT, d / 16));
+    CKR(pack_into(ws, pre + "v_proj.weight", d, d, *W, KT, 2 * d / 16));
+    CKR(dalloc(e->allocs, b, (size_t)3 * d));
+    CKR(load_vec(ws, pre + "q_proj.bias", d, *b));
+    CKR(load_vec(ws, pre + "v_proj.bias", d, *b + 2 * d));   // k_proj has no bias
+    return WLX_OK;
+}
+static int load_linear(Engine* e, WeightSource& ws, const std::string& pre, int N, int K, half_t** W, float** b) {
+    int KT;
+    CKR(alloc_packed(e, N, K, W, &KT));
+    CKR(pack_into(ws, pre + ".weight", N, K, *W, KT, 0));
+    CKR(alloc_vec(e, ws, pre + ".bias", N, b));
+    return WLX_OK;
+}
+
+static int engine_load(Engine* e, const wlx_tensor* weights, int n_weights) {
+    const wlx_spec& sp = e->spec;
+    const int d = sp.d_model, F = sp.ffn, V = sp.vocab;
+    WeightSource ws;
+    for (int i = 0; i < n_weights; ++i) ws.by_name[weights[i].name] = &weights[i];
+    CK(hipStreamCreate(&ws.stream));
+    int rc = WLX_OK;
+    auto body = [&]() -> int {
+        CKR(build_logmel_consts(e));
+        // ---- encoder stem
+        {
+            const wlx_tensor* t; const float* src;
+            CKR(need(ws, "model.encoder.conv1.weight", {d, sp.n_mels, 3}, &t));
+            e->conv1_KT = (3 * sp.n_mels + 31) / 32;
+            CKR(dalloc(e->allocs, &e->conv1_w, (size_t)(d / 16) * e->conv1_KT * 512));
+            CKR(ws.device_f32(t, &src));
+            launch_pack_conv3(src, d, sp.n_mels, e->conv1_w, e->conv1_KT, ws.stream);
+            CKR(need(ws, "model.encoder.conv2.weight", {d, d, 3}, &t));
+            CKR(dalloc(e->allocs, &e->conv2_w, (size_t)(d / 16) * (3 * d / 32) * 512));
+            CKR(ws.device_f32(t, &src));
+            launch_pack_conv3(src, d, d, e->conv2_w, 3 * d / 32, ws.stream);
+            CKR(alloc_vec(e, ws, "model.encoder.conv1.bias", d, &e->conv1_b));
+            CKR(alloc_vec(e, ws, "model.encoder.conv2.bias", d, &e->conv2_b));
+            CKR(need(ws, "model.encoder.embed_positions.weight", {sp.n_audio_ctx, d}, &t));
+            CKR(dalloc(e->allocs, &e->enc_pos, (size_t)sp.n_audio_ctx * d));
+            CKR(ws.device_f32(t, &src));
+            CK(hipMemcpyAsync(e->enc_pos, src, (size_t)sp.n_audio_ctx * d * 4, hipMemcpyDeviceToDevice, ws.stream));
+        }
+        e->enc.resize(sp.enc_layers);
+        for (int l = 0; l < sp.enc_layers; ++l) {
+            EncLayerW& w = e->enc[l];
+            const std::string p = "model.encoder.layers." + std::to_string(l) + ".";
+            CKR(alloc_vec(e, ws, p + "self_attn_layer_norm.weight", d, &w.ln1_g));
+            CKR(alloc_vec(e, ws, p + "self_attn_layer_norm.bias", d, &w.ln1_b));
+            CKR(load_attn_qkv(e, ws, p + "self_attn.", d, &w.Wqkv, &w.bqkv));
+            CKR(load_linear(e, ws, p + "self_attn.out_proj", d, d, &w.Wo, &w.bo));
+            CKR(alloc_vec(e, ws, p + "final_layer_norm.weight", d, &w.ln2_g));
+            CKR(alloc_vec(e, ws, p + "final_layer_norm.bias", d, &w.ln2_b));
+            CKR(load_linear(e, ws, p + "fc1", F, d, &w.W1, &w.b1));
+            CKR(load_linear(e, ws, p + "fc2", d, F, &w.W2, &w.b2));
+        }
+        CKR(alloc_vec(e, ws, "model.encoder.layer_norm.weight", d, &e->enc_ln_g));
+        CKR(alloc_vec(e, ws, "model.encoder.layer_norm.bias", d, &e->enc_ln_b));
+        // ---- decoder
+        {
+            const wlx_tensor* t; const float* src;
+            CKR(need(ws, "model.decoder.embed_tokens.weight", {V, d}, &t));
+            CKR(dalloc(e->allocs, &e->tok_emb16, (size_t)V * d));
+            CKR(ws.device_f32(t, &src));
+            launch_f32_to_f16(src, e->tok_emb16, (long)V * d, ws.stream);
+            int KT;
+            CKR(alloc_packed(e, V, d, &e->Wvocab, &KT));
+            launch_pack_linear(src, V, d, d, e->Wvocab, KT, 0, ws.stream);   // tied output projection
+            CKR(need(ws, "model.decoder.embed_positions.weight", {sp.n_text_ctx, d}, &t));
+            CKR(dalloc(e->allocs, &e->dec_pos, (size_t)sp.n_text_ctx * d));
+            CKR(ws.device_f32(t, &src));
+            CK(hipMemcpyAsync(e->dec_pos, src, (size_t)sp.n_text_ctx * d * 4, hipMemcpyDeviceToDevice, ws.stream));
+        }
+        e->dec.resize(sp.dec_layers);
+        int KTd = d / 32;
+        CKR(dalloc(e->allocs, &e->Wckv, (size_t)(sp.dec_layers * 2 * d / 16) * KTd * 512));
+        CKR(dalloc(e->allocs, &e->bckv, (size_t)sp.dec_layers * 2 * d));
+        for (int l = 0; l < sp.dec_layers; ++l) {
+            DecLayerW& w = e->dec[l];
+            const std::string p = "model.decoder.layers." + std::to_string(l) + ".";
+            CKR(alloc_vec(e, ws, p + "self_attn_layer_norm.weight", d, &w.ln1_g));
+            CKR(alloc_vec(e, ws, p + "self_attn_layer_norm.bias", d, &w.ln1_b));
+            CKR(load_attn_qkv(e, ws, p + "self_attn.", d, &w.Wqkv, &w.bqkv));
+            CKR(load_linear(e, ws, p + "self_attn.out_proj", d, d, &w.Wo, &w.bo));
+            CKR(alloc_vec(e, ws, p + "encoder_attn_layer_norm.weight", d, &w.ln2_g));
+            CKR(alloc_vec(e, ws, p + "encoder_attn_layer_norm.bias", d, &w.ln2_b));
+            CKR(load_linear(e, ws, p + "encoder_attn.q_proj", d, d, &w.Wcq, &w.bcq));
+            CKR(load_linear(e, ws, p + "encoder_attn.out_proj", d, d, &w.Wco, &w.bco));
+            // cross K/V projections of all layers are fused into one encoder-side GEMM
+            CKR(pack_into(ws, p + "encoder_attn.k_proj.weight", d, d, e->Wckv, KTd, l * 2 * d / 16));
+            CKR(pack_into(ws, p + "encoder_attn.v_proj.weight", d, d, e->Wckv, KTd, (l * 2 * d + d) / 16));
+            CKR(load_vec(ws, p + "encoder_attn.v_proj.bias", d, e->bckv + (size_t)l * 2 * d + d));
+            CKR(alloc_vec(e, ws, p + "final_layer_norm.weight", d, &w.ln3_g));
+            CKR(alloc_vec(e, ws, p + "final_layer_norm.bias", d, &w.ln3_b));
+            CKR(load_linear(e, ws, p + "fc1", F, d, &w.W1, &w.b1));
+            CKR(load_linear(e, ws, p + "fc2", d, F, &w.W2, &w.b2));
+        }
+        CKR(alloc_vec(e, ws, "model.decoder.layer_norm.weight", d, &e->dec_ln_g));
+        CKR(alloc_vec(e, ws, "model.decoder.layer_norm.bias", d, &e->dec_ln_b));
+        CK(hipStreamSynchronize(ws.stream));
+        CK(hipGetLastError());
+        return WLX_OK;
+    };
+    rc = body();
+    (void)hipStreamSynchronize(ws.stream);
+    if (ws.staging) (void)hipFree(ws.staging);
+    (void)hipStreamDestroy(ws.stream);
+    return rc;
+}
+
+extern "C" int32_t wlx_engine_create(const wlx_spec* spec, const wlx_tensor* weights, int32_t n_weights,
+                                     int32_t device, wlx_engine** out) {
+    if (!spec || !weights || !out) return fail(WLX_ERR_ARG, "null argument");
+    if (spec->d_model % 64 || spec->d_model / 64 != spec->n_heads)
+        return fail(WLX_ERR_ARG, "d_model must be 64*n_heads");
+    if (spec->d_model % 128 || spec->d_model > 1536) return fail(WLX_ERR_ARG, "d_model must be a multiple of 128, <= 1536");
+    if (spec->ffn % 128) return fail(WLX_ERR_ARG, "ffn must be a multiple of 128");
+    if (spec->n_mels != 80 && spec->n_mels != 128) return fail(WLX_ERR_ARG, "n_mels must be 80 or 128");
+    if (spec->n_audio_ctx != WLX_T_AUDIO || spec->n_text_ctx != WLX_T_TEXT)
+        return fail(WLX_ERR_ARG, "n_audio_ctx/n_text_ctx must be 1500/448");
+    if (spec->vocab > 1024 * 52) return fail(WLX_ERR_ARG, "vocab too large");
+    int ndev = 0;
+    CK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(WLX_ERR_ARG, "device %d out of range (%d)", device, ndev);
+    CK(hipSetDevice(device));
+    wlx_engine* e = new wlx_engine();
+    e->spec = *spec;
+    e->device = device;
+    e->H = spec->n_heads;
+    const char* ng = getenv("WLX_NO_GRAPH");
+    e->use_graph = !(ng && ng[0] == '1');
+    int rc = engine_load(e, weights, n_weights);
+    if (rc != WLX_OK) {
+        for (void* p : e->allocs) (void)hipFree(p);
+        delete e;
+        return rc;
+    }
+    *out = e;
+    return WLX_OK;
+}
+
+static void slot_free(Slot* s) {
+    if (!s) return;
+    for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
+    for (void* p : s->allocs) (void)hipFree(p);
+    if (s->h_stage) (void)hipHostFree(s->h_stage);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+extern "C" void wlx_engine_destroy(wlx_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipDeviceSynchronize();
+    for (Slot* s : e->slots) slot_free(s);
+    for (void* p : e->allocs) (void)hipFree(p);
+    delete e;
+}
+
+extern "C" int32_t wlx_engine_spec(const wlx_engine* e, wlx_spec* out) {
+    if (!e || !out) return fail(WLX_ERR_ARG, "null argument");
+    *out = e->spec;
+    return WLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// slots
+static int slot_get(wlx_engine* e, int slot, Slot** out) {
+    if (!e) return fail(WLX_ERR_ARG, "null engine");
+    std::lock_guard<std::mutex> g(e->mu);
+    if (slot < 0 || slot >= (int)e->slots.size() || !e->slots[slot]) return fail(WLX_ERR_ARG, "bad slot %d", slot);
+    *out = e->slots[slot];
+    return WLX_OK;
+}
+
+static int slot_grow_audio(Engine* e, Slot* s, size_t n_samples) {
+    if (n_samples <= s->pcm_cap) return WLX_OK;
+    // grow PCM + feature buffers (sizes rounded up to whole 30 s windows)
+    size_t cap = ((n_samples + 479999) / 480000) * 480000;
+    CK(hipStreamSynchronize(s->stream));
+    float* npcm; float* nfe;
+    long ld = (long)(cap / 160 + 64);
+    CKR(dalloc(s->allocs, &npcm, (size_t)s->B * cap, false));
+    CKR(dalloc(s->allocs, &nfe, (size_t)s->B * e->spec.n_mels * ld));
+    // (old buffers stay in the pool until slot destruction; growth is rare: 1-2 times per stream)
+    s->pcm = npcm; s->pcm_cap = cap; s->feats = nfe; s->feat_ld = ld;
+    std::fill(s->nframes.begin(), s->nframes.end(), 0);
+    return WLX_OK;
+}
+
+extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max_rows_per_item, int32_t* slot_out) {
+    if (!e || !slot_out) return fail(WLX_ERR_ARG, "null argument");
+    if (max_batch < 1 || max_batch > 64) return fail(WLX_ERR_ARG, "max_batch out of range");
+    if (max_rows_per_item < 1 || max_rows_per_item > 16) return fail(WLX_ERR_ARG, "max_rows_per_item must be 1..16");
+    if (max_batch * max_rows_per_item > 64) return fail(WLX_ERR_ARG, "max_batch*max_rows_per_item must be <= 64");
+    CK(hipSetDevice(e->device));
+    const wlx_spec& sp = e->spec;
+    const int d = sp.d_model, F = sp.ffn, L = sp.dec_layers, B = max_batch, R = max_rows_per_item;
+    Slot* s = new Slot();
+    s->B = B; s->R = R; s->cache_rows = B * R; s->rows_cap = 64; s->groups_cap = std::max(B, 4);
+    s->nframes.assign(B, 0);
+    int rc = [&]() -> int {
+        CK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        CK(hipEventCreate(&s->ev0)); CK(hipEventCreate(&s->ev1));
+        CKR(slot_grow_audio(e, s, 480000));
+        CKR(dalloc(s->allocs, &s->gmax, (size_t)B));
+        s->featT_stride = (long)(WLX_N_FRAMES + 2) * sp.n_mels + 64;
+        s->h1_stride = (long)(WLX_N_FRAMES + 2) * d;
+        CKR(dalloc(s->allocs, &s->featT, (size_t)B * s->featT_stride));
+        CKR(dalloc(s->allocs, &s->h1, (size_t)B * s->h1_stride));
+        const size_t TB = (size_t)B * WLX_T_AUDIO;
+        CKR(dalloc(s->allocs, &s->x, TB * d));
+        CKR(dalloc(s->allocs, &s->ln, TB * d));
+        CKR(dalloc(s->allocs, &s->q, TB * d));
+        CKR(dalloc(s->allocs, &s->k, (size_t)B * WLX_T_AUDIO_PAD * d));
+        CKR(dalloc(s->allocs, &s->vt, (size_t)B * d * WLX_T_AUDIO_PAD));
+        CKR(dalloc(s->allocs, &s->attn, TB * d));
+        CKR(dalloc(s->allocs, &s->h2, TB * F));
+        CKR(dalloc(s->allocs, &s->enc16, TB * d));
+        CKR(dalloc(s->allocs, &s->enc32, TB * d));
+        CKR(dalloc(s->allocs, &s->ck, (size_t)L * B * WLX_T_AUDIO_PAD * d));
+        CKR(dalloc(s->allocs, &s->cvt, (size_t)L * B * d * WLX_T_AUDIO_PAD));
+        CKR(dalloc(s->allocs, &s->kc, (size_t)L * s->cache_rows * WLX_T_TEXT * d));
+        CKR(dalloc(s->allocs, &s->vc, (size_t)L * s->cache_rows * WLX_T_TEXT * d));
+        const int RC = s->rows_cap;
+        CKR(dalloc(s->allocs, &s->xd, (size_t)RC * d));
+        CKR(dalloc(s->allocs, &s->qd, (size_t)RC * d));
+        CKR(dalloc(s->allocs, &s->attnd, (size_t)RC * d));
+        CKR(dalloc(s->allocs, &s->hd, (size_t)RC * F));
+        CKR(dalloc(s->allocs, &s->part_o, (size_t)s->groups_cap * e->H * WLX_XSPLIT * 16 * 64));
+        CKR(dalloc(s->allocs, &s->part_ml, (size_t)s->groups_cap * e->H * WLX_XSPLIT * 16 * 2));
+        s->ldl = ((sp.vocab + 15) / 16) * 16;
+        CKR(dalloc(s->allocs, &s->logits, (size_t)RC * s->ldl));
+        CKR(dalloc(s->allocs, &s->d_token, (size_t)RC));
+        CKR(dalloc(s->allocs, &s->d_pos, (size_t)RC));
+        CKR(dalloc(s->allocs, &s->d_cache, (size_t)RC));
+        CKR(dalloc(s->allocs, &s->d_ancrow, (size_t)RC));
+        CKR(dalloc(s->allocs, &s->d_group_item, (size_t)RC));
+        const int CR = std::max(s->cache_rows, RC);
+        CKR(dalloc(s->allocs, &s->d_anc, (size_t)CR * WLX_T_TEXT));
+        CKR(dalloc(s->allocs, &s->d_intok, (size_t)CR * WLX_T_TEXT));
+        SearchState& st = s->st;
+        CKR(dalloc(s->allocs, &st.step, 1)); CKR(dalloc(s->allocs, &st.done, 1)); CKR(dalloc(s->allocs, &st.n_finished, 1));
+        CKR(dalloc(s->allocs, &st.item_done, (size_t)B)); CKR(dalloc(s->allocs, &st.plen, (size_t)B));
+        CKR(dalloc(s->allocs, &st.cum, (size_t)RC)); CKR(dalloc(s->allocs, &st.row_done, (size_t)RC));
+        CKR(dalloc(s->allocs, &st.cand_score, (size_t)RC * WLX_MAX_CAND));
+        CKR(dalloc(s->allocs, &st.cand_tok, (size_t)RC * WLX_MAX_CAND));
+        CKR(dalloc(s->allocs, &st.samp_tok, (size_t)RC)); CKR(dalloc(s->allocs, &st.samp_lp, (size_t)RC));
+        CKR(dalloc(s->allocs, &st.hyp_tokens, (size_t)B * WLX_MAX_HYP * WLX_T_TEXT));
+        CKR(dalloc(s->allocs, &st.hyp_len, (size_t)B * WLX_MAX_HYP));
+        CKR(dalloc(s->allocs, &st.hyp_score, (size_t)B * WLX_MAX_HYP));
+        CKR(dalloc(s->allocs, &st.n_hyp, (size_t)B)); CKR(dalloc(s->allocs, &st.no_speech, (size_t)B));
+        CKR(dalloc(s->allocs, &st.nsp_row, (size_t)RC));
+        st.token = s->d_token; st.pos = s->d_pos; st.anc = s->d_anc; st.intok = s->d_intok;
+        CKR(dalloc(s->allocs, &s->d_sp, 1));
+        CKR(dalloc(s->allocs, &s->d_suppress, (size_t)(1024 * 52 / 32)));
+        CKR(dalloc(s->allocs, &s->d_lang_ids, 256));
+        CKR(dalloc(s->allocs, &s->d_probs, (size_t)B * 256));
+        CKR(dalloc(s->allocs, &s->d_tokprob, (size_t)RC));
+        s->h_stage_ints = 1 << 16;
+        CK(hipHostMalloc(reinterpret_cast<void**>(&s->h_stage), s->h_stage_ints * sizeof(int), hipHostMallocDefault));
+        CK(hipDeviceSynchronize());
+        return WLX_OK;
+    }();
+    if (rc != WLX_OK) { slot_free(s); return rc; }
+    std::lock_guard<std::mutex> g(e->mu);
+    int id = -1;
+    for (size_t i = 0; i < e->slots.size(); ++i) if (!e->slots[i]) { id = (int)i; break; }
+    if (id < 0) { e->slots.push_back(nullptr); id = (int)e->slots.size() - 1; }
+    e->slots[id] = s;
+    *slot_out = id;
+    return WLX_OK;
+}
+
+extern "C" int32_t wlx_slot_destroy(wlx_engine* e, int32_t slot) {
+    Slot* s;
+    CKR(slot_get(e, slot, &s));
+    CK(hipSetDevice(e->device));
+    CK(hipStreamSynchronize(s->stream));
+    {
+        std::lock_guard<std::mutex> g(e->mu);
+        e->slots[slot] = nullptr;
+    }
+    slot_free(s);
+    return WLX_OK;
+}
+
+extern "C" int32_t wlx_sync(wlx_engine* e, int32_t slot) {
+    Slot* s;
+    CKR(slot_get(e, slot, &s));
+    CK(hipSetDevice(e->device));
+    CK(hipStreamSynchronize(s->stream));
+    return WLX_OK;
+}
+
+extern "C" int32_t wlx_timings_get(wlx_engine* e, int32_t slot, wlx_timings* out) {
+    Slot* s;
+    CKR(slot_get(e, slot, &s));
+    if (!out) return fail(WLX_ERR_ARG, "null out");
+    *out = s->tm;
+    return WLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// log-mel
+extern "C" int32_t wlx_logmel(wlx_engine* e, int32_t slot, int32_t item, const float* pcm, int64_t n,
+                              int32_t* n_frames_out) {
+    Slot* s;
+    CKR(slot_get(e, slot, &s));
+    if (!pcm || n <= 0) return fail(WLX_ERR_ARG, "empty audio");
+    if (item < 0 || item >= s->B) return fail(WLX_ERR_ARG, "bad item %d", item);
+    if (n > 16000LL * 3600) return fail(WLX_ERR_ARG, "audio chunk too long");
+    CK(hipSetDevice(e->device));
+    CKR(slot_grow_audio(e, s, (size_t)n));
+    const int T = (int)((n + 160) / 160);
+    float* dp = s->pcm + (size_t)item * s->pcm_cap;
+    float* df = s->feats + (size_t)item * e->spec.n_mels * s->feat_ld;
+    CK(hipEventRecord(s->ev0, s->stream));
+    CK(hipMemcpyAsync(dp, pcm, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    launch_logmel(dp, (long)n, e->spec.n_mels, e->lm, df, s->feat_ld, T, s->gmax + item, s->stream);
+    CK(hipGetLastError());
+    CK(hipEventRecord(s->ev1, s->stream));
+    CK(hipStreamSynchronize(s->stream));   // the caller's PCM buffer may be reused after return
+    CK(hipEventElapsedTime(&s->tm.logmel_ms, s->ev0, s->ev1));
+    s->nframes[item] = T;
+    if (n_frames_out) *n_frames_out = T;
+    return WLX_OK;
+}
+
+extern "C" int32_t wlx_features_get(wlx_engine* e, int32_t slot, int32_t item, float* out, int64_t cap_floats,
+                                    int32_t* n_frames_out) {
+    Slot* s;
+    CKR(slot_get(e, slot, &s));
+    if (item < 0 || item >= s->B) return fail(WLX_ERR_ARG, "bad item");
+    const int T = s->nframes[item], nm = e->spec.n_mels;
+    if (n_frames_out) *n_frames_out = T;
+    if (!out) return WLX_OK;
+    if ((int64_t)T * nm > cap_floats) return fail(WLX_ERR_ARG, "output buffer too small");
+    CK(hipSetDevice(e->device));
+    const float* df = s->feats + (size_t)item * nm * s->feat_ld;
+    CK(hipMemcpy2DAsync(out, (size_t)T * 4, df, (size_t)s->feat_ld * 4, (size_t)T * 4, nm, hipMemcpyDeviceToHost, s->stream));
+    CK(hipStreamSynchronize(s->stream));
+    return WLX_OK;
+}
+
+extern "C" int32_t wlx_features_set(wlx_engine* e, int32_t slot, int32_t item, const float* feats,
+                                    int32_t n_mels, int32_t n_frames) {
+    Slot* s;
+    CKR(slot_get(e, slot, &s));
+    if (item < 0 || item >= s->B || !feats) return fail(WLX_ERR_ARG, "bad item / null");
+    if (n_mels != e->spec.n_mels || n_frames < 1) return fail(WLX_ERR_ARG, "features must be [%d, T>=1]", e->spec.n_mels);
+    CK(hipSetDevice(e->device));
+    CKR(slot_grow_audio(e, s, (size_t)n_frames * 160));
+    float* df = s->feats + (size_t)item * n_mels * s->feat_ld;
+    CK(hipMemcpy2DAsync(df, (size_t)s->feat_ld * 4, feats, (size_t)n_frames * 4, (size_t)n_frames * 4, n_mels,
+                        hipMemcpyHostToDevice, s->stream));
+    CK(hipStreamSynchronize(s->stream));
+    s->nframes[item] = n_frames;
+    return WLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// encoder
+extern "C" int32_t wlx_encode(wlx_engine* e, int32_t slot, int32_t batch, const int32_t* seek, const int32_t* seg) {
+    Slot* s;
+    CKR(slot_get(e, slot, &s));
+    if (batch < 1 || batch > s->B) return fail(WLX_ERR_ARG, "batch %d out of range (slot max %d)", batch, s->B);
+    const wlx_spec& sp = e->spec;
+    const int d = sp.d_model, F = sp.ffn, nm = sp.n_mels, H = e->H, T = WLX_T_AUDIO;
+    CK(hipSetDevice(e->device));
+    hipStream_t st = s->stream;
+    CK(hipEventRecord(s->ev0, st));
+    for (int b = 0; b < batch; ++b) {
+        const int sk = seek ? seek[b] : 0;
+        int sg = seg ? seg[b] : (s->nframes[b] - sk);
+        if (sk < 0 || sg < 0 || sk + sg > s->nframes[b])
+            return fail(WLX_ERR_ARG, "item %d: window [%d,%d) outside %d feature frames", b, sk, sk + sg, s->nframes[b]);
+        if (sg > WLX_N_FRAMES) sg = WLX_N_FRAMES;
+        launch_prep_window(s->feats + (size_t)b * nm * s->feat_ld, s->feat_ld, nm, sk, sg,
+                           s->featT + (size_t)b * s->featT_stride, st);
+    }
+    GemmParams g{};
+    // conv1 (k=3, s=1, p=1) + GELU: K-row of frame t = featT rows t..t+2 (row 0 / 3001 are the zero pad)
+    g.A = s->featT; g.lda = nm; g.strideA = s->featT_stride; g.Wp = e->conv1_w; g.KT = e->conv1_KT;
+    g.M = WLX_N_FRAMES; g.N = d; g.mode = GEMM_GELU_F16; g.bias = e->conv1_b;
+    g.C = s->h1 + d; g.ldc = d; g.strideC = s->h1_stride;
+    launch_gemm(g, batch, st);
+    // conv2 (k=3, s=2, p=1) + GELU + sinusoidal positions -> fp32 residual stream
+    g = GemmParams{};
+    g.A = s->h1; g.lda = 2 * d; g.strideA = s->h1_stride; g.Wp = e->conv2_w; g.KT = 3 * d / 32;
+    g.M = T; g.N = d; g.mode = GEMM_GELU_POS_F32; g.bias = e->conv2_b;
+    g.X = s->x; g.ldx = d; g.strideX = (long)T * d; g.pos = e->enc_pos;
+    launch_gemm(g, batch, st);
+    const int M = batch * T;
+    for (int l = 0; l < sp.enc_layers; ++l) {
+        const EncLayerW& w = e->enc[l];
+        launch_layernorm_f16(s->x, d, w.ln1_g, w.ln1_b, s->ln, d, M, d, st);
+        g = GemmParams{};
+        g.A = s->ln; g.lda = d; g.Wp = w.Wqkv; g.KT = d / 32; g.M = M; g.N = 3 * d; g.mode = GEMM_QKV; g.bias = w.bqkv;
+        g.C = s->q; g.ldc = d; g.d = d; g.qscale = 0.125f; g.Kout = s->k; g.ldk = d; g.Vt = s->vt; g.ldvt = WLX_T_AUDIO_PAD;
+        g.rows_per_item = T; g.kv_item_stride_k = (long)WLX_T_AUDIO_PAD * d; g.kv_item_stride_v = (long)d * WLX_T_AUDIO_PAD;
+        launch_gemm(g, 1, st);
+        launch_attn_encoder(s->q, d, s->k, d, s->vt, WLX_T_AUDIO_PAD, s->attn, d, T, H, batch, (long)T * d,
+                            (long)WLX_T_AUDIO_PAD * d, (long)d * WLX_T_AUDIO_PAD, (long)T * d, st);
+        g = GemmParams{};
+        g.A = s->attn; g.lda = d; g.Wp = w.Wo; g.KT = d / 32; g.M = M; g.N = d; g.mode = GEMM_RESID_F32; g.bias = w.bo;
+        g.X = s->x; g.ldx = d;
+        launch_gemm(g, 1, st);
+        launch_layernorm_f16(s->x, d, w.ln2_g, w.ln2_b, s->ln, d, M, d, st);
+        g = GemmParams{};
+        g.A = s->ln; g.lda = d; g.Wp = w.W1; g.KT = d / 32; g.M = M; g.N = F; g.mode = GEMM_GELU_F16; g.bias = w.b1;
+        g.C = s->h2; g.ldc = F;
+        launch_gemm(g, 1, st);
+        g = GemmParams{};
+        g.A = s->h2; g.lda = F; g.Wp = w.W2; g.KT = F / 32; g.M = M; g.N = d; g.mode = GEMM_RESID_F32; g.bias = w.b2;
+        g.X = s->x; g.ldx = d;
+        launch_gemm(g, 1, st);
+    }
+    launch_layernorm_f16_f32(s->x, d, e->enc_ln_g, e->enc_ln_b, s->enc16, s->enc32, d, M, d, st);
+    // cross-attention K/V of every decoder layer in one GEMM (N = L*2d)
+    g = GemmParams{};
+    g.A = s->enc16; g.lda = d; g.Wp = e->Wckv; g.KT = d / 32; g.M = M; g.N = sp.dec_layers * 2 * d; g.mode = GEMM_CROSS_KV;
+    g.bias = e->bckv; g.d = d; g.Kout = s->ck; g.ldk = d; g.Vt = s->cvt; g.ldvt = WLX_T_AUDIO_PAD; g.rows_per_item = T;
+    g.kv_item_stride_k = (long)WLX_T_AUDIO_PAD * d; g.kv_item_stride_v = (long)d * WLX_T_AUDIO_PAD;
+    g.kv_layer_stride_k = (long)s->B * WLX_T_AUDIO_PAD * d; g.kv_layer_stride_v = (long)s->B * d * WLX_T_AUDIO_PAD;
+    launch_gemm(g, 1, st);
+    CK(hipGetLastError());
+    CK(hipEventRecord(s->ev1, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipEventElapsedTime(&s->tm.encode_ms, s->ev0, s->ev1));
+    s->enc_batch = batch;
+    return WLX_OK;
+}
+
+extern "C" int32_t wlx_encoder_output_get(wlx_engine* e, int32_t slot, int32_t item, float* out, int64_t cap_floats) {
+    Slot* s;
+    CKR(slot_get(e, slot, &s));
+    if (item < 0 || item >= s->enc_batch) return fail(WLX_ERR_STATE, "item %d not encoded", item);
+    const size_t n = (size_t)WLX_T_AUDIO * e->spec.d_model;
+    if (!out || (int64_t)n > cap_floats) return fail(WLX_ERR_ARG, "output buffer too small");
+    CK(hipSetDevice(e->device));
+    CK(hipMemcpyAsync(out, s->enc32 + (size_t)item * n, n * 4, hipMemcpyDeviceToHost, s->stream));
+    CK(hipStreamSynchronize(s->stream));
+    return WLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// decoder pass: embed -> L x {self-attn block, cross-attn block, MLP} -> (final LN + vocab projection)
+// Row tables / ancestry must already be on the device. `rows` live rows in `groups` groups of R rows.
+static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool with_logits, bool check_done) {
+    const wlx_spec& sp = e->spec;
+    const int d = sp.d_model, F = sp.ffn, H = e->H;
+    hipStream_t st = s->stream;
+    const int* done = check_done ? s->st.done : nullptr;
+    RowTables rt{s->d_token, s->d_pos, s->d_cache, s->d_ancrow, s->d_anc, s->d_intok};
+    launch_dec_embed(e->tok_emb16, e->dec_pos, d, rt, rows, s->xd, done, st);
+    const long crs = (long)WLX_T_TEXT * d;
+    for (int l = 0; l < sp.dec_layers; ++l) {
+        const DecLayerW& w = e->dec[l];
+        half_t* kc = s->kc + (size_t)l * s->cache_rows * crs;
+        half_t* vc = s->vc + (size_t)l * s->cache_rows * crs;
+        GemvParams p{};
+        // LN1 + QKV, K/V appended to the self-attention cache
+        p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_QKV; p.M = rows; p.K = d; p.KT = d / 32; p.N = 3 * d;
+        p.Wp = w.Wqkv; p.bias = w.bqkv; p.X = s->xd; p.ldx = d; p.gamma = w.ln1_g; p.beta = w.ln1_b;
+        p.Yh = s->qd; p.ldyh = d; p.d = d; p.qscale = 0.125f; p.Kc = kc; p.Vc = vc; p.cache_row_stride = crs;
+        p.row_cache = s->d_cache; p.row_pos = s->d_pos; p.done = done;
+        launch_dec_gemv(p, st);
+        launch_dec_self_attn(s->qd, d, kc, vc, crs, d, H, rt, rows, s->attnd, d, done, st);
+        p = GemvParams{};
+        p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
+        p.Wp = w.Wo; p.bias = w.bo; p.Xh = s->attnd; p.ldxh = d; p.Xres = s->xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
+        launch_dec_gemv(p, st);
+        // LN2 + cross-attention query
+        p = GemvParams{};
+        p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_F16; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
+        p.Wp = w.Wcq; p.bias = w.bcq; p.X = s->xd; p.ldx = d; p.gamma = w.ln2_g; p.beta = w.ln2_b;
+        p.Yh = s->qd; p.ldyh = d; p.qscale = 0.125f; p.done = done;
+        launch_dec_gemv(p, st);
+        launch_dec_cross_attn(s->qd, d, s->ck + (size_t)l * s->B * WLX_T_AUDIO_PAD * d, d, (long)WLX_T_AUDIO_PAD * d,
+                              s->cvt + (size_t)l * s->B * d * WLX_T_AUDIO_PAD, WLX_T_AUDIO_PAD, (long)d * WLX_T_AUDIO_PAD,
+                              H, R, groups, rows, s->d_group_item, s->part_o, s->part_ml, done, st);
+        p = GemvParams{};
+        p.in_mode = GEMV_IN_XATTN; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
+        p.Wp = w.Wco; p.bias = w.bco; p.part_o = s->part_o; p.part_ml = s->part_ml; p.H = H; p.R = R;
+        p.Xres = s->xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
+        launch_dec_gemv(p, st);
+        // LN3 + MLP
+        p = GemvParams{};
+        p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_GELU_F16; p.M = rows; p.K = d; p.KT = d / 32; p.N = F;
+        p.Wp = w.W1; p.bias = w.b1; p.X = s->xd; p.ldx = d; p.gamma = w.ln3_g; p.beta = w.ln3_b;
+        p.Yh = s->hd; p.ldyh = F; p.qscale = 1.f; p.done = done;
+        launch_dec_gemv(p, st);
+        p = GemvParams{};
+        p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = F; p.KT = F / 32; p.N = d;
+        p.Wp = w.W2; p.bias = w.b2; p.Xh = s->hd; p.ldxh = F; p.Xres = s->xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
+        launch_dec_gemv(p, st);
+    }
+    if (with_logits) {
+        GemvParams p{};
+        p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_F32; p.M = rows; p.K = d; p.KT = d / 32; p.N = sp.vocab;
+        p.Wp = e->Wvocab; p.bias = nullptr; p.X = s->xd; p.ldx = d; p.gamma = e->dec_ln_g; p.beta = e->dec_ln_b;
+        p.Y = s->logits; p.ldy = s->ldl; p.qscale = 1.f; p.done = done;
+        launch_dec_gemv(p, st);
+    }
+}
+
+// upload row tables for a pass: token/pos/cache/ancrow [rows], group_item [groups]
+static int upload_rows(Slot* s, const std::vector<int>& token, const std::vector<int>& pos,
+                       const std::vector<int>& cache, const std::vector<int>& ancrow, const std::vector<int>& group_item) {
+    const size_t rows = token.size(), ng = group_item.size();
+    if (4 * rows + ng > s->h_stage_ints) return fail(WLX_ERR_ARG, "row table too large");
+    CK(hipStreamSynchronize(s->stream));   // staging buffer reuse
+    int* h = s->h_stage;
+    memcpy(h, token.data(), rows * 4); memcpy(h + rows, pos.data(), rows * 4);
+    memcpy(h + 2 * rows, cache.data(), rows * 4); memcpy(h + 3 * rows, ancrow.data(), rows * 4);
+    memcpy(h + 4 * rows, group_item.data(), ng * 4);
+    CK(hipMemcpyAsync(s->d_token, h, rows * 4, hipMemcpyHostToDevice, s->stream));
+    CK(hipMemcpyAsync(s->d_pos, h + rows, rows * 4, hipMemcpyHostToDevice, s->stream));
+    CK(hipMemcpyAsync(s->d_cache, h + 2 * rows, rows * 4, hipMemcpyHostToDevice, s->stream));
+    CK(hipMemcpyAsync(s->d_ancrow, h + 3 * rows, rows * 4, hipMemcpyHostToDevice, s->stream));
+    CK(hipMemcpyAsync(s->d_group_item, h + 4 * rows, ng * 4, hipMemcpyHostToDevice, s->stream));
+    return WLX_OK;
+}
+
+// prefill `n` tokens of one sequence (audio item `item`, KV-cache row `crow`) starting at position pos0,
+// in chunks of <= 64 rows; if logits_out != null the vocabulary projection runs and rows are copied out.
+static int prefill_tokens(Engine* e, Slot* s, int item, int crow, const int* tokens, int pos0, int n,
+                          float* logits_host, int nsp_index, int nsp_token, float* nsp_out) {
+    for (int c0 = 0; c0 < n; c0 += 64) {
+        const int rows = std::min(64, n - c0);
+        const int groups = (rows + 15) / 16;
+        std::vector<int> tk(rows), ps(rows), ca(rows, crow), an(rows, crow), gi(groups, item);
+        for (int i = 0; i < rows; ++i) { tk[i] = tokens[c0 + i]; ps[i] = pos0 + c0 + i; }
+        CKR(upload_rows(s, tk, ps, ca, an, gi));
+        const bool want_nsp = nsp_index >= c0 && nsp_index < c0 + rows;
+        const bool lg = (logits_host != nullptr) || want_nsp;
+        decoder_pass(e, s, rows, 16, groups, lg, false);
+        CK(hipGetLastError());
+        if (logits_host) {
+            CK(hipMemcpy2DAsync(logits_host + (size_t)c0 * e->spec.vocab, (size_t)e->spec.vocab * 4, s->logits,
+                                (size_t)s->ldl * 4, (size_t)e->spec.vocab * 4, rows, hipMemcpyDeviceToHost, s->stream));
+        }
+        if (want_nsp) {
+            launch_token_prob(s->logits + (size_t)(nsp_index - c0) * s->ldl, s->ldl, e->spec.vocab, 1, nsp_token,
+                              s->d_tokprob, s->stream);
+            CK(hipMemcpyAsync(nsp_out, s->d_tokprob, 4, hipMemcpyDeviceToDevice, s->stream));
+        }
+    }
+    return WLX_OK;
+}
+
+// identity ancestry for cache row `crow` over positions [0, upto)
+static int set_anc_rows(Slot* s, const std::vector<short>& anc_host, int first_row, int nrows) {
+    CK(hipMemcpyAsync(s->d_anc + (size_t)first_row * WLX_T_TEXT, anc_host.data(), (size_t)nrows * WLX_T_TEXT * sizeof(short),
+                      hipMemcpyHostToDevice, s->stream));
+    CK(hipStreamSynchronize(s->stream));   // anc_host is caller stack memory
+    return WLX_OK;
+}
+
+static int get_step_graph(Engine* e, Slot* s, int rows, int R, int groups, hipGraphExec_t* out) {
+    StepGraphKey key{rows, R, groups};
+    auto it = s->graphs.find(key);
+    if (it != s->graphs.end()) { *out = it->second; return WLX_OK; }
+    hipGraph_t graph;
+    CK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+    decoder_pass(e, s, rows, R, groups, true, true);
+    launch_search_rows(s->logits, s->d_sp, rows, s->st, s->stream);
+    launch_search_update(s->d_sp, groups, s->st, s->stream);
+    CK(hipStreamEndCapture(s->stream, &graph));
+    hipGraphExec_t exec;
+    CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    CK(hipGraphDestroy(graph));
+    s->graphs[key] = exec;
+    *out = exec;
+    return WLX_OK;
+}
+
+static int run_step(Engine* e, Slot* s, int rows, int R, int groups) {
+    if (e->use_graph) {
+        hipGraphExec_t exec;
+        CKR(get_step_graph(e, s, rows, R, groups, &exec));
+        CK(hipGraphLaunch(exec, s->stream));
+    } else {
+        decoder_pass(e, s, rows, R, groups, true, true);
+        launch_search_rows(s->logits, s->d_sp, rows, s->st, s->stream);
+        launch_search_update(s->d_sp, groups, s->st, s->stream);
+        CK(hipGetLastError());
+    }
+    return WLX_OK;
+}
+
+static int fill_search_params(Engine* e, Slot* s, int batch, int R, const wlx_gen_opts* o, bool apply_ts, SearchParams* sp) {
+    memset(sp, 0, sizeof(*sp));
+    sp->V = e->spec.vocab; sp->ldl = s->ldl; sp->items = batch; sp->R = R; sp->rows = batch * R;
+    sp->sampling = (o->sampling_temperature > 0.f || o->beam_size <= 1) ? 1 : 0;
+    sp->beam = sp->sampling ? 1 : o->beam_size;
+    sp->ncand = sp->sampling ? 1 : 2 * o->beam_size;
+    sp->max_cand_hyp = std::max(1, (int)std::lround((double)o->beam_size * (double)o->patience));
+    sp->num_hyp = std::max(1, o->num_hypotheses);
+    sp->allow_early_exit = (o->length_penalty == 0.f) ? 1 : 0;
+    sp->length_penalty = o->length_penalty; sp->rep_penalty = (o->repetition_penalty > 0.f) ? o->repetition_penalty : 1.f;
+    sp->temperature = o->sampling_temperature; sp->no_repeat_ngram = o->no_repeat_ngram_size;
+    sp->topk = (o->sampling_temperature > 0.f) ? o->sampling_topk : 1;
+    sp->suppress_blank = o->suppress_blank; sp->apply_ts_rules = apply_ts ? 1 : 0;
+    sp->max_initial_ts = o->max_initial_timestamp_index;
+    sp->sot = o->ids.sot; sp->eot = o->ids.eot; sp->no_timestamps = o->ids.no_timestamps; sp->ts_begin = o->ids.timestamp_begin;
+    sp->no_speech = o->ids.no_speech; sp->blank = o->ids.blank;
+    sp->max_length = o->max_length; sp->seed = o->seed; sp->suppress_mask = s->d_suppress;
+    return WLX_OK;
+}
+
+static int validate_opts(Engine* e, Slot* s, int batch, const wlx_gen_opts* o) {
+    if (!o) return fail(WLX_ERR_ARG, "null opts");
+    const int V = e->spec.vocab;
+    auto bad = [&](int id) { return id < 0 || id >= V; };
+    if (bad(o->ids.sot) || bad(o->ids.eot) || bad(o->ids.no_timestamps) || bad(o->ids.timestamp_begin) || bad(o->ids.no_speech))
+        return fail(WLX_ERR_ARG, "token ids out of vocabulary");
+    if (o->max_length < 2 || o->max_length > WLX_T_TEXT) return fail(WLX_ERR_ARG, "max_length must be 2..448");
+    const bool sampling = (o->sampling_temperature > 0.f || o->beam_size <= 1);
+    const int R = sampling ? std::max(1, o->num_hypotheses) : o->beam_size;
+    if (R < 1 || R > s->R) return fail(WLX_ERR_ARG, "beam_size/num_hypotheses %d exceeds slot rows per item %d", R, s->R);
+    if (!sampling && o->num_hypotheses > o->beam_size) return fail(WLX_ERR_ARG, "num_hypotheses > beam_size");
+    if (!sampling && 2 * o->beam_size > WLX_MAX_CAND) return fail(WLX_ERR_ARG, "beam_size too large");
+    if (batch * R > s->rows_cap) return fail(WLX_ERR_ARG, "too many decoder rows");
+    if (o->n_suppress_tokens < 0 || (o->n_suppress_tokens > 0 && !o->suppress_tokens)) return fail(WLX_ERR_ARG, "bad suppress_tokens");
+    return WLX_OK;
+}
+
+static int upload_suppress(Engine* e, Slot* s, const wlx_gen_opts* o) {
+    const int V = e->spec.vocab, words = (V + 31) / 32;
+    std::vector<unsigned> mask(words, 0u);
+    for (int i = 0; i < o->n_suppress_tokens; ++i) {
+        const int id = o->suppress_tokens[i];
+        if (id >= 0 && id < V) mask[id >> 5] |= 1u << (id & 31);
+    }
+    CK(hipMemcpyAsync(s->d_suppress, mask.data(), words * 4, hipMemcpyHostToDevice, s->stream));
+    CK(hipStreamSynchronize(s->stream));
+    return WLX_OK;
+}
+
+struct HypOut { std::vector<int> tokens; float score; };
+
+static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, const int32_t* plens, int pstride,
+                         const wlx_gen_opts* o, bool injected_logits, const float* inj, int inj_steps,
+                         int32_t* tokens_out, int tstride, int32_t* n_tokens_out, float* scores_out, float* nsp_out) {
+    CKR(validate_opts(e, s, batch, o));
+    const bool sampling = (o->sampling_temperature > 0.f || o->beam_size <= 1);
+    const int R = sampling ? std::max(1, o->num_hypotheses) : o->beam_size;
+    const int rows = batch * R, V = e->spec.vocab;
+    hipStream_t st = s->stream;
+    int max_steps = 0;
+    bool apply_ts = true;
+    for (int b = 0; b < batch; ++b) {
+        const int pl = plens[b];
+        if (pl < 1 || pl >= o->max_length) return fail(WLX_ERR_ARG, "item %d: prompt length %d vs max_length %d", b, pl, o->max_length);
+        const int32_t* pr = prompts + (size_t)b * pstride;
+        for (int i = 0; i < pl; ++i) {
+            if (pr[i] < 0 || pr[i] >= V) return fail(WLX_ERR_ARG, "prompt token out of vocabulary");
+            if (pr[i] == o->ids.no_timestamps) apply_ts = false;   // CT2: timestamp rules only without <|notimestamps|>
+        }
+        max_steps = std::max(max_steps, o->max_length - pl);
+    }
+    CK(hipEventRecord(s->ev0, st));
+    CKR(upload_suppress(e, s, o));
+    SearchParams sp;
+    CKR(fill_search_params(e, s, batch, R, o, apply_ts, &sp));
+    CK(hipMemcpyAsync(s->d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, st));
+    // ---- reset search state
+    SearchState& S = s->st;
+    CK(hipMemsetAsync(S.step, 0, 4, st)); CK(hipMemsetAsync(S.done, 0, 4, st)); CK(hipMemsetAsync(S.n_finished, 0, 4, st));
+    CK(hipMemsetAsync(S.item_done, 0, (size_t)batch * 4, st)); CK(hipMemsetAsync(S.n_hyp, 0, (size_t)batch * 4, st));
+    CK(hipMemsetAsync(S.row_done, 0, (size_t)rows * 4, st)); CK(hipMemsetAsync(S.no_speech, 0, (size_t)batch * 4, st));
+    CK(hipMemsetAsync(S.hyp_len, 0, (size_t)batch * WLX_MAX_HYP * 4, st));
+    std::vector<float> cum(rows);
+    std::vector<int> nsp(rows, 0), pl(batch);
+    std::vector<short> anc((size_t)rows * WLX_T_TEXT, 0);
+    for (int b = 0; b < batch; ++b) {
+        pl[b] = plens[b];
+        for (int r = 0; r < R; ++r) {
+            const int row = b * R + r;
+            cum[row] = (sampling || r == 0) ? 0.f : -INFINITY;
+            short* a = anc.data() + (size_t)row * WLX_T_TEXT;
+            for (int p = 0; p < pl[b] - 1; ++p) a[p] = (short)(b * R);   // prompt K/V live in the item's first cache row
+            a[pl[b] - 1] = (short)row;
+        }
+    }
+    CK(hipMemcpyAsync(S.cum, cum.data(), rows * 4, hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(S.plen, pl.data(), batch * 4, hipMemcpyHostToDevice, st));
+    CKR(set_anc_rows(s, anc, 0, rows));
+    // ---- prefill prompt[0 .. plen-2]; no_speech_prob is read at the sot position
+    if (!injected_logits) {
+        for (int b = 0; b < batch; ++b) {
+            const int32_t* pr = prompts + (size_t)b * pstride;
+            int sot_idx = -1;
+            for (int i = 0; i < pl[b]; ++i) if (pr[i] == o->ids.sot) sot_idx = i;
+            if (sot_idx == pl[b] - 1) { for (int r = 0; r < (sampling ? R : 1); ++r) nsp[b * R + r] = (r == 0) ? 1 : 0; }
+            if (pl[b] > 1)
+                CKR(prefill_tokens(e, s, b, b * R, pr, 0, pl[b] - 1, nullptr, (sot_idx >= 0 && sot_idx < pl[b] - 1) ? sot_idx : -1,
+                                   o->ids.no_speech, S.no_speech + b));
+        }
+    }
+    // ---- decode rows
+    {
+        std::vector<int> tk(rows), ps(rows), ca(rows), an(rows), gi(batch);
+        for (int b = 0; b < batch; ++b) {
+            gi[b] = b;
+            for (int r = 0; r < R; ++r) {
+                const int row = b * R + r;
+                tk[row] = prompts[(size_t)b * pstride + pl[b] - 1]; ps[row] = pl[b] - 1; ca[row] = row; an[row] = row;
+            }
+        }
+        CKR(upload_rows(s, tk, ps, ca, an, gi));
+        CK(hipMemcpyAsync(S.nsp_row, nsp.data(), rows * 4, hipMemcpyHostToDevice, st));
+        CK(hipStreamSynchronize(st));
+    }
+    // ---- autoregressive loop: one graph replay per step, host looks at the done flag every few steps
+    int* h_done = s->h_stage + (s->h_stage_ints - 4);
+    *h_done = 0;
+    int steps_run = 0;
+    const int CHK = 4;
+    for (int step = 0; step < max_steps; ++step) {
+        if (injected_logits) {
+            if (step >= inj_steps) break;
+            // test hook: logits come from the caller; the embed kernel still records the fed tokens
+            RowTables rt{s->d_token, s->d_pos, s->d_cache, s->d_ancrow, s->d_anc, s->d_intok};
+            launch_dec_embed(e->tok_emb16, e->dec_pos, e->spec.d_model, rt, rows, s->xd, nullptr, st);
+            CK(hipMemcpy2DAsync(s->logits, (size_t)s->ldl * 4, inj + (size_t)step * rows * V, (size_t)V * 4, (size_t)V * 4, rows,
+                                hipMemcpyHostToDevice, st));
+            launch_search_rows(s->logits, s->d_sp, rows, s->st, st);
+            launch_search_update(s->d_sp, batch, s->st, st);
+            CK(hipGetLastError());
+        } else {
+            CKR(run_step(e, s, rows, R, batch));
+        }
+        ++steps_run;
+        if ((step + 1) % CHK == 0 || step == max_steps - 1 || injected_logits) {
+            CK(hipMemcpyAsync(h_done, S.done, 4, hipMemcpyDeviceToHost, st));
+            CK(hipStreamSynchronize(st));
+            if (*h_done) break;
+        }
+    }
+    CK(hipStreamSynchronize(st));
+    // ---- results
+    std::vector<int> n_hyp(batch), hyp_len((size_t)batch * WLX_MAX_HYP);
+    std::vector<float> hyp_score((size_t)batch * WLX_MAX_HYP), nspv(batch);
+    std::vector<int> hyp_tok((size_t)batch * WLX_MAX_HYP * WLX_T_TEXT);
+    CK(hipMemcpy(n_hyp.data(), S.n_hyp, batch * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hyp_len.data(), S.hyp_len, hyp_len.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hyp_score.data(), S.hyp_score, hyp_score.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(hyp_tok.data(), S.hyp_tokens, hyp_tok.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(nspv.data(), S.no_speech, batch * 4, hipMemcpyDeviceToHost));
+    int step_dev = 0;
+    CK(hipMemcpy(&step_dev, S.step, 4, hipMemcpyDeviceToHost));
+    const int NH = std::max(1, o->num_hypotheses);
+    for (int b = 0; b < batch; ++b) {
+        std::vector<int> order(std::min(n_hyp[b], WLX_MAX_HYP));
+        for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+        std::stable_sort(order.begin(), order.end(), [&](int a, int c) {
+            return hyp_score[(size_t)b * WLX_MAX_HYP + a] > hyp_score[(size_t)b * WLX_MAX_HYP + c];
+        });
+        for (int h = 0; h < NH; ++h) {
+            int32_t* dst = tokens_out + ((size_t)b * NH + h) * tstride;
+            if (h < (int)order.size()) {
+                const int src = order[h];
+                int len = hyp_len[(size_t)b * WLX_MAX_HYP + src];
+                if (len > tstride) len = tstride;
+                memcpy(dst, &hyp_tok[((size_t)b * WLX_MAX_HYP + src) * WLX_T_TEXT], (size_t)len * 4);
+                n_tokens_out[b * NH + h] = len;
+                scores_out[b * NH + h] = hyp_score[(size_t)b * WLX_MAX_HYP + src];
+            } else {
+                n_tokens_out[b * NH + h] = 0;
+                scores_out[b * NH + h] = -INFINITY;
+            }
+        }
+        if (nsp_out) nsp_out[b] = nspv[b];
+    }
+    CK(hipEventRecord(s->ev1, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipEventElapsedTime(&s->tm.generate_ms, s->ev0, s->ev1));
+    s->tm.decode_steps = step_dev;
+    (void)steps_run;
+    return WLX_OK;
+}
+
+extern "C" int32_t wlx_generate(wlx_engine* e, int32_t slot, int32_t batch, const int32_t* prompts,
+                                const int32_t* prompt_lens, int32_t prompt_stride, const wlx_gen_opts* opts,
+                                int32_t* tokens_out, int32_t tokens_stride, int32_t* n_tokens_out, float* scores_out,
+                                float* no_speech_prob_out) {
+    Slot* s;
+    CKR(slot_get(e, slot, &s));
+    if (!prompts || !prompt_lens || !tokens_out || !n_tokens_out || !scores_out) return fail(WLX_ERR_ARG, "null argument");
+    if (batch < 1 || batch > s->enc_batch) return fail(WLX_ERR_STATE, "generate(batch=%d) before encode(batch=%d)", batch, s->enc_batch);
+    CK(hipSetDevice(e->device));
+    return generate_impl(e, s, batch, prompts, prompt_lens, prompt_stride, opts, false, nullptr, 0, tokens_out,
+                         tokens_stride, n_tokens_out, scores_out, no_speech_prob_out);
+}
+
+extern "C" int32_t wlx_debug_search(wlx_engine* e, int32_t slot, const float* logits, int32_t steps,
+                                    const int32_t* prompt, int32_t prompt_len, const wlx_gen_opts* opts,
+                                    int32_t* tokens_out, int32_t tokens_stride, int32_t* n_tokens_out, float* scores_out) {
+    Slot* s;
+    CKR(slot_get(e, slot, &s));
+    if (!logits || !prompt || !opts) return fail(WLX_ERR_ARG, "null argument");
+    CK(hipSetDevice(e->device));
+    float nsp;
+    return generate_impl(e, s, 1, prompt, &prompt_len, prompt_len, opts, true, logits, steps, tokens_out, tokens_stride,
+                         n_tokens_out, scores_out, &nsp);
+}
+
+extern "C" int32_t wlx_detect_language(wlx_engine* e, int32_t slot, int32_t batch, int32_t sot, const int32_t* lang_ids,
+                                       int32_t n_lang, float* probs_out) {
+    Slot* s;
+    CKR(slot_get(e, slot, &s));
+    if (batch < 1 || batch > s->enc_batch) return fail(WLX_ERR_STATE, "detect_language before encode");
+    if (!lang_ids || n_lang < 1 || n_lang > 256 || !probs_out) return fail(WLX_ERR_ARG, "bad language id list");
+    if (sot < 0 || sot >= e->spec.vocab) return fail(WLX_ERR_ARG, "bad sot id");
+    for (int i = 0; i < n_lang; ++i) if (lang_ids[i] < 0 || lang_ids[i] >= e->spec.vocab) return fail(WLX_ERR_ARG, "bad language id");
+    CK(hipSetDevice(e->device));
+    hipStream_t st = s->stream;
+    // one decoder step on [sot] per item: row b -> cache row b*R (distinct per item)
+    std::vector<int> tk(batch, sot), ps(batch, 0), ca(batch), an(batch), gi(batch);
+    std::vector<short> anc((size_t)s->cache_rows * WLX_T_TEXT, 0);
+    for (int b = 0; b < batch; ++b) { ca[b] = an[b] = b * s->R; gi[b] = b; anc[(size_t)(b * s->R) * WLX_T_TEXT] = (short)(b * s->R); }
+    CKR(set_anc_rows(s, anc, 0, s->cache_rows));
+    CKR(upload_rows(s, tk, ps, ca, an, gi));
+    decoder_pass(e, s, batch, 1, batch, true, false);
+    CK(hipMemcpyAsync(s->d_lang_ids, lang_ids, (size_t)n_lang * 4, hipMemcpyHostToDevice, st));
+    launch_lang_probs(s->logits, s->ldl, batch, s->d_lang_ids, n_lang, s->d_probs, st);
+    CK(hipGetLastError());
+    CK(hipMemcpyAsync(probs_out, s->d_probs, (size_t)batch * n_lang * 4, hipMemcpyDeviceToHost, st));
+    CK(hipStreamSynchronize(st));
+    return WLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// test hooks
+extern "C" int32_t wlx_debug_logits_get(wlx_engine* e, int32_t slot, float* out, int32_t rows, int64_t cap_floats) {
+    Slot* s;
+    CKR(slot_get(e, slot, &s));
+    const int V = e->spec.vocab;
+    if (!out || rows < 1 || rows > s->rows_cap || (int64_t)rows * V > cap_floats) return fail(WLX_ERR_ARG, "bad rows/cap");
+    CK(hipSetDevice(e->device));
+    CK(hipMemcpy2DAsync(out, (size_t)V * 4, s->logits, (size_t)s->ldl * 4, (size_t)V * 4, rows, hipMemcpyDeviceToHost, s->stream));
+    CK(hipStreamSynchronize(s->stream));
+    return WLX_OK;
+}
+
+extern "C" int32_t wlx_debug_decode_logits(wlx_engine* e, int32_t slot, const int32_t* tokens, int32_t n, float* out) {
+    Slot* s;
+    CKR(slot_get(e, slot, &s));
+    if (!tokens || !out || n < 1 || n > WLX_T_TEXT) return fail(WLX_ERR_ARG, "bad tokens");
+    if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "decode before encode");
+    for (int i = 0; i < n; ++i) if (tokens[i] < 0 || tokens[i] >= e->spec.vocab) return fail(WLX_ERR_ARG, "token out of vocabulary");
+    CK(hipSetDevice(e->device));
+    std::vector<short> anc(WLX_T_TEXT, 0);   // cache row 0, identity ancestry
+    CKR(set_anc_rows(s, anc, 0, 1));
+    CKR(prefill_tokens(e, s, 0, 0, tokens, 0, n, out, -1, 0, nullptr));
+    CK(hipStreamSynchronize(s->stream));
+    return WLX_OK;
+}
+
+extern "C" int32_t wlx_debug_time_decode_step(wlx_engine* e, int32_t slot, int32_t rows, int32_t t, int32_t iters,
+                                              float* avg_ms_out) {
+    Slot* s;
+    CKR(slot_get(e, slot, &s));
+    if (rows < 1 || rows > s->cache_rows || rows > 16 || t < 0 || t >= WLX_T_TEXT || iters < 1 || !avg_ms_out)
+        return fail(WLX_ERR_ARG, "bad arguments");
+    if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "decode before encode");
+    CK(hipSetDevice(e->device));
+    hipStream_t st = s->stream;
+    // one item, `rows` beams all at position t with identity history (timing only: cache content is whatever is there)
+    std::vector<int> tk(rows, 0), ps(rows, t), ca(rows), an(rows), gi(1, 0);
+    std::vector<short> anc((size_t)rows * WLX_T_TEXT);
+    for (int r = 0; r < rows; ++r) { ca[r] = an[r] = r; for (int p = 0; p < WLX_T_TEXT; ++p) anc[(size_t)r * WLX_T_TEXT + p] = (short)r; }
+    CKR(set_anc_rows(s, anc, 0, rows));
+    CKR(upload_rows(s, tk, ps, ca, an, gi));
+    CK(hipMemsetAsync(s->st.done, 0, 4, st));
+    hipGraph_t graph; hipGraphExec_t exec;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    decoder_pass(e, s, rows, rows, 1, true, true);
+    CK(hipStreamEndCapture(st, &graph));
+    CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    CK(hipGraphDestroy(graph));
+    for (int i = 0; i < 3; ++i) CK(hipGraphLaunch(exec, st));
+    CK(hipEventRecord(s->ev0, st));
+    for (int i = 0; i < iters; ++i) CK(hipGraphLaunch(exec, st));
+    CK(hipEventRecord(s->ev1, st));
+    CK(hipStreamSynchronize(st));
+    float ms = 0.f;
+    CK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
+    *avg_ms_out = ms / (float)iters;
+    CK(hipGraphExecDestroy(exec));
+    return WLX_OK;
+}

@@ -1,0 +1,228 @@
+// gemm.hip — fp16 MFMA GEMM for the encoder (ctranslate2 Whisper.encode replacement,
+// whisper_live/transcriber/transcriber_faster_whisper.py:1339-1348) plus row LayerNorm.
+//
+// D[n][m] = sum_k W[n][k] * X[m][k]  ("swapped" operands, see common.h): weights are read as
+// pre-packed 1 KiB fragments straight into registers, activations as 16-byte row segments of a
+// row-major fp16 matrix (lda is free, which is how the two conv1d layers run without im2col:
+// a conv window of 3 consecutive time steps of a time-major activation IS one contiguous K-row
+// of length 3*C starting at row t*stride — the GEMM just uses lda = stride*C).
+// No LDS, no barriers: every operand byte comes from L2/L1, so the compiler is free to software
+// pipeline the fragment loads under the MFMAs. Wave tile = WNT x WMT 16x16 tiles; a 4-wave
+// workgroup covers (2*WNT*16) x (2*WMT*16) outputs. Epilogues are fused (bias, exact GELU,
+// positional add, residual accumulate in fp32, q-scaling, K/V scatter with V stored transposed
+// for the attention kernels).
+#include "kernels.h"
+
+namespace wlx {
+
+template <int WNT, int WMT>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int c = lane & 15, g = lane >> 4;
+    const int wn = wave & 1, wm = wave >> 1;
+    const int NT_total = (p.N + 15) >> 4;
+    const int nt0 = blockIdx.x * (2 * WNT) + wn * WNT;
+    const int m0 = blockIdx.y * (2 * WMT * 16) + wm * (WMT * 16);
+    const int z = blockIdx.z;
+    const half_t* A = p.A + (long)z * p.strideA;
+    const int KT = p.KT;
+
+    const half_t* wptr[WNT];
+    const half_t* aptr[WMT];
+#pragma unroll
+    for (int ni = 0; ni < WNT; ++ni) {
+        int nt = nt0 + ni;
+        if (nt >= NT_total) nt = NT_total - 1;
+        wptr[ni] = p.Wp + ((long)nt * KT * 64 + lane) * 8;
+    }
+#pragma unroll
+    for (int mi = 0; mi < WMT; ++mi) {
+        int row = m0 + mi * 16 + c;
+        if (row >= p.M) row = p.M - 1;
+        aptr[mi] = A + (long)row * p.lda + g * 8;
+    }
+
+    f32x4 acc[WNT][WMT];
+#pragma unroll
+    for (int ni = 0; ni < WNT; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < WMT; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    f16x8 wf[WNT], af[WMT];
+#pragma unroll
+    for (int ni = 0; ni < WNT; ++ni) wf[ni] = ld_f16x8(wptr[ni]);
+#pragma unroll
+    for (int mi = 0; mi < WMT; ++mi) af[mi] = ld_f16x8(aptr[mi]);
+
+    for (int kt = 0; kt < KT; ++kt) {
+        f16x8 wn_[WNT], an_[WMT];
+        const int ktn = (kt + 1 < KT) ? kt + 1 : kt;  // prefetch next k-tile (last one reloads itself)
+#pragma unroll
+        for (int ni = 0; ni < WNT; ++ni) wn_[ni] = ld_f16x8(wptr[ni] + (long)ktn * 512);
+#pragma unroll
+        for (int mi = 0; mi < WMT; ++mi) an_[mi] = ld_f16x8(aptr[mi] + (long)ktn * 32);
+#pragma unroll
+        for (int ni = 0; ni < WNT; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < WMT; ++mi) acc[ni][mi] = mfma16(wf[ni], af[mi], acc[ni][mi]);
+#pragma unroll
+        for (int ni = 0; ni < WNT; ++ni) wf[ni] = wn_[ni];
+#pragma unroll
+        for (int mi = 0; mi < WMT; ++mi) af[mi] = an_[mi];
+    }
+
+    // ---------------- epilogue: lane owns columns n..n+3 of row m
+#pragma unroll
+    for (int ni = 0; ni < WNT; ++ni) {
+        const int n = (nt0 + ni) * 16 + g * 4;
+        if (n >= p.N) continue;
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+            b4[0] = bv.x; b4[1] = bv.y; b4[2] = bv.z; b4[3] = bv.w;
+        }
+#pragma unroll
+        for (int mi = 0; mi < WMT; ++mi) {
+            const int m = m0 + mi * 16 + c;
+            if (m >= p.M) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] + b4[r];
+            switch (p.mode) {
+                case GEMM_STORE_F16:
+                case GEMM_GELU_F16: {
+                    if (p.mode == GEMM_GELU_F16) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    }
+                    f16x4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    *reinterpret_cast<f16x4*>(p.C + (long)z * p.strideC + (long)m * p.ldc + n) = o;
+                } break;
+                case GEMM_GELU_POS_F32: {
+                    float4 pv = *reinterpret_cast<const float4*>(p.pos + (long)m * p.N + n);
+                    float4 o = make_float4(gelu_erf(v[0]) + pv.x, gelu_erf(v[1]) + pv.y,
+                                           gelu_erf(v[2]) + pv.z, gelu_erf(v[3]) + pv.w);
+                    *reinterpret_cast<float4*>(p.X + (long)z * p.strideX + (long)m * p.ldx + n) = o;
+                } break;
+                case GEMM_RESID_F32: {
+                    float4* xp = reinterpret_cast<float4*>(p.X + (long)z * p.strideX + (long)m * p.ldx + n);
+                    float4 o = *xp;
+                    o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+                    *xp = o;
+                } break;
+                case GEMM_QKV: {
+                    const int item = m / p.rows_per_item, t = m - item * p.rows_per_item;
+                    if (n < p.d) {
+                        f16x4 o = {(half_t)(v[0] * p.qscale), (half_t)(v[1] * p.qscale),
+                                   (half_t)(v[2] * p.qscale), (half_t)(v[3] * p.qscale)};
+                        *reinterpret_cast<f16x4*>(p.C + (long)m * p.ldc + n) = o;
+                    } else if (n < 2 * p.d) {
+                        f16x4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        *reinterpret_cast<f16x4*>(p.Kout + (long)item * p.kv_item_stride_k + (long)t * p.ldk + (n - p.d)) = o;
+                    } else {
+                        half_t* vt = p.Vt + (long)item * p.kv_item_stride_v + (long)(n - 2 * p.d) * p.ldvt + t;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vt[(long)r * p.ldvt] = (half_t)v[r];
+                    }
+                } break;
+                case GEMM_CROSS_KV: {
+                    const int item = m / p.rows_per_item, t = m - item * p.rows_per_item;
+                    const int l = n / (2 * p.d), nn = n - l * 2 * p.d;
+                    if (nn < p.d) {
+                        f16x4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        *reinterpret_cast<f16x4*>(p.Kout + (long)l * p.kv_layer_stride_k +
+                                                  (long)item * p.kv_item_stride_k + (long)t * p.ldk + nn) = o;
+                    } else {
+                        half_t* vt = p.Vt + (long)l * p.kv_layer_stride_v + (long)item * p.kv_item_stride_v +
+                                     (long)(nn - p.d) * p.ldvt + t;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vt[(long)r * p.ldvt] = (half_t)v[r];
+                    }
+                } break;
+                default: break;
+            }
+        }
+    }
+}
+
+void launch_gemm(const GemmParams& p, int zbatch, hipStream_t s) {
+    const int NT_total = (p.N + 15) / 16;
+    // tile choice: wide outputs get 128x128 workgroup tiles (4x4 wave tiles: 16 MFMAs per 8 fragment
+    // loads); narrow ones (N = d) use 64x64 so the launch still spreads over the 256 CUs.
+    long blocks_big = (long)((NT_total + 7) / 8) * ((p.M + 127) / 128) * zbatch;
+    if (blocks_big >= 200) {
+        dim3 grid((NT_total + 7) / 8, (p.M + 127) / 128, zbatch);
+        hipLaunchKernelGGL((gemm_kernel<4, 4>), grid, dim3(256), 0, s, p);
+    } else {
+        long blocks_mid = (long)((NT_total + 7) / 8) * ((p.M + 63) / 64) * zbatch;
+        if (blocks_mid >= 200) {
+            dim3 grid((NT_total + 7) / 8, (p.M + 63) / 64, zbatch);
+            hipLaunchKernelGGL((gemm_kernel<4, 2>), grid, dim3(256), 0, s, p);
+        } else {
+            dim3 grid((NT_total + 3) / 4, (p.M + 63) / 64, zbatch);
+            hipLaunchKernelGGL((gemm_kernel<2, 2>), grid, dim3(256), 0, s, p);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- LayerNorm (wave per row)
+template <bool OUT32>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, long ldx,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        half_t* __restrict__ out16, float* __restrict__ out32,
+                                                        long ldo, int M, int d) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= M) return;
+    const float4* xr = reinterpret_cast<const float4*>(x + (long)row * ldx);
+    const int n4 = d >> 2;
+    float4 v[8];  // d <= 2048
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int j = lane + i * 64;
+        if (j < n4) { v[i] = xr[j]; s += v[i].x + v[i].y + v[i].z + v[i].w; }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int j = lane + i * 64;
+        if (j < n4) {
+            float a = v[i].x - mean, b = v[i].y - mean, c2 = v[i].z - mean, e = v[i].w - mean;
+            q += a * a + b * b + c2 * c2 + e * e;
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int j = lane + i * 64;
+        if (j < n4) {
+            float4 gg = g4[j], bb = b4[j];
+            float o0 = (v[i].x - mean) * rstd * gg.x + bb.x;
+            float o1 = (v[i].y - mean) * rstd * gg.y + bb.y;
+            float o2 = (v[i].z - mean) * rstd * gg.z + bb.z;
+            float o3 = (v[i].w - mean) * rstd * gg.w + bb.w;
+            f16x4 o = {(half_t)o0, (half_t)o1, (half_t)o2, (half_t)o3};
+            *reinterpret_cast<f16x4*>(out16 + (long)row * ldo + j * 4) = o;
+            if (OUT32) *reinterpret_cast<float4*>(out32 + (long)row * ldo + j * 4) = make_float4(o0, o1, o2, o3);
+        }
+    }
+}
+
+void launch_layernorm_f16(const float* x, long ldx, const float* gamma, const float* beta,
+                          half_t* out, long ldo, int M, int d, hipStream_t s) {
+    hipLaunchKernelGGL((layernorm_kernel<false>), dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, gamma, beta, out,
+                       (float*)nullptr, ldo, M, d);
+}
+void launch_layernorm_f16_f32(const float* x, long ldx, const float* gamma, const float* beta,
+                              half_t* out16, float* out32, long ldo, int M, int d, hipStream_t s) {
+    hipLaunchKernelGGL((layernorm_kernel<true>), dim3((M + 3) / 4), dim3(256), 0, s, x, ldx, gamma, beta, out16,
+                       out32, ldo, M, d);
+}
+
+}  // namespace wlx
