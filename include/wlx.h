@@ -124,6 +124,12 @@ int32_t wlx_slot_destroy(wlx_engine* e, int32_t slot);
  * Result stays on the device as float32 [n_mels, n_frames], n_frames = (n+160)/160. */
 int32_t wlx_logmel(wlx_engine* e, int32_t slot, int32_t item, const float* pcm, int64_t n,
                    int32_t* n_frames_out);
+/* The same in two halves, for callers that keep the stream's PCM resident in HBM (the device-side
+ * counterpart of the session buffer of whisper_live/backend/base.py:173-234): wlx_pcm_put copies
+ * `n` host samples into the item's device PCM buffer; wlx_logmel_resident computes the features of
+ * whatever is resident. wlx_logmel == wlx_pcm_put + wlx_logmel_resident. */
+int32_t wlx_pcm_put(wlx_engine* e, int32_t slot, int32_t item, const float* pcm, int64_t n);
+int32_t wlx_logmel_resident(wlx_engine* e, int32_t slot, int32_t item, int32_t* n_frames_out);
 /* Copy an item's device features to host / replace them from host (float32 [n_mels, n_frames]). */
 int32_t wlx_features_get(wlx_engine* e, int32_t slot, int32_t item, float* out, int64_t cap_floats,
                          int32_t* n_frames_out);

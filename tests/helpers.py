@@ -44,23 +44,7 @@ def f16_weights(weights):
     return out
 
 
-class NetProvider(odec.LogitsProvider):
-    """Oracle network as a logits provider for oracle.decoding.generate."""
-
-    def __init__(self, model: omodel.WhisperOracle, enc):
-        self.dec = omodel.StepDecoder(model, enc)
-
-    def prefill(self, tokens):
-        if len(tokens) == 0:
-            return None
-        return self.dec.step(np.asarray(tokens)[None, :])[0].numpy()
-
-    def step(self, tokens, parents):
-        if self.dec.k[0] is not None and self.dec.k[0].shape[0] == 1 and len(parents) > 1:
-            self.dec.reorder([0] * len(parents))
-        elif self.dec.k[0] is not None:
-            self.dec.reorder(list(parents))
-        return self.dec.step(np.asarray(tokens)[:, None])[:, 0].numpy()
+from oracle.provider import NetProvider  # noqa: E402,F401
 
 
 def engine_ids(ids: odec.TokenIds):

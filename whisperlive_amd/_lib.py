@@ -14,7 +14,7 @@ LIB_PATH = PKG_DIR / "libwlx.so"
 SOURCES = ["pack.hip", "logmel.hip", "gemm.hip", "attention.hip", "decoder.hip", "search.hip", "engine.hip"]
 EXPORTS = [
     "wlx_abi_version", "wlx_last_error", "wlx_engine_create", "wlx_engine_destroy", "wlx_engine_spec",
-    "wlx_slot_create", "wlx_slot_destroy", "wlx_logmel", "wlx_features_get", "wlx_features_set", "wlx_encode",
+    "wlx_slot_create", "wlx_slot_destroy", "wlx_logmel", "wlx_pcm_put", "wlx_logmel_resident", "wlx_features_get", "wlx_features_set", "wlx_encode",
     "wlx_encoder_output_get", "wlx_generate", "wlx_detect_language", "wlx_timings_get", "wlx_sync",
     "wlx_debug_logits_get", "wlx_debug_decode_logits", "wlx_debug_search", "wlx_debug_time_decode_step",
 ]
@@ -100,6 +100,8 @@ def load() -> C.CDLL:
     lib.wlx_slot_create.argtypes = [vp, i32, i32, i32p]
     lib.wlx_slot_destroy.argtypes = [vp, i32]
     lib.wlx_logmel.argtypes = [vp, i32, i32, f32p, i64, i32p]
+    lib.wlx_pcm_put.argtypes = [vp, i32, i32, f32p, i64]
+    lib.wlx_logmel_resident.argtypes = [vp, i32, i32, i32p]
     lib.wlx_features_get.argtypes = [vp, i32, i32, f32p, i64, i32p]
     lib.wlx_features_set.argtypes = [vp, i32, i32, f32p, i32, i32]
     lib.wlx_encode.argtypes = [vp, i32, i32, i32p, i32p]

@@ -39,6 +39,7 @@ struct Slot {
     float* pcm = nullptr; size_t pcm_cap = 0;       // [B][pcm_cap]
     float* feats = nullptr; long feat_ld = 0;        // [B][n_mels][feat_ld]
     std::vector<int> nframes;
+    std::vector<int64_t> npcm;                       // samples resident per item
     unsigned* gmax = nullptr;
     // encoder
     half_t *featT = nullptr, *h1 = nullptr, *ln = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr,

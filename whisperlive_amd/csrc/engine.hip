@@ -378,6 +378,7 @@ static int slot_grow_audio(Engine* e, Slot* s, size_t n_samples) {
     // (old buffers stay in the pool until slot destruction; growth is rare: 1-2 times per stream)
     s->pcm = npcm; s->pcm_cap = cap; s->feats = nfe; s->feat_ld = ld;
     std::fill(s->nframes.begin(), s->nframes.end(), 0);
+    std::fill(s->npcm.begin(), s->npcm.end(), 0);
     return WLX_OK;
 }
 
@@ -392,6 +393,7 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
     Slot* s = new Slot();
     s->B = B; s->R = R; s->cache_rows = B * R; s->rows_cap = 64; s->groups_cap = std::max(B, 4);
     s->nframes.assign(B, 0);
+    s->npcm.assign(B, 0);
     int rc = [&]() -> int {
         CK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         CK(hipEventCreate(&s->ev0)); CK(hipEventCreate(&s->ev1));
@@ -496,8 +498,7 @@ extern "C" int32_t wlx_timings_get(wlx_engine* e, int32_t slot, wlx_timings* out
 
 // ------------------------------------------------------------------------------------------------
 // log-mel
-extern "C" int32_t wlx_logmel(wlx_engine* e, int32_t slot, int32_t item, const float* pcm, int64_t n,
-                              int32_t* n_frames_out) {
+extern "C" int32_t wlx_pcm_put(wlx_engine* e, int32_t slot, int32_t item, const float* pcm, int64_t n) {
     Slot* s;
     CKR(slot_get(e, slot, &s));
     if (!pcm || n <= 0) return fail(WLX_ERR_ARG, "empty audio");
@@ -505,19 +506,38 @@ extern "C" int32_t wlx_logmel(wlx_engine* e, int32_t slot, int32_t item, const f
     if (n > 16000LL * 3600) return fail(WLX_ERR_ARG, "audio chunk too long");
     CK(hipSetDevice(e->device));
     CKR(slot_grow_audio(e, s, (size_t)n));
+    float* dp = s->pcm + (size_t)item * s->pcm_cap;
+    CK(hipMemcpyAsync(dp, pcm, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s->stream));
+    CK(hipStreamSynchronize(s->stream));   // the caller's PCM buffer may be reused after return
+    s->npcm[item] = n;
+    return WLX_OK;
+}
+
+extern "C" int32_t wlx_logmel_resident(wlx_engine* e, int32_t slot, int32_t item, int32_t* n_frames_out) {
+    Slot* s;
+    CKR(slot_get(e, slot, &s));
+    if (item < 0 || item >= s->B) return fail(WLX_ERR_ARG, "bad item %d", item);
+    const int64_t n = s->npcm[item];
+    if (n <= 0) return fail(WLX_ERR_STATE, "item %d: no PCM resident (call wlx_pcm_put first)", item);
+    CK(hipSetDevice(e->device));
     const int T = (int)((n + 160) / 160);
     float* dp = s->pcm + (size_t)item * s->pcm_cap;
     float* df = s->feats + (size_t)item * e->spec.n_mels * s->feat_ld;
     CK(hipEventRecord(s->ev0, s->stream));
-    CK(hipMemcpyAsync(dp, pcm, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s->stream));
     launch_logmel(dp, (long)n, e->spec.n_mels, e->lm, df, s->feat_ld, T, s->gmax + item, s->stream);
     CK(hipGetLastError());
     CK(hipEventRecord(s->ev1, s->stream));
-    CK(hipStreamSynchronize(s->stream));   // the caller's PCM buffer may be reused after return
+    CK(hipStreamSynchronize(s->stream));
     CK(hipEventElapsedTime(&s->tm.logmel_ms, s->ev0, s->ev1));
     s->nframes[item] = T;
     if (n_frames_out) *n_frames_out = T;
     return WLX_OK;
+}
+
+extern "C" int32_t wlx_logmel(wlx_engine* e, int32_t slot, int32_t item, const float* pcm, int64_t n,
+                              int32_t* n_frames_out) {
+    CKR(wlx_pcm_put(e, slot, item, pcm, n));
+    return wlx_logmel_resident(e, slot, item, n_frames_out);
 }
 
 extern "C" int32_t wlx_features_get(wlx_engine* e, int32_t slot, int32_t item, float* out, int64_t cap_floats,

@@ -112,6 +112,15 @@ class Slot:
         check(self.lib.wlx_logmel(self.engine._h, self.sid, item, _f32p(pcm), pcm.shape[0], C.byref(nf)))
         return nf.value
 
+    def pcm_put(self, pcm: np.ndarray, item: int = 0):
+        pcm = np.ascontiguousarray(pcm, dtype=np.float32)
+        check(self.lib.wlx_pcm_put(self.engine._h, self.sid, item, _f32p(pcm), pcm.shape[0]))
+
+    def logmel_resident(self, item: int = 0) -> int:
+        nf = C.c_int32(0)
+        check(self.lib.wlx_logmel_resident(self.engine._h, self.sid, item, C.byref(nf)))
+        return nf.value
+
     def features(self, item: int = 0) -> np.ndarray:
         nf = C.c_int32(0)
         check(self.lib.wlx_features_get(self.engine._h, self.sid, item, None, 0, C.byref(nf)))
