@@ -174,6 +174,16 @@ int32_t wlx_debug_search(wlx_engine* e, int32_t slot, const float* logits, int32
 int32_t wlx_debug_time_decode_step(wlx_engine* e, int32_t slot, int32_t rows, int32_t t, int32_t iters,
                                    float* avg_ms_out);
 
+/* per-kernel HIP-event profile of one decode step (eager launches bracketed by event pairs on the slot
+ * stream), aggregated by kernel name; bytes_per_launch = algorithmic bytes (weights / K,V streamed once). */
+typedef struct {
+    char name[64];
+    float launches_per_step, avg_us, total_us_per_step;
+    double bytes_per_launch;
+} wlx_kernel_stat;
+int32_t wlx_debug_profile_step(wlx_engine* e, int32_t slot, int32_t rows, int32_t t, int32_t iters,
+                               wlx_kernel_stat* out, int32_t cap, int32_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

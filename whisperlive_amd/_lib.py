@@ -16,7 +16,7 @@ EXPORTS = [
     "wlx_abi_version", "wlx_last_error", "wlx_engine_create", "wlx_engine_destroy", "wlx_engine_spec",
     "wlx_slot_create", "wlx_slot_destroy", "wlx_logmel", "wlx_pcm_put", "wlx_logmel_resident", "wlx_features_get", "wlx_features_set", "wlx_encode",
     "wlx_encoder_output_get", "wlx_generate", "wlx_detect_language", "wlx_timings_get", "wlx_sync",
-    "wlx_debug_logits_get", "wlx_debug_decode_logits", "wlx_debug_search", "wlx_debug_time_decode_step",
+    "wlx_debug_logits_get", "wlx_debug_decode_logits", "wlx_debug_search", "wlx_debug_time_decode_step", "wlx_debug_profile_step",
 ]
 
 
@@ -50,6 +50,11 @@ class wlx_gen_opts(C.Structure):
 
 class wlx_timings(C.Structure):
     _fields_ = [("logmel_ms", C.c_float), ("encode_ms", C.c_float), ("generate_ms", C.c_float), ("decode_steps", C.c_int32)]
+
+
+class wlx_kernel_stat(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("launches_per_step", C.c_float), ("avg_us", C.c_float),
+                ("total_us_per_step", C.c_float), ("bytes_per_launch", C.c_double)]
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
@@ -114,6 +119,7 @@ def load() -> C.CDLL:
     lib.wlx_debug_decode_logits.argtypes = [vp, i32, i32p, i32, f32p]
     lib.wlx_debug_search.argtypes = [vp, i32, f32p, i32, i32p, i32, C.POINTER(wlx_gen_opts), i32p, i32, i32p, f32p]
     lib.wlx_debug_time_decode_step.argtypes = [vp, i32, i32, i32, i32, f32p]
+    lib.wlx_debug_profile_step.argtypes = [vp, i32, i32, i32, i32, C.POINTER(wlx_kernel_stat), i32, i32p]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("wlx_last_error", "wlx_engine_destroy"):

@@ -30,6 +30,9 @@ struct StepGraphKey {
     }
 };
 
+struct ProfRec { const char* name; double bytes; hipEvent_t a, b; };
+struct Prof { std::vector<ProfRec> recs; std::vector<std::string> names; int t = 0; };
+
 struct Slot {
     int B = 0, R = 0, rows_cap = 0, cache_rows = 0, groups_cap = 0;
     hipStream_t stream = nullptr;
@@ -63,6 +66,7 @@ struct Slot {
     int* h_stage = nullptr; size_t h_stage_ints = 0;
     std::map<StepGraphKey, hipGraphExec_t> graphs;
     wlx_timings tm{};
+    Prof* prof = nullptr;
 };
 
 struct Engine {

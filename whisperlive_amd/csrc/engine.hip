@@ -658,6 +658,34 @@ extern "C" int32_t wlx_encoder_output_get(wlx_engine* e, int32_t slot, int32_t i
 }
 
 // ------------------------------------------------------------------------------------------------
+// per-kernel HIP-event profiler (test hook wlx_debug_profile_step): when s->prof is set every launch of
+// the decoder pass is bracketed by an event pair on the slot stream and tagged with its kernel name
+// (as rocprofv3 prints it) and its ALGORITHMIC bytes (weights / K,V it has to stream once).
+template <class F>
+static inline void plaunch(Slot* s, const char* name, double bytes, F&& f) {
+    if (!s->prof) { f(); return; }
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    (void)hipEventRecord(a, s->stream);
+    f();
+    (void)hipEventRecord(b, s->stream);
+    s->prof->recs.push_back(ProfRec{name, bytes, a, b});
+}
+static std::string gemv_name(const GemvParams& p) {
+    const int MT = (p.M + 15) / 16;
+    char buf[64];
+    snprintf(buf, sizeof(buf), "dec_gemv_kernel<%d, %d, %d>", MT > 4 ? 4 : MT, MT == 1 ? 2 : 1, p.in_mode);
+    return buf;
+}
+static double gemv_bytes(const GemvParams& p) { return 2.0 * (double)p.N * (double)p.K + (p.bias ? 4.0 * p.N : 0.0); }
+static void pgemv(Slot* s, const GemvParams& p) {
+    if (!s->prof) { launch_dec_gemv(p, s->stream); return; }
+    s->prof->names.push_back(gemv_name(p));
+    const char* nm = s->prof->names.back().c_str();
+    plaunch(s, nm, gemv_bytes(p), [&] { launch_dec_gemv(p, s->stream); });
+}
+
+// ------------------------------------------------------------------------------------------------
 // decoder pass: embed -> L x {self-attn block, cross-attn block, MLP} -> (final LN + vocab projection)
 // Row tables / ancestry must already be on the device. `rows` live rows in `groups` groups of R rows.
 static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool with_logits, bool check_done) {
@@ -666,7 +694,7 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
     hipStream_t st = s->stream;
     const int* done = check_done ? s->st.done : nullptr;
     RowTables rt{s->d_token, s->d_pos, s->d_cache, s->d_ancrow, s->d_anc, s->d_intok};
-    launch_dec_embed(e->tok_emb16, e->dec_pos, d, rt, rows, s->xd, done, st);
+    plaunch(s, "dec_embed_kernel", (double)rows * d * (2 + 4), [&] { launch_dec_embed(e->tok_emb16, e->dec_pos, d, rt, rows, s->xd, done, st); });
     const long crs = (long)WLX_T_TEXT * d;
     for (int l = 0; l < sp.dec_layers; ++l) {
         const DecLayerW& w = e->dec[l];
@@ -678,43 +706,45 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
         p.Wp = w.Wqkv; p.bias = w.bqkv; p.X = s->xd; p.ldx = d; p.gamma = w.ln1_g; p.beta = w.ln1_b;
         p.Yh = s->qd; p.ldyh = d; p.d = d; p.qscale = 0.125f; p.Kc = kc; p.Vc = vc; p.cache_row_stride = crs;
         p.row_cache = s->d_cache; p.row_pos = s->d_pos; p.done = done;
-        launch_dec_gemv(p, st);
-        launch_dec_self_attn(s->qd, d, kc, vc, crs, d, H, rt, rows, s->attnd, d, done, st);
+        pgemv(s, p);
+        plaunch(s, "dec_self_attn_kernel", 4.0 * rows * d * (s->prof ? s->prof->t + 1 : 1), [&] { launch_dec_self_attn(s->qd, d, kc, vc, crs, d, H, rt, rows, s->attnd, d, done, st); });
         p = GemvParams{};
         p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
         p.Wp = w.Wo; p.bias = w.bo; p.Xh = s->attnd; p.ldxh = d; p.Xres = s->xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
-        launch_dec_gemv(p, st);
+        pgemv(s, p);
         // LN2 + cross-attention query
         p = GemvParams{};
         p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_F16; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
         p.Wp = w.Wcq; p.bias = w.bcq; p.X = s->xd; p.ldx = d; p.gamma = w.ln2_g; p.beta = w.ln2_b;
         p.Yh = s->qd; p.ldyh = d; p.qscale = 0.125f; p.done = done;
-        launch_dec_gemv(p, st);
-        launch_dec_cross_attn(s->qd, d, s->ck + (size_t)l * s->B * WLX_T_AUDIO_PAD * d, d, (long)WLX_T_AUDIO_PAD * d,
-                              s->cvt + (size_t)l * s->B * d * WLX_T_AUDIO_PAD, WLX_T_AUDIO_PAD, (long)d * WLX_T_AUDIO_PAD,
-                              H, R, groups, rows, s->d_group_item, s->part_o, s->part_ml, done, st);
+        pgemv(s, p);
+        plaunch(s, "dec_cross_attn_kernel", 4.0 * groups * WLX_T_AUDIO * d, [&] {
+            launch_dec_cross_attn(s->qd, d, s->ck + (size_t)l * s->B * WLX_T_AUDIO_PAD * d, d, (long)WLX_T_AUDIO_PAD * d,
+                                  s->cvt + (size_t)l * s->B * d * WLX_T_AUDIO_PAD, WLX_T_AUDIO_PAD, (long)d * WLX_T_AUDIO_PAD,
+                                  H, R, groups, rows, s->d_group_item, s->part_o, s->part_ml, done, st);
+        });
         p = GemvParams{};
         p.in_mode = GEMV_IN_XATTN; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
         p.Wp = w.Wco; p.bias = w.bco; p.part_o = s->part_o; p.part_ml = s->part_ml; p.H = H; p.R = R;
         p.Xres = s->xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
-        launch_dec_gemv(p, st);
+        pgemv(s, p);
         // LN3 + MLP
         p = GemvParams{};
         p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_GELU_F16; p.M = rows; p.K = d; p.KT = d / 32; p.N = F;
         p.Wp = w.W1; p.bias = w.b1; p.X = s->xd; p.ldx = d; p.gamma = w.ln3_g; p.beta = w.ln3_b;
         p.Yh = s->hd; p.ldyh = F; p.qscale = 1.f; p.done = done;
-        launch_dec_gemv(p, st);
+        pgemv(s, p);
         p = GemvParams{};
         p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = F; p.KT = F / 32; p.N = d;
         p.Wp = w.W2; p.bias = w.b2; p.Xh = s->hd; p.ldxh = F; p.Xres = s->xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
-        launch_dec_gemv(p, st);
+        pgemv(s, p);
     }
     if (with_logits) {
         GemvParams p{};
         p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_F32; p.M = rows; p.K = d; p.KT = d / 32; p.N = sp.vocab;
         p.Wp = e->Wvocab; p.bias = nullptr; p.X = s->xd; p.ldx = d; p.gamma = e->dec_ln_g; p.beta = e->dec_ln_b;
         p.Y = s->logits; p.ldy = s->ldl; p.qscale = 1.f; p.done = done;
-        launch_dec_gemv(p, st);
+        pgemv(s, p);
     }
 }
 
@@ -1104,5 +1134,54 @@ extern "C" int32_t wlx_debug_time_decode_step(wlx_engine* e, int32_t slot, int32
     CK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
     *avg_ms_out = ms / (float)iters;
     CK(hipGraphExecDestroy(exec));
+    return WLX_OK;
+}
+
+extern "C" int32_t wlx_debug_profile_step(wlx_engine* e, int32_t slot, int32_t rows, int32_t t, int32_t iters,
+                                          wlx_kernel_stat* out, int32_t cap, int32_t* n_out) {
+    Slot* s;
+    CKR(slot_get(e, slot, &s));
+    if (rows < 1 || rows > s->cache_rows || rows > 16 || t < 0 || t >= WLX_T_TEXT || iters < 1 || !out || !n_out || cap < 1)
+        return fail(WLX_ERR_ARG, "bad arguments");
+    if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "decode before encode");
+    CK(hipSetDevice(e->device));
+    hipStream_t st = s->stream;
+    std::vector<int> tk(rows, 0), ps(rows, t), ca(rows), an(rows), gi(1, 0);
+    std::vector<short> anc((size_t)rows * WLX_T_TEXT);
+    for (int r = 0; r < rows; ++r) { ca[r] = an[r] = r; for (int p = 0; p < WLX_T_TEXT; ++p) anc[(size_t)r * WLX_T_TEXT + p] = (short)r; }
+    CKR(set_anc_rows(s, anc, 0, rows));
+    CKR(upload_rows(s, tk, ps, ca, an, gi));
+    CK(hipMemsetAsync(s->st.done, 0, 4, st));
+    for (int i = 0; i < 2; ++i) decoder_pass(e, s, rows, rows, 1, true, true);   // warm caches / code objects
+    CK(hipStreamSynchronize(st));
+    Prof prof;
+    prof.t = t;
+    prof.names.reserve((size_t)iters * 128);
+    s->prof = &prof;
+    for (int i = 0; i < iters; ++i) decoder_pass(e, s, rows, rows, 1, true, true);
+    s->prof = nullptr;
+    CK(hipStreamSynchronize(st));
+    CK(hipGetLastError());
+    struct Agg { int launches = 0; double us = 0, bytes = 0; };
+    std::map<std::string, Agg> agg;
+    for (auto& r : prof.recs) {
+        float ms = 0.f;
+        (void)hipEventElapsedTime(&ms, r.a, r.b);
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+        Agg& a = agg[r.name];
+        a.launches += 1; a.us += 1000.0 * ms; a.bytes += r.bytes;
+    }
+    int n = 0;
+    for (auto& kv : agg) {
+        if (n >= cap) break;
+        wlx_kernel_stat& o = out[n++];
+        memset(&o, 0, sizeof(o));
+        snprintf(o.name, sizeof(o.name), "%s", kv.first.c_str());
+        o.launches_per_step = (float)kv.second.launches / (float)iters;
+        o.avg_us = (float)(kv.second.us / kv.second.launches);
+        o.total_us_per_step = (float)(kv.second.us / iters);
+        o.bytes_per_launch = kv.second.bytes / kv.second.launches;
+    }
+    *n_out = n;
     return WLX_OK;
 }

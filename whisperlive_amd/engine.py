@@ -231,3 +231,11 @@ class Slot:
         ms = C.c_float(0)
         check(self.lib.wlx_debug_time_decode_step(self.engine._h, self.sid, rows, t, iters, C.byref(ms)))
         return ms.value
+
+    def debug_profile_step(self, rows: int, t: int, iters: int = 20) -> List[dict]:
+        cap = 64
+        arr = (_lib.wlx_kernel_stat * cap)()
+        n = C.c_int32(0)
+        check(self.lib.wlx_debug_profile_step(self.engine._h, self.sid, rows, t, iters, arr, cap, C.byref(n)))
+        return [dict(name=arr[i].name.decode(), launches=arr[i].launches_per_step, avg_us=arr[i].avg_us,
+                     total_us=arr[i].total_us_per_step, bytes_per_launch=arr[i].bytes_per_launch) for i in range(n.value)]
