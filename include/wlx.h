@@ -153,6 +153,15 @@ int32_t wlx_generate(wlx_engine* e, int32_t slot, int32_t batch,
                      int32_t* tokens_out, int32_t tokens_stride /* per hypothesis */,
                      int32_t* n_tokens_out, float* scores_out, float* no_speech_prob_out);
 
+/* The same with an item map: decoder item i attends to the encoder output of item enc_items[i]
+ * (NULL = identity). Lets the batched fallback of whisper_live/batch_inference.py:318-384 retry a subset
+ * of a batch without re-encoding it (the reference re-encodes, :334-339). */
+int32_t wlx_generate_ex(wlx_engine* e, int32_t slot, int32_t batch, const int32_t* enc_items,
+                        const int32_t* prompts, const int32_t* prompt_lens, int32_t prompt_stride,
+                        const wlx_gen_opts* opts,
+                        int32_t* tokens_out, int32_t tokens_stride,
+                        int32_t* n_tokens_out, float* scores_out, float* no_speech_prob_out);
+
 /* One decoder step on [sot]; softmax restricted to `lang_ids`; probs_out[batch][n_lang]. */
 int32_t wlx_detect_language(wlx_engine* e, int32_t slot, int32_t batch, int32_t sot,
                             const int32_t* lang_ids, int32_t n_lang, float* probs_out);

@@ -1,0 +1,256 @@
+"""CPU tests of the callers on either side of the hot path: the per-client session state machine (contract of the
+reference's tests/test_base_backend.py: buffer cap/trim, chunk slicing, clip rule, commit logic, first-frame wait),
+the HIP backend adaptor, and the batch worker (contract of tests/test_batch_inference.py: single -> transcribe,
+multi -> encode + generate, error propagation, worker survival, max_batch_size)."""
+import json
+import threading
+import time
+from types import SimpleNamespace
+from unittest.mock import MagicMock
+
+import numpy as np
+import pytest
+
+from tests.fakes import FakeEngine
+from whisperlive_amd import metrics
+from whisperlive_amd.batching import BatchInferenceWorker, BatchRequest
+from whisperlive_amd.engine import GenerationResult
+from whisperlive_amd.serve_client import ServeClientBase, ServeClientHIP
+from whisperlive_amd.tokenizer import Tokenizer, synthetic_tokenizer
+from whisperlive_amd.transcriber import WhisperModelHIP
+
+V = 2310
+
+
+class Client(ServeClientBase):
+    def __init__(self, **kw):
+        super().__init__("uid", MagicMock(), **kw)
+        self.language = "en"
+        self.script = []
+
+    def transcribe_audio(self, x):
+        return self.script.pop(0) if self.script else None
+
+    def handle_transcription_output(self, result, duration):
+        seg = self.update_segments(result, duration)
+        self.send_transcription_to_client(self.prepare_segments(seg))
+
+
+def seg(start, end, text, nsp=0.0):
+    return SimpleNamespace(start=start, end=end, text=text, no_speech_prob=nsp)
+
+
+def test_buffer_cap_trim_and_chunk_slicing():
+    c = Client()
+    c.add_frames(np.ones(16000, np.float32))
+    c.add_frames(np.ones(8000, np.float32) * 2)
+    assert c.frames_np.shape[0] == 24000 and c.frames_np[16000] == 2
+    c.frames_np = np.zeros(46 * 16000, np.float32)
+    c.add_frames(np.ones(16000, np.float32))
+    assert c.frames_offset == 30.0 and c.frames_np.shape[0] == 17 * 16000 and c.timestamp_offset == 30.0
+    c.timestamp_offset = 35.0
+    chunk, dur = c.get_audio_chunk_for_processing()
+    assert chunk.shape[0] == 12 * 16000 and dur == 12.0
+    # clip rule: > 25 s unconsumed -> keep the last 5 s
+    c2 = Client(clip_audio=True)
+    c2.frames_np = np.zeros(28 * 16000, np.float32)
+    c2.clip_audio_if_no_valid_segment()
+    assert c2.timestamp_offset == 23.0
+
+
+def test_add_frames_thread_safety():
+    c = Client()
+    ths = [threading.Thread(target=lambda: [c.add_frames(np.ones(160, np.float32)) for _ in range(50)]) for _ in range(8)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    assert c.frames_np.shape[0] == 8 * 50 * 160
+
+
+def test_update_segments_commits_all_but_last_and_advances_offset():
+    c = Client()
+    last = c.update_segments([seg(0.0, 2.0, " one"), seg(2.0, 4.0, " two"), seg(4.0, 5.5, " thr")], 6.0)
+    assert [s["text"] for s in c.transcript] == [" one", " two"] and all(s["completed"] for s in c.transcript)
+    assert c.timestamp_offset == 4.0 and last == {"start": "4.000", "end": "5.500", "text": " thr", "completed": False}
+    # high no-speech tail: nothing is committed, nothing is sent as partial
+    c2 = Client()
+    assert c2.update_segments([seg(0, 1, " a"), seg(1, 2, " b", nsp=0.9)], 3.0) is None and c2.transcript == []
+    # segment end is clamped to the chunk duration
+    c3 = Client()
+    c3.update_segments([seg(0.0, 9.0, " long"), seg(9.0, 9.5, " t")], 5.0)
+    assert c3.transcript[0]["end"] == "5.000" and c3.timestamp_offset == 5.0
+
+
+def test_repeated_output_is_committed_after_threshold(monkeypatch):
+    monkeypatch.setattr(time, "sleep", lambda s: None)
+    c = Client(same_output_threshold=3)
+    for i in range(5):
+        out = c.update_segments([seg(0.0, 1.5 + 0.1 * i, " same")], 3.0)
+    assert c.transcript and c.transcript[-1]["text"] == " same" and c.transcript[-1]["completed"]
+    assert c.transcript[-1]["end"] == "1.600"              # end time captured when the repetition STARTED
+    assert c.timestamp_offset == pytest.approx(1.6) and out is None and c.same_output_count == 0
+    assert c.prepare_segments({"x": 1})[-1] == {"x": 1}
+    c.send_last_n_segments = 1
+    c.transcript = [{"a": 1}, {"b": 2}]
+    assert c.prepare_segments() == [{"b": 2}]
+
+
+def test_speech_to_text_loop_measures_latency_and_handles_errors(monkeypatch):
+    metrics.snapshot(reset=True)
+    c = Client()
+    c.script = [[seg(0.0, 1.0, " a"), seg(1.0, 1.5, " b")], None]
+    c.add_frames(np.zeros(2 * 16000, np.float32))
+    th = threading.Thread(target=c.speech_to_text, daemon=True)
+    th.start()
+    time.sleep(0.6)
+    c.cleanup(); th.join(timeout=2)
+    snap = metrics.snapshot()
+    assert snap["chunks"] == 1 and snap["audio_s"] == 2.0 and snap["xrt"] > 0
+    sent = json.loads(c.websocket.send.call_args_list[0][0][0])
+    assert sent["uid"] == "uid" and sent["segments"][0]["completed"] and sent["segments"][-1]["text"] == " b"
+    assert c.timestamp_offset >= 1.0                       # advanced by the commit (then by the silent chunk)
+    # a client with no frames idles cheaply and exits on cleanup
+    idle = Client()
+    t2 = threading.Thread(target=idle.speech_to_text, daemon=True); t2.start(); time.sleep(0.15); idle.cleanup(); t2.join(timeout=1)
+    assert not t2.is_alive()
+
+
+def _model(engine=None):
+    return WhisperModelHIP("fake", engine=engine or FakeEngine(), hf_tokenizer=synthetic_tokenizer(V), max_batch=8)
+
+
+def test_serve_client_hip_protocol_and_model_failure():
+    ws = MagicMock()
+    m = _model()
+    tk = Tokenizer(m.hf_tokenizer, False)
+    m.engine.default_tokens = [tk.timestamp_begin] + tk.encode(" hi there") + [tk.timestamp_begin + 40]
+    c = ServeClientHIP(ws, client_uid="u1", model="small.en", transcriber=m, start_thread=False, use_vad=False)
+    ready = json.loads(ws.send.call_args_list[0][0][0])
+    assert ready == {"uid": "u1", "message": "SERVER_READY", "backend": "faster_whisper"} and c.language == "en"
+    out = c.transcribe_audio(np.zeros(16000, np.float32) + 0.01)
+    assert out[0].text == " hi there"
+    c.handle_transcription_output(out, 1.0)
+    msg = json.loads(ws.send.call_args_list[-1][0][0])
+    assert msg["segments"][0]["text"] == " hi there" and msg["segments"][0]["completed"] is False
+    # model load failure -> ERROR status + close (faster_whisper_backend.py:108-116)
+    ws2 = MagicMock()
+    ServeClientHIP.MODELS.clear()
+    ServeClientHIP(ws2, client_uid="u2", model="/no/such/dir", start_thread=False)
+    err = json.loads(ws2.send.call_args_list[0][0][0])
+    assert err["status"] == "ERROR" and "Failed to load model" in err["message"] and ws2.close.called
+    # language detection message
+    ws3 = MagicMock()
+    ml = WhisperModelHIP("fake", engine=FakeEngine(), hf_tokenizer=synthetic_tokenizer(V), multilingual=True)
+    c3 = ServeClientHIP(ws3, client_uid="u3", model="small", transcriber=ml, start_thread=False, use_vad=False)
+    assert c3.language is None
+    c3.transcribe_audio(np.zeros(16000, np.float32) + 0.01)
+    assert c3.language == "en" and json.loads(ws3.send.call_args_list[-1][0][0])["language"] == "en"
+
+
+# ------------------------------------------------------------------------------------------------ batch worker
+def _mock_transcriber():
+    """Same shape as the reference's fixture (tests/test_batch_inference.py:52-78)."""
+    t = MagicMock()
+    t.feature_extractor.sampling_rate = 16000
+    t.feature_extractor.side_effect = lambda a: np.zeros((80, (len(a) + 160) // 160), np.float32)
+    del t.encode_audio_batch                                  # force the generic duck-typed path
+    t.encode.side_effect = lambda f: np.zeros((f.shape[0], 1500, 512), np.float32)
+    t.model.is_multilingual = False
+    t.hf_tokenizer = synthetic_tokenizer(51864)
+    t.max_length, t.frames_per_second = 448, 100
+    t.get_prompt.return_value = [50257]
+    t.model.generate.side_effect = lambda enc, prompts, **kw: [
+        SimpleNamespace(sequences_ids=[[50363, 1234, 50463]], scores=[-0.1], no_speech_prob=0.01) for _ in prompts]
+    t._split_segments_by_timestamps.side_effect = lambda **kw: ([dict(seek=0, start=0.0, end=2.0, tokens=kw["tokens"])], 0, True)
+    return t
+
+
+def test_batch_single_request_uses_transcribe():
+    t = _mock_transcriber()
+    t.transcribe.return_value = ([SimpleNamespace(text="x")], SimpleNamespace(language="en"))
+    w = BatchInferenceWorker(t, max_batch_size=4, batch_window_ms=10); w.start()
+    r = BatchRequest(audio=np.zeros(16000, np.float32), use_vad=False); w.submit(r)
+    assert r.future.wait(2) and r.error is None and r.result[0].text == "x"
+    t.transcribe.assert_called_once(); t.encode.assert_not_called(); w.stop()
+
+
+def test_batch_multi_uses_one_encode_and_one_generate():
+    t = _mock_transcriber()
+    w = BatchInferenceWorker(t, max_batch_size=8, batch_window_ms=200)
+    reqs = [BatchRequest(audio=np.zeros(16000 * (i + 1), np.float32) + 0.01, use_vad=False) for i in range(3)]
+    w._process_batch(reqs)
+    assert all(r.future.is_set() and r.error is None for r in reqs)
+    t.transcribe.assert_not_called(); assert t.encode.call_count == 1 and t.model.generate.call_count == 1
+    assert t.encode.call_args[0][0].shape == (3, 80, 3000)
+    kw = t.model.generate.call_args[1]
+    assert kw["beam_size"] == 5 and kw["sampling_temperature"] == 0.0 and "sampling_topk" not in kw
+    assert reqs[0].result[0].tokens == [50363, 1234, 50463] and reqs[1].info.language == "en"
+
+
+def test_batch_error_propagation_and_worker_survival():
+    t = _mock_transcriber()
+    t.encode.side_effect = RuntimeError("boom")
+    w = BatchInferenceWorker(t, max_batch_size=2, batch_window_ms=100); w.start()
+    rs = [BatchRequest(audio=np.zeros(16000, np.float32), use_vad=False) for _ in range(2)]
+    [w.submit(r) for r in rs]
+    assert all(r.future.wait(3) for r in rs) and all(isinstance(r.error, RuntimeError) for r in rs)
+    t.transcribe.return_value = ([], SimpleNamespace(language="en"))
+    r = BatchRequest(audio=np.zeros(16000, np.float32), use_vad=False); w.submit(r)
+    assert r.future.wait(3) and r.error is None              # the worker thread is still alive
+    w.stop(); assert not w._thread.is_alive()
+
+
+def test_batch_respects_max_batch_size():
+    t = _mock_transcriber()
+    sizes = []
+    w = BatchInferenceWorker(t, max_batch_size=2, batch_window_ms=300)
+    orig = w._process_batch
+    w._process_batch = lambda b: (sizes.append(len(b)), orig(b))[1]
+    rs = [BatchRequest(audio=np.zeros(16000, np.float32) + 0.01, use_vad=False) for _ in range(5)]
+    [w.submit(r) for r in rs]
+    w.start()
+    assert all(r.future.wait(5) for r in rs)
+    w.stop(); assert max(sizes) <= 2 and sum(sizes) == 5
+
+
+def test_batch_fallback_retries_only_failed_items_on_the_hip_transcriber():
+    eng = FakeEngine()
+    m = _model(eng)
+    tk = Tokenizer(m.hf_tokenizer, False)
+    tb = tk.timestamp_begin
+    good = [tb] + tk.encode(" fine") + [tb + 50]
+    bad = [tb] + tk.encode(" la" * 150) + [tb + 50]
+    eng.generate_script = [
+        lambda p, i, k: [GenerationResult([good], [-0.1], 0.0), GenerationResult([bad], [-0.1], 0.0), GenerationResult([good], [-0.1], 0.0)],
+        lambda p, i, k: [GenerationResult([good], [-0.3], 0.0)],
+    ]
+    w = BatchInferenceWorker(m, max_batch_size=8)
+    reqs = [BatchRequest(audio=np.zeros(16000 * 2, np.float32) + 0.01, use_vad=False) for _ in range(3)]
+    w._process_batch(reqs)
+    assert all(r.error is None for r in reqs)
+    calls = eng.slots[0].calls
+    assert [c[0] for c in calls] == ["logmel", "logmel", "logmel", "encode", "generate", "generate"]   # no re-encode
+    assert calls[3] == ("encode", 3, [0, 0, 0], [201, 201, 201])                  # trailing pad frame kept (quirk)
+    assert calls[5][2]["enc_items"] == [1] and calls[5][2]["sampling_temperature"] == 0.0 and calls[5][2]["beam_size"] == 1
+    assert reqs[1].result[0].temperature == 0.2 and reqs[0].result[0].temperature == 0.0
+    # empty-after-VAD item is answered without touching the engine
+    silent = BatchRequest(audio=np.zeros(16000, np.float32), use_vad=True, vad_parameters={"threshold": 0.5})
+    w._process_batch([silent, BatchRequest(audio=np.zeros(16000, np.float32) + 0.01, use_vad=False)])
+    assert silent.future.is_set() and silent.result == []
+
+
+def test_hip_backend_goes_through_the_batch_worker():
+    m = _model()
+    tk = Tokenizer(m.hf_tokenizer, False)
+    m.engine.default_tokens = [tk.timestamp_begin] + tk.encode(" batched") + [tk.timestamp_begin + 40]
+    w = BatchInferenceWorker(m, max_batch_size=4, batch_window_ms=150); w.start()
+    ServeClientHIP.BATCH_WORKER = w
+    try:
+        cs = [ServeClientHIP(MagicMock(), client_uid=f"c{i}", model="small.en", transcriber=m, start_thread=False, use_vad=False)
+              for i in range(3)]
+        outs = [None] * 3
+        ths = [threading.Thread(target=lambda i=i: outs.__setitem__(i, cs[i].transcribe_audio(np.zeros(16000, np.float32) + 0.01)))
+               for i in range(3)]
+        [t.start() for t in ths]; [t.join(5) for t in ths]
+        assert all(o and o[0].text == "batched" for o in outs)
+    finally:
+        ServeClientHIP.BATCH_WORKER = None
+        w.stop()

@@ -885,7 +885,7 @@ static int upload_suppress(Engine* e, Slot* s, const wlx_gen_opts* o) {
 struct HypOut { std::vector<int> tokens; float score; };
 
 static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, const int32_t* plens, int pstride,
-                         const wlx_gen_opts* o, bool injected_logits, const float* inj, int inj_steps,
+                         const int32_t* enc_items, const wlx_gen_opts* o, bool injected_logits, const float* inj, int inj_steps,
                          int32_t* tokens_out, int tstride, int32_t* n_tokens_out, float* scores_out, float* nsp_out) {
     CKR(validate_opts(e, s, batch, o));
     const bool sampling = (o->sampling_temperature > 0.f || o->beam_size <= 1);
@@ -939,7 +939,7 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
             for (int i = 0; i < pl[b]; ++i) if (pr[i] == o->ids.sot) sot_idx = i;
             if (sot_idx == pl[b] - 1) { for (int r = 0; r < (sampling ? R : 1); ++r) nsp[b * R + r] = (r == 0) ? 1 : 0; }
             if (pl[b] > 1)
-                CKR(prefill_tokens(e, s, b, b * R, pr, 0, pl[b] - 1, nullptr, (sot_idx >= 0 && sot_idx < pl[b] - 1) ? sot_idx : -1,
+                CKR(prefill_tokens(e, s, enc_items ? enc_items[b] : b, b * R, pr, 0, pl[b] - 1, nullptr, (sot_idx >= 0 && sot_idx < pl[b] - 1) ? sot_idx : -1,
                                    o->ids.no_speech, S.no_speech + b));
         }
     }
@@ -947,7 +947,7 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
     {
         std::vector<int> tk(rows), ps(rows), ca(rows), an(rows), gi(batch);
         for (int b = 0; b < batch; ++b) {
-            gi[b] = b;
+            gi[b] = enc_items ? enc_items[b] : b;
             for (int r = 0; r < R; ++r) {
                 const int row = b * R + r;
                 tk[row] = prompts[(size_t)b * pstride + pl[b] - 1]; ps[row] = pl[b] - 1; ca[row] = row; an[row] = row;
@@ -1026,17 +1026,31 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
     return WLX_OK;
 }
 
+extern "C" int32_t wlx_generate_ex(wlx_engine* e, int32_t slot, int32_t batch, const int32_t* enc_items,
+                                   const int32_t* prompts, const int32_t* prompt_lens, int32_t prompt_stride,
+                                   const wlx_gen_opts* opts, int32_t* tokens_out, int32_t tokens_stride,
+                                   int32_t* n_tokens_out, float* scores_out, float* no_speech_prob_out) {
+    Slot* s;
+    CKR(slot_get(e, slot, &s));
+    if (!prompts || !prompt_lens || !tokens_out || !n_tokens_out || !scores_out) return fail(WLX_ERR_ARG, "null argument");
+    if (batch < 1 || batch > s->B) return fail(WLX_ERR_ARG, "batch %d out of range (slot max %d)", batch, s->B);
+    if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "generate before encode");
+    for (int b = 0; b < batch; ++b) {
+        const int it = enc_items ? enc_items[b] : b;
+        if (it < 0 || it >= s->enc_batch)
+            return fail(WLX_ERR_STATE, "generate: item %d uses encoder item %d but only %d are encoded", b, it, s->enc_batch);
+    }
+    CK(hipSetDevice(e->device));
+    return generate_impl(e, s, batch, prompts, prompt_lens, prompt_stride, enc_items, opts, false, nullptr, 0, tokens_out,
+                         tokens_stride, n_tokens_out, scores_out, no_speech_prob_out);
+}
+
 extern "C" int32_t wlx_generate(wlx_engine* e, int32_t slot, int32_t batch, const int32_t* prompts,
                                 const int32_t* prompt_lens, int32_t prompt_stride, const wlx_gen_opts* opts,
                                 int32_t* tokens_out, int32_t tokens_stride, int32_t* n_tokens_out, float* scores_out,
                                 float* no_speech_prob_out) {
-    Slot* s;
-    CKR(slot_get(e, slot, &s));
-    if (!prompts || !prompt_lens || !tokens_out || !n_tokens_out || !scores_out) return fail(WLX_ERR_ARG, "null argument");
-    if (batch < 1 || batch > s->enc_batch) return fail(WLX_ERR_STATE, "generate(batch=%d) before encode(batch=%d)", batch, s->enc_batch);
-    CK(hipSetDevice(e->device));
-    return generate_impl(e, s, batch, prompts, prompt_lens, prompt_stride, opts, false, nullptr, 0, tokens_out,
-                         tokens_stride, n_tokens_out, scores_out, no_speech_prob_out);
+    return wlx_generate_ex(e, slot, batch, nullptr, prompts, prompt_lens, prompt_stride, opts, tokens_out, tokens_stride,
+                           n_tokens_out, scores_out, no_speech_prob_out);
 }
 
 extern "C" int32_t wlx_debug_search(wlx_engine* e, int32_t slot, const float* logits, int32_t steps,
@@ -1047,7 +1061,7 @@ extern "C" int32_t wlx_debug_search(wlx_engine* e, int32_t slot, const float* lo
     if (!logits || !prompt || !opts) return fail(WLX_ERR_ARG, "null argument");
     CK(hipSetDevice(e->device));
     float nsp;
-    return generate_impl(e, s, 1, prompt, &prompt_len, prompt_len, opts, true, logits, steps, tokens_out, tokens_stride,
+    return generate_impl(e, s, 1, prompt, &prompt_len, prompt_len, nullptr, opts, true, logits, steps, tokens_out, tokens_stride,
                          n_tokens_out, scores_out, &nsp);
 }
 

@@ -167,7 +167,7 @@ class Slot:
     def generate(self, prompts: Sequence[Sequence[int]], ids: TokenIds, *, beam_size=5, patience=1.0, num_hypotheses=1,
                  length_penalty=1.0, repetition_penalty=1.0, no_repeat_ngram_size=0, max_length=448,
                  suppress_blank=True, suppress_tokens=(), max_initial_timestamp_index=50, sampling_topk=0,
-                 sampling_temperature=0.0, seed=0) -> List[GenerationResult]:
+                 sampling_temperature=0.0, seed=0, enc_items: Optional[Sequence[int]] = None) -> List[GenerationResult]:
         batch = len(prompts)
         o, keep = self._opts(ids, beam_size, patience, num_hypotheses, length_penalty, repetition_penalty,
                              no_repeat_ngram_size, max_length, suppress_blank, suppress_tokens,
@@ -183,8 +183,10 @@ class Slot:
         nt = np.zeros((batch, nh), dtype=np.int32)
         sc = np.zeros((batch, nh), dtype=np.float32)
         nsp = np.zeros(batch, dtype=np.float32)
-        check(self.lib.wlx_generate(self.engine._h, self.sid, batch, _i32p(pr), _i32p(pl), stride, C.byref(o),
-                                    _i32p(toks), 448, _i32p(nt), _f32p(sc), _f32p(nsp)))
+        items = np.asarray(enc_items, dtype=np.int32) if enc_items is not None else None
+        check(self.lib.wlx_generate_ex(self.engine._h, self.sid, batch, _i32p(items) if items is not None else None,
+                                       _i32p(pr), _i32p(pl), stride, C.byref(o),
+                                       _i32p(toks), 448, _i32p(nt), _f32p(sc), _f32p(nsp)))
         out = []
         for b in range(batch):
             seqs = [toks[b, h, :nt[b, h]].tolist() for h in range(nh) if np.isfinite(sc[b, h])]
