@@ -1,0 +1,116 @@
+"""GPU tests (-m gpu): the drop-in transcriber end to end. The same host logic runs once on libwlx.so (through the
+C-ABI) and once on the CPU oracle (tests/oracle_engine.py); segments must agree: identical segment boundaries and
+token ids up to the first fp16-vs-fp32 near-tie (random weights give flat distributions), identical language."""
+import threading
+from unittest.mock import MagicMock
+
+import numpy as np
+import pytest
+
+from oracle import logmel as olm
+from tests import helpers as H
+from tests.oracle_engine import OracleEngine
+
+pytestmark = pytest.mark.gpu
+
+
+def _common_prefix(a, b):
+    n = 0
+    while n < min(len(a), len(b)) and a[n] == b[n]:
+        n += 1
+    return n
+
+
+@pytest.fixture(scope="module")
+def pair(gpu):
+    from whisperlive_amd.specs import WhisperSpec
+    from whisperlive_amd.tokenizer import synthetic_tokenizer
+    from whisperlive_amd.transcriber import WhisperModelHIP
+    from whisperlive_amd.weights import random_weights
+    spec = WhisperSpec(n_mels=80, d_model=256, n_heads=4, enc_layers=2, dec_layers=2, ffn=1024, vocab=4310)
+    w = random_weights(spec, seed=21)
+    tok = synthetic_tokenizer(spec.vocab)
+    hip = WhisperModelHIP("rand", weights=w, spec=spec, hf_tokenizer=tok, max_batch=4, multilingual=True)
+    ora = WhisperModelHIP("rand", engine=OracleEngine(spec, H.f16_weights(w)), hf_tokenizer=tok, max_batch=4, multilingual=True)
+    yield hip, ora
+    hip.close()
+    hip.engine.close()
+
+
+def test_transcribe_matches_oracle_pipeline(pair):
+    hip, ora = pair
+    pcm = olm.speech_like_pcm(7.0, seed=3)
+    kw = dict(language="en", temperature=0.0, max_new_tokens=20, vad_filter=False)
+    gs, gi = hip.transcribe(pcm, **kw)
+    rs, ri = ora.transcribe(pcm, **kw)
+    assert gi.language == ri.language == "en" and gi.duration == ri.duration == 7.0
+    gt = [t for s in gs for t in s.tokens]
+    rt = [t for s in rs for t in s.tokens]
+    n = _common_prefix(gt, rt)
+    print("transcribe common prefix", n, len(rt), [(s.start, s.end) for s in gs], [(s.start, s.end) for s in rs])
+    assert n >= min(6, len(rt))
+    if gt == rt:
+        assert [(s.start, s.end, s.text) for s in gs] == [(s.start, s.end, s.text) for s in rs]
+        assert abs(gs[0].avg_logprob - rs[0].avg_logprob) < 2e-2 and abs(gs[0].no_speech_prob - rs[0].no_speech_prob) < 1e-2
+
+
+def test_language_detection_matches_oracle(pair):
+    hip, ora = pair
+    pcm = olm.speech_like_pcm(4.0, seed=9)
+    gl = hip.detect_language(audio=pcm)
+    rl = ora.detect_language(audio=pcm)
+    gp, rp = dict(gl[2]), dict(rl[2])
+    assert set(gp) == set(rp) and len(gp) == 99
+    assert max(abs(gp[k] - rp[k]) for k in gp) < 3e-3
+    assert abs(sum(gp.values()) - 1.0) < 1e-3
+
+
+def test_vad_gate_and_streaming_session_on_the_engine(pair):
+    """ServeClientHIP driven like the server drives it: frames in, JSON segments out, metric observations recorded."""
+    import json
+    import time
+    from whisperlive_amd import metrics
+    from whisperlive_amd.serve_client import ServeClientHIP
+    hip, _ = pair
+    metrics.snapshot(reset=True)
+    ws = MagicMock()
+    c = ServeClientHIP(ws, client_uid="s1", model="x.en", transcriber=hip, use_vad=True, same_output_threshold=2)
+    pcm = olm.speech_like_pcm(6.0, seed=5)
+    for i in range(0, pcm.size, 4096):
+        c.add_frames(pcm[i:i + 4096])
+    deadline = time.time() + 20
+    while time.time() < deadline and metrics.snapshot()["chunks"] < 2:
+        time.sleep(0.05)
+    c.cleanup(); c.trans_thread.join(timeout=5)
+    snap = metrics.snapshot()
+    assert snap["chunks"] >= 2 and snap["errors"] == {} and snap["xrt"] > 1.0, snap
+    msgs = [json.loads(a[0][0]) for a in ws.send.call_args_list]
+    assert msgs[0]["message"] == "SERVER_READY" and any("segments" in m for m in msgs)
+    # silence: VAD gate removes everything -> None -> offset advances, no segments
+    out = hip.transcribe(np.zeros(32000, np.float32), vad_filter=True, vad_parameters={"threshold": 0.5})
+    assert out == (None, None)
+
+
+def test_batch_worker_on_device_equals_single_requests(pair):
+    from whisperlive_amd.batching import BatchInferenceWorker, BatchRequest
+    hip, _ = pair
+    clips = [olm.speech_like_pcm(3.0 + i, seed=40 + i) for i in range(3)]
+    w = BatchInferenceWorker(hip, max_batch_size=4, batch_window_ms=10)
+    # force T=0 only so the comparison is deterministic
+    w.TEMPERATURES = (0.0,)
+    reqs = [BatchRequest(audio=c, language="en", use_vad=False) for c in clips]
+    w._process_batch(reqs)
+    assert all(r.error is None and r.future.is_set() for r in reqs)
+    for c, r in zip(clips, reqs):
+        solo = BatchRequest(audio=c, language="en", use_vad=False)
+        w2 = BatchInferenceWorker(hip, max_batch_size=4)
+        w2.TEMPERATURES = (0.0,)
+        w2._process_multi([solo])
+        assert [s.tokens for s in solo.result] == [s.tokens for s in r.result]
+    # concurrent clients on distinct slots (one engine, one HIP stream each)
+    outs = [None] * 3
+    ths = [threading.Thread(target=lambda i=i: outs.__setitem__(i, hip.transcribe(clips[i], language="en", temperature=0.0,
+                                                                                   max_new_tokens=12)[0])) for i in range(3)]
+    [t.start() for t in ths]; [t.join(60) for t in ths]
+    seq = [hip.transcribe(clips[i], language="en", temperature=0.0, max_new_tokens=12)[0] for i in range(3)]
+    assert [[s.tokens for s in o] for o in outs] == [[s.tokens for s in o] for o in seq]
