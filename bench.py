@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--model", default="small.en")
     ap.add_argument("--decode-steps", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-decode-steps", type=int, default=6)
+    ap.add_argument("--cpu-decode-steps", type=int, default=32)
     args = ap.parse_args()
 
     import torch
@@ -175,6 +175,11 @@ def main():
                     launches_per_decode_step=dom["launches"], avg_us=dom["avg_us"],
                     algorithmic_bytes_per_launch=dom["bytes_per_launch"])
         roof["frac"] = roof["achieved"] / roof["peak"]
+        # the one launch of the step that is bandwidth- rather than latency-sized: the vocabulary projection (80 MB)
+        big = max(prof, key=lambda k: k["bytes_per_launch"])
+        roof["largest_launch"] = dict(kernel=big["name"], algorithmic_bytes=big["bytes_per_launch"], avg_us=big["avg_us"],
+                                      achieved=big["bytes_per_launch"] / (big["avg_us"] * 1e-6) / 1e9,
+                                      frac=big["bytes_per_launch"] / (big["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS)
         step_us = sum(k["total_us"] for k in prof)
         step_graph_ms = slot.debug_time_decode_step(rows=5, t=1 + args.decode_steps // 2, iters=50)
         sb = decode_step_bytes(spec, 5, 1 + args.decode_steps // 2)

@@ -32,6 +32,7 @@ struct GemvParams {
     int in_mode, out_mode;
     int M;                                   // live rows
     int K, KT, N;                            // K real, KT = Kpad/32, N real outputs
+    int KTW;                                 // (set by the launcher) k-tiles per wave, even
     const half_t* Wp; const float* bias;
     // GEMV_IN_LN
     const float* X; long ldx; const float* gamma; const float* beta;
@@ -49,6 +50,10 @@ struct GemvParams {
     const int* done;
 };
 void launch_dec_gemv(const GemvParams& p, hipStream_t s);
+// kernel name (as rocprofv3 prints it) the launcher picks for these parameters — profiling hook
+const char* dec_gemv_kernel_name(const GemvParams& p);
+// WLX_DECODE_V1=1 selects the first-generation decode kernels (kept as the in-tree A/B reference)
+extern bool g_decode_v1;
 
 // causal self-attention over the KV cache, one wave per (row, head)
 void launch_dec_self_attn(const half_t* q, long ldq, const half_t* Kc, const half_t* Vc, long cache_row_stride,
@@ -80,7 +85,15 @@ struct SearchState {            // device pointers, one set per slot
     int* nsp_row;               // [rows] 1 if this row's raw distribution defines no_speech_prob (-1 none)
     // row tables (mutable here)
     int* token; int* pos; short* anc; int* intok;
+    // chunked scan of the logits rows (beam mode, search_scan_kernel -> search_merge_update_kernel)
+    float* scan_stats;          // [rows][SC_MAXCH][SC_NSTAT]
+    float* scan_cv; int* scan_ci;   // [rows][SC_MAXCH + 1][WLX_MAX_CAND] per-chunk candidate lists (value desc, id asc)
 };
+#define SC_THREADS 256
+#define SC_NPT 8
+#define SC_CHUNK (SC_THREADS * SC_NPT)   // 2048 vocabulary ids per scan workgroup
+#define SC_MAXCH 26                      // vocab <= 53248
+#define SC_NSTAT 8
 struct SearchParams {
     int V; long ldl;
     int items, R, rows;
@@ -98,6 +111,11 @@ struct SearchParams {
 // SearchParams live in device memory (sp_dev) so a captured step graph is reusable across calls
 void launch_search_rows(const float* logits, const SearchParams* sp_dev, int rows, const SearchState& st, hipStream_t s);
 void launch_search_update(const SearchParams* sp_dev, int items, const SearchState& st, hipStream_t s);
+// beam mode, second generation: (chunks x rows) scan workgroups + one merge/update workgroup per item
+void launch_search_scan(const float* logits, long ldl, int V, const SearchParams* sp_dev, int rows, const SearchState& st,
+                        hipStream_t s);
+void launch_search_merge_update(const float* logits, long ldl, int V, const SearchParams* sp_dev, int items,
+                                const SearchState& st, hipStream_t s);
 // softmax prob of token `tok` in given logits rows -> out[rows]
 void launch_token_prob(const float* logits, long ldl, int V, int rows, int tok, float* out, hipStream_t s);
 // softmax restricted to ids -> probs[rows][n]

@@ -36,7 +36,7 @@ struct Prof { std::vector<ProfRec> recs; std::vector<std::string> names; int t =
 struct Slot {
     int B = 0, R = 0, rows_cap = 0, cache_rows = 0, groups_cap = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_poll0 = nullptr, ev_poll1 = nullptr;
     std::vector<void*> allocs;
     // features
     float* pcm = nullptr; size_t pcm_cap = 0;       // [B][pcm_cap]

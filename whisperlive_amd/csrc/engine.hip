@@ -320,6 +320,8 @@ extern "C" int32_t wlx_engine_create(const wlx_spec* spec, const wlx_tensor* wei
     e->H = spec->n_heads;
     const char* ng = getenv("WLX_NO_GRAPH");
     e->use_graph = !(ng && ng[0] == '1');
+    const char* v1 = getenv("WLX_DECODE_V1");
+    g_decode_v1 = (v1 && v1[0] == '1');
     int rc = engine_load(e, weights, n_weights);
     if (rc != WLX_OK) {
         for (void* p : e->allocs) (void)hipFree(p);
@@ -337,6 +339,8 @@ static void slot_free(Slot* s) {
     if (s->h_stage) (void)hipHostFree(s->h_stage);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->ev_poll0) (void)hipEventDestroy(s->ev_poll0);
+    if (s->ev_poll1) (void)hipEventDestroy(s->ev_poll1);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -397,6 +401,8 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
     int rc = [&]() -> int {
         CK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         CK(hipEventCreate(&s->ev0)); CK(hipEventCreate(&s->ev1));
+        CK(hipEventCreateWithFlags(&s->ev_poll0, hipEventDisableTiming));
+        CK(hipEventCreateWithFlags(&s->ev_poll1, hipEventDisableTiming));
         CKR(slot_grow_audio(e, s, 480000));
         CKR(dalloc(s->allocs, &s->gmax, (size_t)B));
         s->featT_stride = (long)(WLX_N_FRAMES + 2) * sp.n_mels + 64;
@@ -447,6 +453,9 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         CKR(dalloc(s->allocs, &st.n_hyp, (size_t)B)); CKR(dalloc(s->allocs, &st.no_speech, (size_t)B));
         CKR(dalloc(s->allocs, &st.nsp_row, (size_t)RC));
         st.token = s->d_token; st.pos = s->d_pos; st.anc = s->d_anc; st.intok = s->d_intok;
+        CKR(dalloc(s->allocs, &st.scan_stats, (size_t)RC * SC_MAXCH * SC_NSTAT));
+        CKR(dalloc(s->allocs, &st.scan_cv, (size_t)RC * (SC_MAXCH + 1) * WLX_MAX_CAND));
+        CKR(dalloc(s->allocs, &st.scan_ci, (size_t)RC * (SC_MAXCH + 1) * WLX_MAX_CAND));
         CKR(dalloc(s->allocs, &s->d_sp, 1));
         CKR(dalloc(s->allocs, &s->d_suppress, (size_t)(1024 * 52 / 32)));
         CKR(dalloc(s->allocs, &s->d_lang_ids, 256));
@@ -671,12 +680,7 @@ static inline void plaunch(Slot* s, const char* name, double bytes, F&& f) {
     (void)hipEventRecord(b, s->stream);
     s->prof->recs.push_back(ProfRec{name, bytes, a, b});
 }
-static std::string gemv_name(const GemvParams& p) {
-    const int MT = (p.M + 15) / 16;
-    char buf[64];
-    snprintf(buf, sizeof(buf), "dec_gemv_kernel<%d, %d, %d>", MT > 4 ? 4 : MT, MT == 1 ? 2 : 1, p.in_mode);
-    return buf;
-}
+static std::string gemv_name(const GemvParams& p) { return dec_gemv_kernel_name(p); }
 static double gemv_bytes(const GemvParams& p) { return 2.0 * (double)p.N * (double)p.K + (p.bias ? 4.0 * p.N : 0.0); }
 static void pgemv(Slot* s, const GemvParams& p) {
     if (!s->prof) { launch_dec_gemv(p, s->stream); return; }
@@ -692,7 +696,10 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
     const wlx_spec& sp = e->spec;
     const int d = sp.d_model, F = sp.ffn, H = e->H;
     hipStream_t st = s->stream;
-    const int* done = check_done ? s->st.done : nullptr;
+    // The decoder pass only rewrites scratch and re-appends the same K/V at the same position when it runs once
+    // more after the search has raised `done` (the host runs at most one step ahead), so the second-generation
+    // kernels do not test the flag: the test was a dependent scalar load at the head of ~100 launches per step.
+    const int* done = (check_done && g_decode_v1) ? s->st.done : nullptr;
     RowTables rt{s->d_token, s->d_pos, s->d_cache, s->d_ancrow, s->d_anc, s->d_intok};
     plaunch(s, "dec_embed_kernel", (double)rows * d * (2 + 4), [&] { launch_dec_embed(e->tok_emb16, e->dec_pos, d, rt, rows, s->xd, done, st); });
     const long crs = (long)WLX_T_TEXT * d;
@@ -707,7 +714,7 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
         p.Yh = s->qd; p.ldyh = d; p.d = d; p.qscale = 0.125f; p.Kc = kc; p.Vc = vc; p.cache_row_stride = crs;
         p.row_cache = s->d_cache; p.row_pos = s->d_pos; p.done = done;
         pgemv(s, p);
-        plaunch(s, "dec_self_attn_kernel", 4.0 * rows * d * (s->prof ? s->prof->t + 1 : 1), [&] { launch_dec_self_attn(s->qd, d, kc, vc, crs, d, H, rt, rows, s->attnd, d, done, st); });
+        plaunch(s, g_decode_v1 ? "dec_self_attn_kernel" : "dec_self_attn2_kernel", 4.0 * rows * d * (s->prof ? s->prof->t + 1 : 1), [&] { launch_dec_self_attn(s->qd, d, kc, vc, crs, d, H, rt, rows, s->attnd, d, done, st); });
         p = GemvParams{};
         p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
         p.Wp = w.Wo; p.bias = w.bo; p.Xh = s->attnd; p.ldxh = d; p.Xres = s->xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
@@ -718,7 +725,7 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
         p.Wp = w.Wcq; p.bias = w.bcq; p.X = s->xd; p.ldx = d; p.gamma = w.ln2_g; p.beta = w.ln2_b;
         p.Yh = s->qd; p.ldyh = d; p.qscale = 0.125f; p.done = done;
         pgemv(s, p);
-        plaunch(s, "dec_cross_attn_kernel", 4.0 * groups * WLX_T_AUDIO * d, [&] {
+        plaunch(s, g_decode_v1 ? "dec_cross_attn_kernel" : "dec_cross_attn2_kernel", 4.0 * groups * WLX_T_AUDIO * d, [&] {
             launch_dec_cross_attn(s->qd, d, s->ck + (size_t)l * s->B * WLX_T_AUDIO_PAD * d, d, (long)WLX_T_AUDIO_PAD * d,
                                   s->cvt + (size_t)l * s->B * d * WLX_T_AUDIO_PAD, WLX_T_AUDIO_PAD, (long)d * WLX_T_AUDIO_PAD,
                                   H, R, groups, rows, s->d_group_item, s->part_o, s->part_ml, done, st);
@@ -801,15 +808,26 @@ static int set_anc_rows(Slot* s, const std::vector<short>& anc_host, int first_r
     return WLX_OK;
 }
 
-static int get_step_graph(Engine* e, Slot* s, int rows, int R, int groups, hipGraphExec_t* out) {
-    StepGraphKey key{rows, R, groups};
+// token search of one step: beam mode runs the chunked scan + merge/update pair, sampling (T > 0 fallback)
+// the one-workgroup-per-row kernels
+static void launch_search(Engine* e, Slot* s, int rows, int groups, bool sampling) {
+    if (sampling || g_decode_v1) {
+        launch_search_rows(s->logits, s->d_sp, rows, s->st, s->stream);
+        launch_search_update(s->d_sp, groups, s->st, s->stream);
+    } else {
+        launch_search_scan(s->logits, s->ldl, e->spec.vocab, s->d_sp, rows, s->st, s->stream);
+        launch_search_merge_update(s->logits, s->ldl, e->spec.vocab, s->d_sp, groups, s->st, s->stream);
+    }
+}
+
+static int get_step_graph(Engine* e, Slot* s, int rows, int R, int groups, bool sampling, hipGraphExec_t* out) {
+    StepGraphKey key{rows, R, groups * 2 + (sampling ? 1 : 0)};
     auto it = s->graphs.find(key);
     if (it != s->graphs.end()) { *out = it->second; return WLX_OK; }
     hipGraph_t graph;
     CK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
     decoder_pass(e, s, rows, R, groups, true, true);
-    launch_search_rows(s->logits, s->d_sp, rows, s->st, s->stream);
-    launch_search_update(s->d_sp, groups, s->st, s->stream);
+    launch_search(e, s, rows, groups, sampling);
     CK(hipStreamEndCapture(s->stream, &graph));
     hipGraphExec_t exec;
     CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
@@ -819,15 +837,14 @@ static int get_step_graph(Engine* e, Slot* s, int rows, int R, int groups, hipGr
     return WLX_OK;
 }
 
-static int run_step(Engine* e, Slot* s, int rows, int R, int groups) {
+static int run_step(Engine* e, Slot* s, int rows, int R, int groups, bool sampling) {
     if (e->use_graph) {
         hipGraphExec_t exec;
-        CKR(get_step_graph(e, s, rows, R, groups, &exec));
+        CKR(get_step_graph(e, s, rows, R, groups, sampling, &exec));
         CK(hipGraphLaunch(exec, s->stream));
     } else {
         decoder_pass(e, s, rows, R, groups, true, true);
-        launch_search_rows(s->logits, s->d_sp, rows, s->st, s->stream);
-        launch_search_update(s->d_sp, groups, s->st, s->stream);
+        launch_search(e, s, rows, groups, sampling);
         CK(hipGetLastError());
     }
     return WLX_OK;
@@ -957,12 +974,15 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
         CK(hipMemcpyAsync(S.nsp_row, nsp.data(), rows * 4, hipMemcpyHostToDevice, st));
         CK(hipStreamSynchronize(st));
     }
-    // ---- autoregressive loop: one graph replay per step, host looks at the done flag every few steps
-    int* h_done = s->h_stage + (s->h_stage_ints - 4);
-    *h_done = 0;
+    // ---- autoregressive loop: one graph replay per step. The host never lets the stream run dry: step k+1 is
+    // enqueued BEFORE the host looks at the done flag copied after step k (double-buffered pinned words, one event
+    // each), so the check costs no GPU idle time; once the flag is set the one extra step already in flight is a
+    // chain of early-exit kernels (every decode kernel tests the flag).
+    volatile int* h_done = s->h_stage + (s->h_stage_ints - 4);
+    h_done[0] = 0; h_done[1] = 0;
     int steps_run = 0;
-    const int CHK = 4;
-    for (int step = 0; step < max_steps; ++step) {
+    bool finished = false;
+    for (int step = 0; step < max_steps && !finished; ++step) {
         if (injected_logits) {
             if (step >= inj_steps) break;
             // test hook: logits come from the caller; the embed kernel still records the fed tokens
@@ -970,17 +990,20 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
             launch_dec_embed(e->tok_emb16, e->dec_pos, e->spec.d_model, rt, rows, s->xd, nullptr, st);
             CK(hipMemcpy2DAsync(s->logits, (size_t)s->ldl * 4, inj + (size_t)step * rows * V, (size_t)V * 4, (size_t)V * 4, rows,
                                 hipMemcpyHostToDevice, st));
-            launch_search_rows(s->logits, s->d_sp, rows, s->st, st);
-            launch_search_update(s->d_sp, batch, s->st, st);
+            launch_search(e, s, rows, batch, sampling);
             CK(hipGetLastError());
         } else {
-            CKR(run_step(e, s, rows, R, batch));
+            CKR(run_step(e, s, rows, R, batch, sampling));
         }
         ++steps_run;
-        if ((step + 1) % CHK == 0 || step == max_steps - 1 || injected_logits) {
-            CK(hipMemcpyAsync(h_done, S.done, 4, hipMemcpyDeviceToHost, st));
+        CK(hipMemcpyAsync(const_cast<int*>(h_done) + (step & 1), S.done, 4, hipMemcpyDeviceToHost, st));
+        CK(hipEventRecord((step & 1) ? s->ev_poll1 : s->ev_poll0, st));
+        if (injected_logits) {
             CK(hipStreamSynchronize(st));
-            if (*h_done) break;
+            finished = h_done[step & 1] != 0;
+        } else if (step >= 1) {
+            CK(hipEventSynchronize(((step - 1) & 1) ? s->ev_poll1 : s->ev_poll0));
+            finished = h_done[(step - 1) & 1] != 0;
         }
     }
     CK(hipStreamSynchronize(st));
