@@ -25,10 +25,6 @@ except Exception as e:
     print("bench parse failed:", e)
 PY
 tail -5 "$OUT/bench.err"
-WLX_DECODE_V1=1 timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline > "$OUT/bench_v1.json" 2> "$OUT/bench_v1.err"
-echo "bench v1 rc=$?"; python -c "
-import json,sys
-d=json.loads(open('$OUT/bench_v1.json').read().strip().splitlines()[-1]); print('v1:', d['value'], d['ms_per_step'], d['stage_ms'], d['decode_step']['graph_replay_ms'])" 2>&1 | tail -2
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/rocprof" -o wlx --output-format csv -- \
   python "$REPO/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/rocprof.log" 2>&1
@@ -36,5 +32,13 @@ echo "rocprof rc=$?"
 cd "$REPO"
 F=$(find "$OUT/rocprof" -name '*kernel_stats.csv' | head -1)
 [ -n "$F" ] && head -30 "$F"
-find "$OUT/rocprof" -name '*kernel_trace.csv' -size +20M -delete
+# HBM traffic counters: their own pass (no --stats / trace domains besides kernel-trace), one window only
+cd /tmp
+timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d "$OUT/pmc_fetch" -o wlx --output-format csv -- \
+  python "$REPO/bench.py" --steps 1 --warmup 0 --no-cpu-baseline > "$OUT/pmc_fetch.log" 2>&1
+echo "pmc fetch rc=$?"
+cd "$REPO"
+python scripts/pmc_summary.py "$OUT/pmc_fetch" > "$OUT/pmc_fetch_summary.csv" 2>&1; head -30 "$OUT/pmc_fetch_summary.csv"
+find "$OUT" -name '*kernel_trace.csv' -size +5M -delete
+find "$OUT" -name '*counter_collection.csv' -size +5M -delete
 du -sh "$OUT"

@@ -75,12 +75,15 @@ def test_vad_gate_and_streaming_session_on_the_engine(pair):
     metrics.snapshot(reset=True)
     ws = MagicMock()
     c = ServeClientHIP(ws, client_uid="s1", model="x.en", transcriber=hip, use_vad=True, same_output_threshold=2)
-    pcm = olm.speech_like_pcm(6.0, seed=5)
-    for i in range(0, pcm.size, 4096):
-        c.add_frames(pcm[i:i + 4096])
-    deadline = time.time() + 20
-    while time.time() < deadline and metrics.snapshot()["chunks"] < 2:
-        time.sleep(0.05)
+    # two bursts of frames: whatever the first transcript commits (random weights), the second burst leaves
+    # unconsumed audio behind, so a second chunk is always due
+    for burst, seed in enumerate((5, 6)):
+        pcm = olm.speech_like_pcm(6.0, seed=seed)
+        for i in range(0, pcm.size, 4096):
+            c.add_frames(pcm[i:i + 4096])
+        deadline = time.time() + 20
+        while time.time() < deadline and metrics.snapshot()["chunks"] < burst + 1:
+            time.sleep(0.05)
     c.cleanup(); c.trans_thread.join(timeout=5)
     snap = metrics.snapshot()
     assert snap["chunks"] >= 2 and snap["errors"] == {} and snap["xrt"] > 1.0, snap
