@@ -10,13 +10,15 @@ from pathlib import Path
 
 PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
-LIB_PATH = PKG_DIR / "libwlx.so"
+# WLX_LIB selects another build of the same sources (scripts/trace_step.py: libwlx_trace.so, compiled with -DWLX_TRACE)
+DEFAULT_LIB = PKG_DIR / "libwlx.so"
+LIB_PATH = Path(os.environ["WLX_LIB"]).resolve() if os.environ.get("WLX_LIB") else DEFAULT_LIB
 SOURCES = ["pack.hip", "logmel.hip", "gemm.hip", "attention.hip", "decoder.hip", "search.hip", "engine.hip"]
 EXPORTS = [
     "wlx_abi_version", "wlx_last_error", "wlx_engine_create", "wlx_engine_destroy", "wlx_engine_spec",
     "wlx_slot_create", "wlx_slot_destroy", "wlx_logmel", "wlx_pcm_put", "wlx_logmel_resident", "wlx_features_get", "wlx_features_set", "wlx_encode",
     "wlx_encoder_output_get", "wlx_generate", "wlx_generate_ex", "wlx_detect_language", "wlx_timings_get", "wlx_sync",
-    "wlx_debug_logits_get", "wlx_debug_decode_logits", "wlx_debug_search", "wlx_debug_time_decode_step", "wlx_debug_profile_step",
+    "wlx_debug_logits_get", "wlx_debug_decode_logits", "wlx_debug_search", "wlx_debug_time_decode_step", "wlx_debug_profile_step", "wlx_debug_trace_step",
 ]
 
 
@@ -57,24 +59,39 @@ class wlx_kernel_stat(C.Structure):
                 ("total_us_per_step", C.c_float), ("bytes_per_launch", C.c_double)]
 
 
+def build_trace() -> Path:
+    """libwlx_trace.so: the same sources with -DWLX_TRACE (in-kernel timeline marks, profiling only)."""
+    out = PKG_DIR / "libwlx_trace.so"
+    srcs = [CSRC / s for s in SOURCES]
+    deps = srcs + list(CSRC.glob("*.h"))
+    if out.exists() and all(out.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return out
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DWLX_TRACE", "-o", str(out)] + [str(s) for s in srcs]
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise WlxError(f"hipcc failed ({proc.returncode}):\n{proc.stderr[-4000:]}")
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile every HIP source for gfx950 into whisperlive_amd/libwlx.so (hipcc cross-compiles without a GPU)."""
     srcs = [CSRC / s for s in SOURCES]
     deps = srcs + list(CSRC.glob("*.h")) + [PKG_DIR.parent / "include" / "wlx.h"]
-    if not force and LIB_PATH.exists() and all(LIB_PATH.stat().st_mtime >= d.stat().st_mtime for d in deps):
-        return LIB_PATH
+    if not force and DEFAULT_LIB.exists() and all(DEFAULT_LIB.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return DEFAULT_LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
         raise WlxError("hipcc not found: cannot build libwlx.so (ROCm toolchain required)")
-    tmp = LIB_PATH.with_suffix(".so.tmp")
+    tmp = DEFAULT_LIB.with_suffix(".so.tmp")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", str(tmp)] + [str(s) for s in srcs]
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or proc.returncode != 0:
         print(proc.stdout, proc.stderr)
     if proc.returncode != 0:
         raise WlxError(f"hipcc failed ({proc.returncode}):\n{proc.stderr[-4000:]}")
-    os.replace(tmp, LIB_PATH)
-    return LIB_PATH
+    os.replace(tmp, DEFAULT_LIB)
+    return DEFAULT_LIB
 
 
 _lib = None
@@ -121,6 +138,7 @@ def load() -> C.CDLL:
     lib.wlx_debug_search.argtypes = [vp, i32, f32p, i32, i32p, i32, C.POINTER(wlx_gen_opts), i32p, i32, i32p, f32p]
     lib.wlx_debug_time_decode_step.argtypes = [vp, i32, i32, i32, i32, f32p]
     lib.wlx_debug_profile_step.argtypes = [vp, i32, i32, i32, i32, C.POINTER(wlx_kernel_stat), i32, i32p]
+    lib.wlx_debug_trace_step.argtypes = [vp, i32, i32, i32, i32, C.POINTER(C.c_uint64), i64, C.c_char_p, i32p]
     for name in EXPORTS:
         fn = getattr(lib, name)
         if name not in ("wlx_last_error", "wlx_engine_destroy"):

@@ -55,3 +55,44 @@ __device__ __forceinline__ f16x4 ld_f16x4(const half_t* p) {
 }
 
 #define WLX_NEG_INF (-__builtin_inff())
+
+// ------------------------------------------------------------------ WLX_TRACE: in-kernel timeline (profiling builds only)
+// libwlx_trace.so (scripts/trace_step.py) is the same source compiled with -DWLX_TRACE: wave 0 of every workgroup of
+// the decode-step kernels stamps s_memrealtime (100 MHz, chip-wide) at entry/exit (plain stores, no atomics: 3 atomics per workgroup on one
+// header word were measured to add up to 7 us of serialised tail to a 192-workgroup launch) and s_memtime (shader clock) at a
+// few interior marks; the marks drain outstanding memory operations first, so a traced kernel is slightly slower
+// than the production one — the trace tells WHERE a launch spends its time, the production build how long it takes.
+#ifdef WLX_TRACE
+#define WLX_TR_MAXWG 2048
+#define WLX_TR_NMARK 6
+#define WLX_TR_REC 8                       // u64 per workgroup record: rt0, rt1, mark[0..5]
+#define WLX_TR_STRIDE ((WLX_TR_MAXWG + 1) * WLX_TR_REC)   // per launch: header record + workgroup records
+struct WlxTrace { unsigned long long* buf; int seq; };
+#define WLX_TR_PARAM , WlxTrace trc
+#define WLX_TR_FIELD WlxTrace trc;
+__device__ __forceinline__ unsigned long long wlx_rt() { return __builtin_amdgcn_s_memrealtime(); }
+__device__ __forceinline__ unsigned long long wlx_ct() { return __builtin_amdgcn_s_memtime(); }
+#define WLX_TR_BEGIN() unsigned long long _trm[WLX_TR_NMARK] = {0, 0, 0, 0, 0, 0}; \
+    const unsigned long long _trt0 = wlx_rt(); _trm[0] = wlx_ct();
+#define WLX_TR_MARK(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); _trm[i] = wlx_ct(); } while (0)
+#define WLX_TR_MARK_NOWAIT(i) do { _trm[i] = wlx_ct(); } while (0)
+#define WLX_TR_END(TRC) do { \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    if ((TRC).buf && threadIdx.x == 0) { \
+        const unsigned long long _trt1 = wlx_rt(); \
+        const int _wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+        unsigned long long* _h = (TRC).buf + (size_t)(TRC).seq * WLX_TR_STRIDE; \
+        if (_wg < WLX_TR_MAXWG) { \
+            unsigned long long* _r = _h + (size_t)(_wg + 1) * WLX_TR_REC; \
+            _r[0] = _trt0; _r[1] = _trt1; \
+            for (int _i = 0; _i < WLX_TR_NMARK; ++_i) _r[2 + _i] = _trm[_i]; \
+        } \
+    } } while (0)
+#else
+#define WLX_TR_PARAM
+#define WLX_TR_FIELD
+#define WLX_TR_BEGIN()
+#define WLX_TR_MARK(i)
+#define WLX_TR_MARK_NOWAIT(i)
+#define WLX_TR_END(TRC)
+#endif

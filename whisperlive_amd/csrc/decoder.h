@@ -33,6 +33,7 @@ struct GemvParams {
     int M;                                   // live rows
     int K, KT, N;                            // K real, KT = Kpad/32, N real outputs
     int KTW;                                 // (set by the launcher) k-tiles per wave, even
+    int NCH;                                 // (set by the launcher, lean kernel) chunks of CH k-tiles per wave
     const half_t* Wp; const float* bias;
     // GEMV_IN_LN
     const float* X; long ldx; const float* gamma; const float* beta;
@@ -48,12 +49,30 @@ struct GemvParams {
     int d; float qscale; half_t* Kc; half_t* Vc; long cache_row_stride;
     const int* row_cache; const int* row_pos;
     const int* done;
+    WLX_TR_FIELD
 };
+#ifdef WLX_TRACE
+// host side of the trace: device buffer + running launch index (baked into the kernel arguments at capture time)
+extern unsigned long long* g_trace_buf;
+extern int g_trace_seq;
+extern const char* g_trace_names[512];
+static inline WlxTrace trace_next(const char* name) {
+    WlxTrace t{g_trace_buf, g_trace_seq};
+    if (g_trace_seq < 512) g_trace_names[g_trace_seq] = name;
+    ++g_trace_seq;
+    return t;
+}
+#define WLX_TR_ARG(name) , trace_next(name)
+#else
+#define WLX_TR_ARG(name)
+#endif
 void launch_dec_gemv(const GemvParams& p, hipStream_t s);
 // kernel name (as rocprofv3 prints it) the launcher picks for these parameters — profiling hook
 const char* dec_gemv_kernel_name(const GemvParams& p);
 // WLX_DECODE_V1=1 selects the first-generation decode kernels (kept as the in-tree A/B reference)
 extern bool g_decode_v1;
+// WLX_DECODE_V2=1 selects the second-generation kernels (dec_gemv1 / cross_attn2): A/B reference for the lean ones
+extern bool g_decode_v2;
 
 // causal self-attention over the KV cache, one wave per (row, head)
 void launch_dec_self_attn(const half_t* q, long ldq, const half_t* Kc, const half_t* Vc, long cache_row_stride,

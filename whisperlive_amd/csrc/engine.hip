@@ -322,6 +322,8 @@ extern "C" int32_t wlx_engine_create(const wlx_spec* spec, const wlx_tensor* wei
     e->use_graph = !(ng && ng[0] == '1');
     const char* v1 = getenv("WLX_DECODE_V1");
     g_decode_v1 = (v1 && v1[0] == '1');
+    const char* v2 = getenv("WLX_DECODE_V2");
+    g_decode_v2 = (v2 && v2[0] == '1');
     int rc = engine_load(e, weights, n_weights);
     if (rc != WLX_OK) {
         for (void* p : e->allocs) (void)hipFree(p);
@@ -725,7 +727,7 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
         p.Wp = w.Wcq; p.bias = w.bcq; p.X = s->xd; p.ldx = d; p.gamma = w.ln2_g; p.beta = w.ln2_b;
         p.Yh = s->qd; p.ldyh = d; p.qscale = 0.125f; p.done = done;
         pgemv(s, p);
-        plaunch(s, g_decode_v1 ? "dec_cross_attn_kernel" : "dec_cross_attn2_kernel", 4.0 * groups * WLX_T_AUDIO * d, [&] {
+        plaunch(s, g_decode_v1 ? "dec_cross_attn_kernel" : "dec_cross_attn3_kernel", 4.0 * groups * WLX_T_AUDIO * d, [&] {
             launch_dec_cross_attn(s->qd, d, s->ck + (size_t)l * s->B * WLX_T_AUDIO_PAD * d, d, (long)WLX_T_AUDIO_PAD * d,
                                   s->cvt + (size_t)l * s->B * d * WLX_T_AUDIO_PAD, WLX_T_AUDIO_PAD, (long)d * WLX_T_AUDIO_PAD,
                                   H, R, groups, rows, s->d_group_item, s->part_o, s->part_ml, done, st);
@@ -1172,6 +1174,61 @@ extern "C" int32_t wlx_debug_time_decode_step(wlx_engine* e, int32_t slot, int32
     *avg_ms_out = ms / (float)iters;
     CK(hipGraphExecDestroy(exec));
     return WLX_OK;
+}
+
+// In-kernel timeline of ONE decode step (scripts/trace_step.py). Only libwlx_trace.so (-DWLX_TRACE) records anything;
+// the production library reports WLX_ERR_STATE. out: [n_launches][WLX_TR_STRIDE] u64 records, names: [n_launches][48].
+extern "C" int32_t wlx_debug_trace_step(wlx_engine* e, int32_t slot, int32_t rows, int32_t t, int32_t with_search,
+                                        uint64_t* out, int64_t cap_u64, char* names, int32_t* n_launches_out) {
+#ifndef WLX_TRACE
+    (void)e; (void)slot; (void)rows; (void)t; (void)with_search; (void)out; (void)cap_u64; (void)names; (void)n_launches_out;
+    return fail(WLX_ERR_STATE, "libwlx.so was built without -DWLX_TRACE (use libwlx_trace.so, scripts/trace_step.py)");
+#else
+    Slot* s;
+    CKR(slot_get(e, slot, &s));
+    if (rows < 1 || rows > s->cache_rows || rows > 16 || t < 0 || t >= WLX_T_TEXT || !out || !names || !n_launches_out)
+        return fail(WLX_ERR_ARG, "bad arguments");
+    if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "decode before encode");
+    CK(hipSetDevice(e->device));
+    hipStream_t st = s->stream;
+    std::vector<int> tk(rows, 0), ps(rows, t), ca(rows), an(rows), gi(1, 0);
+    std::vector<short> anc((size_t)rows * WLX_T_TEXT);
+    for (int r = 0; r < rows; ++r) { ca[r] = an[r] = r; for (int p = 0; p < WLX_T_TEXT; ++p) anc[(size_t)r * WLX_T_TEXT + p] = (short)r; }
+    const size_t max_launch = 128;
+    unsigned long long* buf = nullptr;
+    CK(hipMalloc(&buf, max_launch * WLX_TR_STRIDE * 8));
+    g_trace_buf = buf; g_trace_seq = 0;
+    hipGraph_t graph; hipGraphExec_t exec;
+    auto reset_state = [&]() -> int {
+        CKR(set_anc_rows(s, anc, 0, rows));
+        CKR(upload_rows(s, tk, ps, ca, an, gi));
+        CK(hipMemsetAsync(s->st.done, 0, 4, st)); CK(hipMemsetAsync(s->st.item_done, 0, 4, st));
+        CK(hipMemsetAsync(s->st.n_hyp, 0, 4, st)); CK(hipMemsetAsync(s->st.n_finished, 0, 4, st));
+        return WLX_OK;
+    };
+    CKR(reset_state());
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+    decoder_pass(e, s, rows, rows, 1, true, true);
+    if (with_search) launch_search(e, s, rows, 1, false);
+    CK(hipStreamEndCapture(st, &graph));
+    CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    CK(hipGraphDestroy(graph));
+    const int n = g_trace_seq;
+    g_trace_buf = nullptr;
+    for (int i = 0; i < 3; ++i) { CKR(reset_state()); CK(hipGraphLaunch(exec, st)); }
+    CKR(reset_state());
+    CK(hipMemsetAsync(buf, 0, max_launch * WLX_TR_STRIDE * 8, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipGraphLaunch(exec, st));
+    CK(hipStreamSynchronize(st));
+    CK(hipGraphExecDestroy(exec));
+    if ((int64_t)n * WLX_TR_STRIDE > cap_u64) { (void)hipFree(buf); return fail(WLX_ERR_ARG, "trace buffer too small"); }
+    CK(hipMemcpy(out, buf, (size_t)n * WLX_TR_STRIDE * 8, hipMemcpyDeviceToHost));
+    CK(hipFree(buf));
+    for (int i = 0; i < n; ++i) { strncpy(names + (size_t)i * 48, g_trace_names[i] ? g_trace_names[i] : "?", 47); names[(size_t)i * 48 + 47] = 0; }
+    *n_launches_out = n;
+    return WLX_OK;
+#endif
 }
 
 extern "C" int32_t wlx_debug_profile_step(wlx_engine* e, int32_t slot, int32_t rows, int32_t t, int32_t iters,

@@ -549,9 +549,10 @@ __device__ __forceinline__ void sc_topk(float (&w)[SC_NPT], int id0, int lo, int
 }
 
 __global__ __launch_bounds__(SC_THREADS) void search_scan_kernel(const float* __restrict__ logits, long ldl, int V,
-                                                                 const SearchParams* __restrict__ spp, SearchState st) {
+                                                                 const SearchParams* __restrict__ spp, SearchState st WLX_TR_PARAM) {
     const int chunk = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
     const int id0 = chunk * SC_CHUNK;
+    WLX_TR_BEGIN();
     // the row slice first: its loads are in flight while the rule state is derived
     const float* lrow = logits + (long)r * ldl;
     float v[SC_NPT];
@@ -584,6 +585,7 @@ __global__ __launch_bounds__(SC_THREADS) void search_scan_kernel(const float* __
         if (tk >= sp.ts_begin) atomicMax(&last_ts_idx, j);
     }
     __syncthreads();
+    WLX_TR_MARK(1);
     const int wv_ = tid >> 6;
 
     // ---- raw (max, sum exp) of the chunk for no_speech_prob at the sot position
@@ -697,6 +699,7 @@ __global__ __launch_bounds__(SC_THREADS) void search_scan_kernel(const float* __
         so[0] = mx_text; so[1] = s_text; so[2] = mx_ts; so[3] = s_ts; so[4] = raw_m; so[5] = raw_s;
     }
 
+    WLX_TR_MARK(2);
     // ---- candidate lists
     const int hi = (id0 + SC_CHUNK < V) ? id0 + SC_CHUNK : V;
     const bool mixed = ts && id0 < sp.ts_begin && sp.ts_begin < hi;
@@ -705,6 +708,7 @@ __global__ __launch_bounds__(SC_THREADS) void search_scan_kernel(const float* __
     for (int i = 0; i < SC_NPT; ++i) w[i] = v[i];
     sc_topk(w, id0, 0, sp.ncand, st.scan_cv + ((long)r * (SC_MAXCH + 1) + chunk) * WLX_MAX_CAND,
             st.scan_ci + ((long)r * (SC_MAXCH + 1) + chunk) * WLX_MAX_CAND, sv, si);
+    WLX_TR_MARK(3);
     if (mixed) {
         __syncthreads();
 #pragma unroll
@@ -712,17 +716,19 @@ __global__ __launch_bounds__(SC_THREADS) void search_scan_kernel(const float* __
         sc_topk(w, id0, sp.ts_begin, sp.ncand, st.scan_cv + ((long)r * (SC_MAXCH + 1) + SC_MAXCH) * WLX_MAX_CAND,
                 st.scan_ci + ((long)r * (SC_MAXCH + 1) + SC_MAXCH) * WLX_MAX_CAND, sv, si);
     }
+    WLX_TR_END(trc);
 }
 
 void launch_search_scan(const float* logits, long ldl, int V, const SearchParams* sp_dev, int rows, const SearchState& st,
                         hipStream_t s) {
     const int nch = (V + SC_CHUNK - 1) / SC_CHUNK;
-    hipLaunchKernelGGL(search_scan_kernel, dim3(nch, rows), dim3(SC_THREADS), 0, s, logits, ldl, V, sp_dev, st);
+    hipLaunchKernelGGL(search_scan_kernel, dim3(nch, rows), dim3(SC_THREADS), 0, s, logits, ldl, V, sp_dev, st WLX_TR_ARG("search_scan"));
 }
 
 __global__ __launch_bounds__(256) void search_merge_update_kernel(const float* __restrict__ logits, long ldl, int V,
-                                                                  const SearchParams* __restrict__ spp, SearchState st) {
+                                                                  const SearchParams* __restrict__ spp, SearchState st WLX_TR_PARAM) {
     if (*st.done) return;
+    WLX_TR_BEGIN();
     const SearchParams sp = *spp;
     const int item = blockIdx.x;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -809,6 +815,7 @@ __global__ __launch_bounds__(256) void search_merge_update_kernel(const float* _
         }
     }
     __syncthreads();
+    WLX_TR_MARK(1);
 
     // ---------------- phase 2: search_update_kernel's beam bookkeeping, candidates read from LDS
     const int p = st.pos[r0];
@@ -866,6 +873,7 @@ __global__ __launch_bounds__(256) void search_merge_update_kernel(const float* _
         anc_s[b * WLX_T_TEXT + q] = st.anc[(long)(r0 + b) * WLX_T_TEXT + q];
     }
     __syncthreads();
+    WLX_TR_MARK(2);
     for (int hh = 0; hh < hyp_n; ++hh) {
         const int b = hyp_src[hh];
         int* dst = st.hyp_tokens + ((long)item * WLX_MAX_HYP + hyp_slot[hh]) * WLX_T_TEXT;
@@ -894,11 +902,12 @@ __global__ __launch_bounds__(256) void search_merge_update_kernel(const float* _
         st.pos[r0 + j] = p + 1;
         st.nsp_row[r0 + j] = 0;
     }
+    WLX_TR_END(trc);
 }
 
 void launch_search_merge_update(const float* logits, long ldl, int V, const SearchParams* sp_dev, int items,
                                 const SearchState& st, hipStream_t s) {
-    hipLaunchKernelGGL(search_merge_update_kernel, dim3(items), dim3(256), 0, s, logits, ldl, V, sp_dev, st);
+    hipLaunchKernelGGL(search_merge_update_kernel, dim3(items), dim3(256), 0, s, logits, ldl, V, sp_dev, st WLX_TR_ARG("search_merge_update"));
 }
 
 // ------------------------------------------------------------------ small softmax helpers

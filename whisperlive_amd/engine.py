@@ -241,3 +241,16 @@ class Slot:
         check(self.lib.wlx_debug_profile_step(self.engine._h, self.sid, rows, t, iters, arr, cap, C.byref(n)))
         return [dict(name=arr[i].name.decode(), launches=arr[i].launches_per_step, avg_us=arr[i].avg_us,
                      total_us=arr[i].total_us_per_step, bytes_per_launch=arr[i].bytes_per_launch) for i in range(n.value)]
+
+    def debug_trace_step(self, rows: int, t: int, with_search: bool = True):
+        """In-kernel timeline of one decode step (libwlx_trace.so only). Returns (names, records[n][2049][8] u64); record 0 of a launch is unused."""
+        stride = (2048 + 1) * 8
+        cap_launch = 128
+        buf = np.zeros(cap_launch * stride, dtype=np.uint64)
+        names = C.create_string_buffer(cap_launch * 48)
+        n = C.c_int32(0)
+        check(self.lib.wlx_debug_trace_step(self.engine._h, self.sid, rows, t, 1 if with_search else 0,
+                                            buf.ctypes.data_as(C.POINTER(C.c_uint64)), buf.size, names, C.byref(n)))
+        nl = n.value
+        nm = [names.raw[i * 48:(i + 1) * 48].split(b"\0")[0].decode() for i in range(nl)]
+        return nm, buf[: nl * stride].reshape(nl, 2049, 8)
