@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--t", type=int, default=33)
     ap.add_argument("--csv", default=None)
     ap.add_argument("--build-only", action="store_true")
+    ap.add_argument("--waves", action="store_true", help="per-wave detail for the lean GEMV launches of the first layer")
     args = ap.parse_args()
     from whisperlive_amd import _lib
     _lib.build_trace()
@@ -78,6 +79,18 @@ def main():
         print(f"{i:3d} {names[i]:<28} {cnt:5d} {(start - t0) * 10.0:8.0f} {gap:6.0f} {span:6.0f} {dur_rt.mean():7.0f} | "
               + " ".join(f"{m:7.0f}" for m in marks) + f"  (ticks; {ratio:.3f} ns/tick)")
         prev_end = end
+        if args.waves and names[i].startswith("gemv2") and i <= 9:
+            # per-wave records (index = workgroup * 16 + wave): when did each wave's loads land (m1), when did it reach
+            # the K-reduction barrier (m3), relative to its own entry; and its entry relative to the launch's first entry
+            raw = rec[i, 1:].astype(np.int64)
+            idx = np.nonzero(raw[:, 1] > 0)[0]
+            wv = idx % 16
+            for w_ in sorted(set(wv.tolist())):
+                sel = raw[idx[wv == w_]]
+                ent = (sel[:, 0] - start).mean() * 10.0
+                m1 = (sel[:, 3] - sel[:, 2]); m3 = (sel[:, 5] - sel[:, 2])
+                print(f"      wave {w_:2d}: n={sel.shape[0]:4d} entry +{ent:5.0f} ns | m1 {m1[m1 > 0].mean() * ratio if (m1 > 0).any() else float('nan'):6.0f} ns  "
+                      f"m3 {m3[m3 > 0].mean() * ratio if (m3 > 0).any() else float('nan'):6.0f} ns  end {(sel[:, 1] - sel[:, 0]).mean() * 10.0:6.0f} ns")
     total = (prev_end - t0) * 10.0
     print(f"step total {total / 1000.0:.1f} us over {n} launches; sum of spans {sum(r[5] for r in rows) / 1000.0:.1f} us, "
           f"sum of gaps {sum(r[4] for r in rows) / 1000.0:.1f} us")

@@ -38,7 +38,7 @@ int main() {
     float* bias = (float*)dz(4 * 4096); float* gamma = (float*)dz(4 * 4096); float* beta = (float*)dz(4 * 4096);
     float* xd = (float*)dz(4 * 64 * d); half_t* qd = (half_t*)dz(2 * 64 * d); half_t* attnd = (half_t*)dz(2 * 64 * d);
     half_t* hd = (half_t*)dz(2 * 64 * F);
-    float* part_o = (float*)dz(4ull * H * WLX_XSPLIT * 16 * 64 * 4); float* part_ml = (float*)dz(4ull * H * WLX_XSPLIT * 16 * 2 * 4);
+    half_t* part_o = (half_t*)dz(2ull * H * WLX_XSPLIT * 16 * 64 * 4); float* part_ml = (float*)dz(4ull * H * WLX_XSPLIT * 16 * 2 * 4);
     const long crs = (long)WLX_T_TEXT * d;
     half_t* kc = (half_t*)dz(2ull * 16 * crs); half_t* vc = (half_t*)dz(2ull * 16 * crs);
     int* d_cache = (int*)dz(64 * 4); int* d_pos = (int*)dz(64 * 4); int* d_ancrow = (int*)dz(64 * 4); int* d_tok = (int*)dz(64 * 4);
@@ -69,12 +69,11 @@ int main() {
         p.Wp = wnext((size_t)d * 51872); p.bias = nullptr; p.X = xd; p.ldx = d; p.gamma = gamma; p.beta = beta; p.Y = logits; p.ldy = 53248; p.qscale = 1.f; launch_dec_gemv(p, st); };
     int lay = 0;
     auto g_sa = [&]() { launch_dec_self_attn(qd, d, kc, vc, crs, d, H, rt, rows, attnd, d, nullptr, st); };
-    auto g_ca = [&]() { lay = (lay + 1) % 12; launch_dec_cross_attn(qd, d, ck + (size_t)lay * WLX_T_AUDIO_PAD * d, d, (long)WLX_T_AUDIO_PAD * d,
-                                                                     cvt + (size_t)lay * d * WLX_T_AUDIO_PAD, WLX_T_AUDIO_PAD, (long)d * WLX_T_AUDIO_PAD,
-                                                                     H, rows, 1, rows, d_gi, part_o, part_ml, nullptr, st); };
+    auto g_ca = [&]() { lay = (lay + 1) % 12; launch_dec_cross_attn(qd, d, ck + (size_t)lay * WLX_T_AUDIO_PAD * d, cvt + (size_t)lay * d * WLX_T_AUDIO_PAD,
+                                                                     (long)WLX_T_AUDIO_PAD * d, H, rows, 1, rows, d_gi, part_o, part_ml, st); };
     struct T { const char* name; std::function<void()> f; };
     std::vector<T> singles = {{"qkv  LN->QKV  N2304 K768 ", g_qkv}, {"self_attn2 (t=33)        ", g_sa}, {"out  F16->RES N768 K768  ", g_out},
-                              {"cq   LN->F16  N768 K768  ", g_cq}, {"cross_attn2              ", g_ca}, {"co   XATT->RES N768 K768 ", g_co},
+                              {"cq   LN->F16  N768 K768  ", g_cq}, {"cross_attn               ", g_ca}, {"co   XATT->RES N768 K768 ", g_co},
                               {"fc1  LN->GELU N3072 K768 ", g_fc1}, {"fc2  F16->RES N768 K3072 ", g_fc2}, {"vocab LN->F32 N51864     ", g_voc}};
     float sum = 0.f;
     for (auto& t : singles) {

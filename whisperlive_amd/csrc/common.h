@@ -50,11 +50,47 @@ __device__ __forceinline__ float gelu_erf(float x) {
 __device__ __forceinline__ f16x8 ld_f16x8(const half_t* p) {
     return *reinterpret_cast<const f16x8*>(p);
 }
+// streamed-once data (decode weights): non-temporal, measured 0.3 us per launch better than the default policy
+__device__ __forceinline__ f16x8 ld_nt_f16x8(const half_t* p) {
+    return __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(p));
+}
 __device__ __forceinline__ f16x4 ld_f16x4(const half_t* p) {
     return *reinterpret_cast<const f16x4*>(p);
 }
 
 #define WLX_NEG_INF (-__builtin_inff())
+
+// ------------------------------------------------------------------ DPP wave reductions (gfx9 row_bcast forms)
+// One VALU instruction per butterfly step: v_<op>_dpp dst, dpp(src0), src1. hipcc does not form these from
+// __builtin_amdgcn_update_dpp + fmaxf/min (it emits v_mov, v_mov_dpp, a canonicalising v_max and the v_max: 5 per step),
+// so they are written out; the s_nop 1 before every step is the 2-wait-state DPP read-after-VALU-write hazard that the
+// compiler does not insert inside an asm statement. After the last step lane 63 holds the wave result.
+#define WLX_DPP_REDUCE(OP, V)                                                                   \
+    asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"    \
+                 "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"    \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"        \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"             \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"           \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"           \
+                 "s_nop 1" : "+v"(V))
+#define WLX_DPP_REDUCE_ROW(OP, V)   /* each 16-lane row separately: every lane of a row ends with the row's result */ \
+    asm volatile("s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"    \
+                 "s_nop 1\n\t" OP " %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"    \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf\n\t"        \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf\n\t"             \
+                 "s_nop 1" : "+v"(V))
+__device__ __forceinline__ float dpp_wave_sum(float v) {      // wave-uniform result
+    WLX_DPP_REDUCE("v_add_f32_dpp", v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float dpp_wave_max(float v) {
+    WLX_DPP_REDUCE("v_max_f32_dpp", v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ int dpp_wave_min_i32(int v) {
+    WLX_DPP_REDUCE("v_min_i32_dpp", v);
+    return __builtin_amdgcn_readlane(v, 63);
+}
 
 // ------------------------------------------------------------------ WLX_TRACE: in-kernel timeline (profiling builds only)
 // libwlx_trace.so (scripts/trace_step.py) is the same source compiled with -DWLX_TRACE: wave 0 of every workgroup of
@@ -88,7 +124,22 @@ __device__ __forceinline__ unsigned long long wlx_ct() { return __builtin_amdgcn
             for (int _i = 0; _i < WLX_TR_NMARK; ++_i) _r[2 + _i] = _trm[_i]; \
         } \
     } } while (0)
+// per-WAVE records (lane 0 of every wave, workgroups 0..127, <= 16 waves each): which wave of a workgroup is late?
+#define WLX_TR_END_WAVES(TRC) do { \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    if ((TRC).buf && (threadIdx.x & 63) == 0) { \
+        const unsigned long long _trt1 = wlx_rt(); \
+        const int _wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); \
+        const int _ix = _wg * 16 + (threadIdx.x >> 6); \
+        unsigned long long* _h = (TRC).buf + (size_t)(TRC).seq * WLX_TR_STRIDE; \
+        if (_wg < 128 && _ix < WLX_TR_MAXWG) { \
+            unsigned long long* _r = _h + (size_t)(_ix + 1) * WLX_TR_REC; \
+            _r[0] = _trt0; _r[1] = _trt1; \
+            for (int _i = 0; _i < WLX_TR_NMARK; ++_i) _r[2 + _i] = _trm[_i]; \
+        } \
+    } } while (0)
 #else
+#define WLX_TR_END_WAVES(TRC)
 #define WLX_TR_PARAM
 #define WLX_TR_FIELD
 #define WLX_TR_BEGIN()

@@ -34,13 +34,14 @@ struct GemvParams {
     int K, KT, N;                            // K real, KT = Kpad/32, N real outputs
     int KTW;                                 // (set by the launcher) k-tiles per wave, even
     int NCH;                                 // (set by the launcher, lean kernel) chunks of CH k-tiles per wave
+    int nwm;                                 // (set by the launcher, lean kernel, XATTN) waves that stream weights
     const half_t* Wp; const float* bias;
     // GEMV_IN_LN
     const float* X; long ldx; const float* gamma; const float* beta;
     // GEMV_IN_F16
     const half_t* Xh; long ldxh;
     // GEMV_IN_XATTN: split partials of the cross attention
-    const float* part_o; const float* part_ml; int H; int R;
+    const half_t* part_o; const float* part_ml; int H; int R;   // [item][H][split][16][64] fp16 normalised O; [item][H][16][split][2] (m, l)
     // outputs
     half_t* Yh; long ldyh;
     float* Y; long ldy;
@@ -71,19 +72,16 @@ void launch_dec_gemv(const GemvParams& p, hipStream_t s);
 const char* dec_gemv_kernel_name(const GemvParams& p);
 // WLX_DECODE_V1=1 selects the first-generation decode kernels (kept as the in-tree A/B reference)
 extern bool g_decode_v1;
-// WLX_DECODE_V2=1 selects the second-generation kernels (dec_gemv1 / cross_attn2): A/B reference for the lean ones
-extern bool g_decode_v2;
 
 // causal self-attention over the KV cache, one wave per (row, head)
 void launch_dec_self_attn(const half_t* q, long ldq, const half_t* Kc, const half_t* Vc, long cache_row_stride,
                           int d, int H, const RowTables& rt, int rows, half_t* out, long ldo,
                           const int* done, hipStream_t s);
-// cross-attention of R rows per item against the item's 1500 encoder keys, split over keys
-// groups of R (<=16) rows; group_item[g] = audio item whose K/V group g attends to
-void launch_dec_cross_attn(const half_t* q, long ldq, const half_t* Kx, long ldk, long item_stride_k,
-                           const half_t* Vtx, long ldvt, long item_stride_v,
-                           int H, int R, int groups, int rows, const int* group_item,
-                           float* part_o, float* part_ml, const int* done, hipStream_t s);
+// cross-attention of R rows per item against the item's 1500 encoder keys, split over keys; groups of R (<=16) rows,
+// group_item[g] = audio item whose K/V group g attends to. Kp / Vp: tile-packed cross K / V of ONE decoder layer
+// (gemm.hip GEMM_CROSS_KV), item_stride halfs per item.
+void launch_dec_cross_attn(const half_t* q, long ldq, const half_t* Kp, const half_t* Vp, long item_stride, int H, int R,
+                           int groups, int rows, const int* group_item, half_t* part_o, float* part_ml, hipStream_t s);
 
 // ---------------------------------------------------------------- search.hip
 struct SearchState {            // device pointers, one set per slot
@@ -107,11 +105,14 @@ struct SearchState {            // device pointers, one set per slot
     // chunked scan of the logits rows (beam mode, search_scan_kernel -> search_merge_update_kernel)
     float* scan_stats;          // [rows][SC_MAXCH][SC_NSTAT]
     float* scan_cv; int* scan_ci;   // [rows][SC_MAXCH + 1][WLX_MAX_CAND] per-chunk candidate lists (value desc, id asc)
+    // rule state carried from step to step (third-generation search): per row (last generated token was a timestamp,
+    // the one before it was — or fewer than two generated tokens —, latest generated timestamp token or -1, unused)
+    int* rule;                  // [rows][4]
 };
 #define SC_THREADS 256
 #define SC_NPT 8
 #define SC_CHUNK (SC_THREADS * SC_NPT)   // 2048 vocabulary ids per scan workgroup
-#define SC_MAXCH 26                      // vocab <= 53248
+#define SC_MAXCH 27                      // vocab <= 53248 (+1: generation 3 cuts text and timestamp ids separately)
 #define SC_NSTAT 8
 struct SearchParams {
     int V; long ldl;
@@ -130,11 +131,11 @@ struct SearchParams {
 // SearchParams live in device memory (sp_dev) so a captured step graph is reusable across calls
 void launch_search_rows(const float* logits, const SearchParams* sp_dev, int rows, const SearchState& st, hipStream_t s);
 void launch_search_update(const SearchParams* sp_dev, int items, const SearchState& st, hipStream_t s);
-// beam mode, second generation: (chunks x rows) scan workgroups + one merge/update workgroup per item
-void launch_search_scan(const float* logits, long ldl, int V, const SearchParams* sp_dev, int rows, const SearchState& st,
-                        hipStream_t s);
-void launch_search_merge_update(const float* logits, long ldl, int V, const SearchParams* sp_dev, int items,
-                                const SearchState& st, hipStream_t s);
+// beam mode: (chunks x rows) scan workgroups + one merge/update workgroup per item (rule state carried in SearchState::rule)
+void launch_search_scan3(const float* logits, long ldl, int V, const SearchParams* sp_dev, int rows, const SearchState& st,
+                         hipStream_t s);
+void launch_search_merge_update3(const float* logits, long ldl, int V, const SearchParams* sp_dev, int items,
+                                 const SearchState& st, hipStream_t s);
 // softmax prob of token `tok` in given logits rows -> out[rows]
 void launch_token_prob(const float* logits, long ldl, int V, int rows, int tok, float* out, hipStream_t s);
 // softmax restricted to ids -> probs[rows][n]

@@ -15,6 +15,9 @@
 // int16 ancestry table maps (row, position) -> cache row. All per-step scalars (position,
 // tokens, ancestry, done flag) live in device memory so one captured hipGraph replays every step.
 #include "decoder.h"
+#include <algorithm>
+#include <cstdlib>
+#include <cstdio>
 
 namespace wlx {
 
@@ -237,7 +240,7 @@ __global__ __launch_bounds__(512) void dec_gemv_kernel(GemvParams p) {
                 }
             }
         } else if constexpr (IN == GEMV_IN_XATTN) {
-            // combine the WLX_XSPLIT partial (m, l, O) triples of the cross attention
+            // combine the WLX_XSPLIT partials of the cross attention: per split a NORMALISED fp16 O row and fp32 (m, l)
 #pragma unroll
             for (int j = 0; j < GV_CH; ++j) {
                 const int kt = base + j;
@@ -249,25 +252,20 @@ __global__ __launch_bounds__(512) void dec_gemv_kernel(GemvParams p) {
                         const int k = kt * 32 + g * 8;
                         const int h = k >> 6, dd = k & 63;
                         const int item = m / p.R, qi = m - item * p.R;
-                        const long pb = ((long)item * p.H + h) * WLX_XSPLIT;
-                        float ms[WLX_XSPLIT], ls[WLX_XSPLIT];
-                        float mmax = WLX_NEG_INF;
+                        const long ih = (long)item * p.H + h;
+                        const float* mlp = p.part_ml + (ih * 16 + qi) * (WLX_XSPLIT * 2);
+                        float wsp[WLX_XSPLIT];
+                        float mmax = WLX_NEG_INF, den = 0.f;
 #pragma unroll
-                        for (int sp = 0; sp < WLX_XSPLIT; ++sp) {
-                            float2 ml = *reinterpret_cast<const float2*>(p.part_ml + ((pb + sp) * 16 + qi) * 2);
-                            ms[sp] = ml.x; ls[sp] = ml.y;
-                            mmax = fmaxf(mmax, ml.x);
-                        }
-                        float den = 0.f;
+                        for (int sp = 0; sp < WLX_XSPLIT; ++sp) mmax = fmaxf(mmax, mlp[sp * 2]);
+#pragma unroll
+                        for (int sp = 0; sp < WLX_XSPLIT; ++sp) { wsp[sp] = __expf(mlp[sp * 2] - mmax) * mlp[sp * 2 + 1]; den += wsp[sp]; }
                         float num[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                         for (int sp = 0; sp < WLX_XSPLIT; ++sp) {
-                            const float w = __expf(ms[sp] - mmax);
-                            den += w * ls[sp];
-                            const float4* op = reinterpret_cast<const float4*>(p.part_o + ((pb + sp) * 16 + qi) * 64 + dd);
-                            float4 a = op[0], b = op[1];
-                            num[0] += w * a.x; num[1] += w * a.y; num[2] += w * a.z; num[3] += w * a.w;
-                            num[4] += w * b.x; num[5] += w * b.y; num[6] += w * b.z; num[7] += w * b.w;
+                            const f16x8 ov = ld_f16x8(p.part_o + ((ih * WLX_XSPLIT + sp) * 16 + qi) * 64 + dd);
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) num[e] += wsp[sp] * (float)ov[e];
                         }
                         const float inv = 1.0f / den;
 #pragma unroll
@@ -369,321 +367,7 @@ __global__ __launch_bounds__(512) void dec_gemv_kernel(GemvParams p) {
 }
 
 
-// ------------------------------------------------------------------ second-generation skinny GEMM, M <= 16 rows
-// The decode step of ONE stream (beam rows only) is a chain of ~100 dependent launches of 1-5 MB each, so a
-// launch is bound by the LENGTH OF ITS DEPENDENT-LOAD CHAIN, not by bandwidth. This kernel therefore
-//   * issues every global load it will ever need (done flag, weight fragments [non-temporal: streamed
-//     once], activations, LayerNorm gamma/beta, bias, residual, KV-cache row tables) up front, in one
-//     burst, before the first wait — one HBM round trip per launch instead of five;
-//   * keeps <= 6 KiB of weights per wave and one 16-column n-tile per workgroup (two for the vocabulary
-//     projection), so a projection spreads over 48..192 CUs (3242/2 workgroups for the logits) instead of
-//     24, and the big-K fc2 runs 16 waves per workgroup instead of 24 KiB per wave;
-//   * combines the split cross-attention partials cooperatively per wave (each wave owns the heads of
-//     its K slice) through LDS instead of 144 dependent loads per lane.
-// Arithmetic (MFMA operand order, fixed-order LDS K reduction, epilogue) is identical to dec_gemv_kernel.
-__device__ __forceinline__ f16x8 ld_nt_f16x8(const half_t* p) {
-    return __builtin_nontemporal_load(reinterpret_cast<const f16x8*>(p));
-}
-
-template <int NTB, int IN, int OUT, int MAXT>
-__global__ __launch_bounds__(MAXT) __attribute__((amdgpu_waves_per_eu(MAXT / 256, MAXT / 256))) void dec_gemv1_kernel(GemvParams p) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
-    const int nw = blockDim.x >> 6;
-    const int KT = p.KT, KTW = p.KTW;
-    const int kt0 = wave * KTW;
-    const int kt1 = (kt0 + KTW < KT) ? kt0 + KTW : KT;
-    const int NT_total = (p.N + 15) >> 4;
-    WLX_TR_BEGIN();
-
-    int dn = 0;
-    if (p.done) dn = *p.done;
-
-    // ---- weights first
-    const half_t* wbase[NTB];
-#pragma unroll
-    for (int i = 0; i < NTB; ++i) {
-        int nt = blockIdx.x * NTB + i;
-        if (nt >= NT_total) nt = NT_total - 1;
-        wbase[i] = p.Wp + ((long)nt * KT * 64 + lane) * 8;
-    }
-    f16x8 wf[GV_CH][NTB];
-#pragma unroll
-    for (int j = 0; j < GV_CH; ++j) {
-        int kt = kt0 + j;
-        if (kt > KT - 1) kt = KT - 1;
-#pragma unroll
-        for (int i = 0; i < NTB; ++i) wf[j][i] = ld_nt_f16x8(wbase[i] + (long)kt * 512);
-    }
-
-    // ---- epilogue operands of the waves that will finish a tile (wave i < NTB owns tile i). Loaded by every lane
-    // from clamped (always valid) addresses: an unconditional load carries no wait until its first use.
-    const int ntile_e = blockIdx.x * NTB + wave;
-    const bool rowok = c < p.M;
-    const int crow = rowok ? c : 0;
-    const bool epi = (wave < NTB) && (ntile_e < NT_total) && rowok;
-    const int n_e = ntile_e * 16 + g * 4;
-    const int n_ld = ((ntile_e < NT_total) ? ntile_e : NT_total - 1) * 16 + g * 4;
-    float4 bias_e = make_float4(0.f, 0.f, 0.f, 0.f);
-    float4 res_e = make_float4(0.f, 0.f, 0.f, 0.f);
-    int rc_e = 0, rp_e = 0;
-    if constexpr (OUT != GEMV_OUT_F32) bias_e = *reinterpret_cast<const float4*>(p.bias + n_ld);   // biased layers: N % 16 == 0
-    if constexpr (OUT == GEMV_OUT_RESID) res_e = *reinterpret_cast<const float4*>(p.Xres + (long)crow * p.ldxres + n_ld);
-    if constexpr (OUT == GEMV_OUT_QKV) { rc_e = p.row_cache[crow]; rp_e = p.row_pos[crow]; }
-
-    float* red = smem;                       // [2][nw][16]
-    float* accred = smem + 2 * nw * 16;      // [nw][NTB][64][4]
-    f16x8 xf[GV_CH];
-
-    if constexpr (IN == GEMV_IN_LN) {
-        // Cooperative LayerNorm over K = d_model. Every workgroup needs LN(x) of all M rows as MFMA B fragments; loading
-        // x / gamma / beta straight into fragment layout costs 36 x 16 B per lane (each of the 16 row-lanes re-reads
-        // gamma and beta, and rows are replicated across g), ~150 KB of L1 traffic per workgroup for 24 KB of weights.
-        // Instead wave w normalises rows w, w + nw, ... with lane-contiguous float4 loads (a row = K/4 float4, lane l
-        // holds l, l + 64, ...), reduces mean / variance with wave shuffles only (no barrier), and writes the fp16 row to
-        // LDS; after ONE barrier each wave reads its B fragments back (row stride K + 8 halfs: conflict-free b128 reads).
-        constexpr int LNV = 6;                                  // float4 per lane per row: K <= 1536
-        const int ldxs = p.K + 8;
-        half_t* xs = reinterpret_cast<half_t*>(accred + nw * NTB * 256);
-        const int nv = p.K >> 2;
-        const float4* g4 = reinterpret_cast<const float4*>(p.gamma);
-        const float4* b4 = reinterpret_cast<const float4*>(p.beta);
-        float4 gq[LNV], bq[LNV];
-#pragma unroll
-        for (int j = 0; j < LNV; ++j) {
-            const int idx = lane + 64 * j;
-            const int idc = (idx < nv) ? idx : 0;
-            gq[j] = g4[idc]; bq[j] = b4[idc];
-        }
-        if (dn) return;
-        const float invK = 1.0f / (float)p.K;
-        for (int r0 = wave; r0 < p.M; r0 += 2 * nw) {           // two rows per trip: M <= 2 nw needs one trip
-            const int r1 = r0 + nw;
-            const bool has1 = r1 < p.M;
-            const float4* xa4 = reinterpret_cast<const float4*>(p.X + (long)r0 * p.ldx);
-            const float4* xb4 = reinterpret_cast<const float4*>(p.X + (long)(has1 ? r1 : r0) * p.ldx);
-            float4 xa[LNV], xb[LNV];
-#pragma unroll
-            for (int j = 0; j < LNV; ++j) {
-                const int idx = lane + 64 * j;
-                const int idc = (idx < nv) ? idx : 0;
-                xa[j] = xa4[idc]; xb[j] = xb4[idc];
-            }
-            if (r0 == wave) WLX_TR_MARK(1);
-            float sa = 0.f, sb = 0.f;
-#pragma unroll
-            for (int j = 0; j < LNV; ++j)
-                if (lane + 64 * j < nv) {
-                    sa += (xa[j].x + xa[j].y) + (xa[j].z + xa[j].w);
-                    sb += (xb[j].x + xb[j].y) + (xb[j].z + xb[j].w);
-                }
-            const float ma = wave_sum(sa) * invK, mb = wave_sum(sb) * invK;
-            float qa = 0.f, qb = 0.f;
-#pragma unroll
-            for (int j = 0; j < LNV; ++j)
-                if (lane + 64 * j < nv) {
-                    float t;
-                    t = xa[j].x - ma; qa += t * t; t = xa[j].y - ma; qa += t * t; t = xa[j].z - ma; qa += t * t; t = xa[j].w - ma; qa += t * t;
-                    t = xb[j].x - mb; qb += t * t; t = xb[j].y - mb; qb += t * t; t = xb[j].z - mb; qb += t * t; t = xb[j].w - mb; qb += t * t;
-                }
-            const float ra = rsqrtf(wave_sum(qa) * invK + 1e-5f), rb = rsqrtf(wave_sum(qb) * invK + 1e-5f);
-#pragma unroll
-            for (int j = 0; j < LNV; ++j) {
-                const int idx = lane + 64 * j;
-                if (idx < nv) {
-                    const f16x4 ha = {(half_t)((xa[j].x - ma) * ra * gq[j].x + bq[j].x), (half_t)((xa[j].y - ma) * ra * gq[j].y + bq[j].y),
-                                      (half_t)((xa[j].z - ma) * ra * gq[j].z + bq[j].z), (half_t)((xa[j].w - ma) * ra * gq[j].w + bq[j].w)};
-                    *reinterpret_cast<f16x4*>(xs + (long)r0 * ldxs + idx * 4) = ha;
-                    if (has1) {
-                        const f16x4 hb = {(half_t)((xb[j].x - mb) * rb * gq[j].x + bq[j].x), (half_t)((xb[j].y - mb) * rb * gq[j].y + bq[j].y),
-                                          (half_t)((xb[j].z - mb) * rb * gq[j].z + bq[j].z), (half_t)((xb[j].w - mb) * rb * gq[j].w + bq[j].w)};
-                        *reinterpret_cast<f16x4*>(xs + (long)r1 * ldxs + idx * 4) = hb;
-                    }
-                }
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < GV_CH; ++j) {
-            f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (kt0 + j < kt1 && rowok) o = *reinterpret_cast<const f16x8*>(xs + (long)c * ldxs + (kt0 + j) * 32 + g * 8);
-            xf[j] = o;
-        }
-    } else if constexpr (IN == GEMV_IN_XATTN) {
-        // wave-local combine of the WLX_XSPLIT (m, l, O) partials of the heads inside this wave's K slice
-        // (KTW even => whole heads), written as fp16 rows to this wave's LDS image, then read back as B fragments.
-        if (dn) return;
-        WLX_TR_MARK(1);
-        const int ldxs = KTW * 32;
-        half_t* xs = reinterpret_cast<half_t*>(smem + 2 * nw * 16 + nw * NTB * 256) + (long)wave * 16 * ldxs;
-        const int nh = (kt1 - kt0) >> 1;
-        const int h0 = kt0 >> 1;
-        const int n_it = p.M * nh * 16;     // (row m, head hh, 4-float group q4)
-        // two items per lane per trip: 32 independent loads in flight (one L2 round trip per 128 items)
-        for (int it0 = lane; it0 < n_it; it0 += 128) {
-            float2 ml[2][WLX_XSPLIT];
-            float4 ov[2][WLX_XSPLIT];
-            int mrow[2], hcol[2];
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int it = it0 + u * 64;
-                const int itc = (it < n_it) ? it : it0;
-                const int q4 = itc & 15;
-                const int t2 = itc >> 4;
-                const int m = t2 / nh, hh = t2 - m * nh;
-                const int item = m / p.R, qi = m - item * p.R;
-                const long pb = ((long)item * p.H + h0 + hh) * WLX_XSPLIT;
-                mrow[u] = m; hcol[u] = hh * 64 + q4 * 4;
-#pragma unroll
-                for (int sp = 0; sp < WLX_XSPLIT; ++sp) {
-                    ml[u][sp] = *reinterpret_cast<const float2*>(p.part_ml + ((pb + sp) * 16 + qi) * 2);
-                    ov[u][sp] = *reinterpret_cast<const float4*>(p.part_o + ((pb + sp) * 16 + qi) * 64 + q4 * 4);
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                float mmax = WLX_NEG_INF;
-#pragma unroll
-                for (int sp = 0; sp < WLX_XSPLIT; ++sp) mmax = fmaxf(mmax, ml[u][sp].x);
-                float den = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
-#pragma unroll
-                for (int sp = 0; sp < WLX_XSPLIT; ++sp) {
-                    const float w = __expf(ml[u][sp].x - mmax);
-                    den += w * ml[u][sp].y;
-                    n0 += w * ov[u][sp].x; n1 += w * ov[u][sp].y; n2 += w * ov[u][sp].z; n3 += w * ov[u][sp].w;
-                }
-                const float inv = 1.0f / den;
-                const f16x4 hv = {(half_t)(n0 * inv), (half_t)(n1 * inv), (half_t)(n2 * inv), (half_t)(n3 * inv)};
-                // an out-of-range slot recomputes item it0 and rewrites the same value: no branch, so the 32 loads stay hoisted
-                *reinterpret_cast<f16x4*>(xs + (long)mrow[u] * ldxs + hcol[u]) = hv;
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < GV_CH; ++j) {
-            f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (kt0 + j < kt1 && rowok) o = *reinterpret_cast<const f16x8*>(xs + (long)c * ldxs + j * 32 + g * 8);
-            xf[j] = o;
-        }
-    }
-
-    f32x4 acc[NTB];
-#pragma unroll
-    for (int i = 0; i < NTB; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if constexpr (IN != GEMV_IN_F16) WLX_TR_MARK(2);
-
-    if constexpr (IN == GEMV_IN_F16) {
-        // activations are fp16 rows already; the loop streams further weight chunks when KTW > GV_CH
-        f16x8 xn[GV_CH];
-#pragma unroll
-        for (int j = 0; j < GV_CH; ++j) {
-            int kt = kt0 + j;
-            if (kt > KT - 1) kt = KT - 1;
-            xn[j] = ld_f16x8(p.Xh + (long)crow * p.ldxh + kt * 32 + g * 8);
-        }
-        if (dn) return;
-        WLX_TR_MARK(1);
-        WLX_TR_MARK_NOWAIT(2);
-        for (int base = kt0; base < kt1; base += GV_CH) {
-            f16x8 wn[GV_CH][NTB], xn2[GV_CH];
-            const bool more = base + GV_CH < kt1;
-            if (more) {
-#pragma unroll
-                for (int j = 0; j < GV_CH; ++j) {
-                    int kt = base + GV_CH + j;
-                    if (kt > KT - 1) kt = KT - 1;
-#pragma unroll
-                    for (int i = 0; i < NTB; ++i) wn[j][i] = ld_nt_f16x8(wbase[i] + (long)kt * 512);
-                    xn2[j] = ld_f16x8(p.Xh + (long)crow * p.ldxh + kt * 32 + g * 8);
-                }
-            }
-#pragma unroll
-            for (int j = 0; j < GV_CH; ++j) {
-                f16x8 o = {0, 0, 0, 0, 0, 0, 0, 0};
-                if (base + j < kt1 && rowok) o = xn[j];
-                xf[j] = o;
-            }
-#pragma unroll
-            for (int j = 0; j < GV_CH; ++j)
-                if (base + j < kt1) {
-#pragma unroll
-                    for (int i = 0; i < NTB; ++i) acc[i] = mfma16(wf[j][i], xf[j], acc[i]);
-                }
-            if (more) {
-#pragma unroll
-                for (int j = 0; j < GV_CH; ++j) {
-                    xn[j] = xn2[j];
-#pragma unroll
-                    for (int i = 0; i < NTB; ++i) wf[j][i] = wn[j][i];
-                }
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < GV_CH; ++j)
-            if (kt0 + j < kt1) {
-#pragma unroll
-                for (int i = 0; i < NTB; ++i) acc[i] = mfma16(wf[j][i], xf[j], acc[i]);
-            }
-    }
-
-    // ---- cross-wave K reduction through LDS (fixed order), epilogue by wave i < NTB for tile i
-#pragma unroll
-    for (int i = 0; i < NTB; ++i)
-        *reinterpret_cast<f32x4*>(accred + (((long)wave * NTB + i) * 64 + lane) * 4) = acc[i];
-    WLX_TR_MARK(3);
-    __syncthreads();
-    if (wave >= NTB) return;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int w = 0; w < nw; ++w) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(accred + (((long)w * NTB + wave) * 64 + lane) * 4);
-        v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
-    }
-    WLX_TR_MARK(4);
-    if (epi) {
-    const float o[4] = {v[0] + bias_e.x, v[1] + bias_e.y, v[2] + bias_e.z, v[3] + bias_e.w};
-    const int m = c, n = n_e;
-    if constexpr (OUT == GEMV_OUT_F16 || OUT == GEMV_OUT_GELU_F16) {
-        float og[4] = {o[0], o[1], o[2], o[3]};
-        if constexpr (OUT == GEMV_OUT_GELU_F16) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) og[r] = gelu_erf(og[r]);
-        }
-        const f16x4 h = {(half_t)(og[0] * p.qscale), (half_t)(og[1] * p.qscale),
-                         (half_t)(og[2] * p.qscale), (half_t)(og[3] * p.qscale)};   // qscale = 1 unless a q projection
-        *reinterpret_cast<f16x4*>(p.Yh + (long)m * p.ldyh + n) = h;
-    } else if constexpr (OUT == GEMV_OUT_F32) {
-        if (n + 3 < p.N) {
-            *reinterpret_cast<float4*>(p.Y + (long)m * p.ldy + n) = make_float4(o[0], o[1], o[2], o[3]);
-        } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (n + r < p.N) p.Y[(long)m * p.ldy + n + r] = o[r];
-        }
-    } else if constexpr (OUT == GEMV_OUT_RESID) {
-        *reinterpret_cast<float4*>(p.Xres + (long)m * p.ldxres + n) =
-            make_float4(res_e.x + o[0], res_e.y + o[1], res_e.z + o[2], res_e.w + o[3]);
-    } else {   // GEMV_OUT_QKV
-        if (n < p.d) {
-            const f16x4 h = {(half_t)(o[0] * p.qscale), (half_t)(o[1] * p.qscale),
-                             (half_t)(o[2] * p.qscale), (half_t)(o[3] * p.qscale)};
-            *reinterpret_cast<f16x4*>(p.Yh + (long)m * p.ldyh + n) = h;
-        } else {
-            const f16x4 h = {(half_t)o[0], (half_t)o[1], (half_t)o[2], (half_t)o[3]};
-            int rc = rc_e, rp = rp_e;
-            asm volatile("" : "+v"(rc), "+v"(rp));   // keep the address arithmetic (and its wait) down here
-            const long kvoff = (long)rc * p.cache_row_stride + (long)rp * p.d;
-            if (n < 2 * p.d) *reinterpret_cast<f16x4*>(p.Kc + kvoff + (n - p.d)) = h;
-            else *reinterpret_cast<f16x4*>(p.Vc + kvoff + (n - 2 * p.d)) = h;
-        }
-    }
-    }
-    WLX_TR_MARK(5);
-    WLX_TR_END(p.trc);
-}
-
 bool g_decode_v1 = false;
-bool g_decode_v2 = false;   // WLX_DECODE_V2=1: second-generation decode kernels (A/B reference)
 
 #ifdef WLX_TRACE
 unsigned long long* g_trace_buf = nullptr;
@@ -702,44 +386,38 @@ const char* g_trace_names[512];
 //     columns >= M are simply not stored;
 //   * LayerNorm rows are reduced with DPP adds (12 VALU ops) instead of 12 dependent ds_bpermute round trips;
 //   * everything rarely needed (ragged K, M > 16, d_model not a multiple of 256) stays in the older kernels.
-template <int CTRL, int ROWMASK>
-__device__ __forceinline__ float dpp_addf(float v) {
-    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWMASK, 0xF, false);
-    return v + __builtin_bit_cast(float, t);
-}
-// sum over the 64 lanes, returned wave-uniform (SGPR)
-__device__ __forceinline__ float wave_sum_dpp(float v) {
-    v = dpp_addf<0xB1, 0xF>(v);     // quad_perm:[1,0,3,2]
-    v = dpp_addf<0x4E, 0xF>(v);     // quad_perm:[2,3,0,1]
-    v = dpp_addf<0x141, 0xF>(v);    // row_half_mirror
-    v = dpp_addf<0x140, 0xF>(v);    // row_mirror: every lane holds its 16-lane row's sum
-    v = dpp_addf<0x142, 0xA>(v);    // row_bcast:15 into rows 1 and 3
-    v = dpp_addf<0x143, 0xC>(v);    // row_bcast:31 into rows 2 and 3: lane 63 holds the wave sum
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
+__device__ __forceinline__ float wave_sum_dpp(float v) { return dpp_wave_sum(v); }   // common.h: 6 v_add_f32_dpp
 
 template <int CH, int LNV, int IN, int OUT, int NTB>
 __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int nw = blockDim.x >> 6;
+    // nw = waves that stream weights and run MFMAs; the cross-attention combine brings extra waves that only help
+    // with the prologue (and load no weights: their wp is clamped to wave 0's slice, results unused)
+    const int nw = (IN == GEMV_IN_XATTN) ? p.nwm : (int)(blockDim.x >> 6);
     WLX_TR_BEGIN();
     float* accred = smem;                                                  // [nw][NTB][64][4]
     half_t* xs = reinterpret_cast<half_t*>(smem + nw * NTB * 256);         // LN / XATTN: fp16 activation rows
 
-    const int kw0 = wave * p.KTW;                                          // first k-tile of this wave
-    const half_t* wp = p.Wp + ((long)(blockIdx.x * NTB) * p.KT + kw0) * 512 + lane * 8;
+    // (Tried and dropped: sub-tile workgroups — a 16-column tile shared by 2-4 workgroups, each streaming a quarter of
+    // the weight rows with the other lanes masked. It spreads N = 768 layers over 192 CUs but does not reduce the number
+    // of load INSTRUCTIONS a CU issues, which is what bounds these launches (~11 ns per wave-level load): no gain.)
+    const int tile = blockIdx.x;
+    const int kw0 = ((IN == GEMV_IN_XATTN && wave >= nw) ? 0 : wave) * p.KTW;   // first k-tile of this wave
+    const half_t* wp = p.Wp + ((long)(tile * NTB) * p.KT + kw0) * 512 + lane * 8;
     const long wstep = (long)p.KT * 512;                                   // next n-tile
     f16x8 wf[CH][NTB];
+    if (IN != GEMV_IN_XATTN || wave < nw) {   // helper waves of the combine: wf stays unset, they leave before the MFMAs
 #pragma unroll
-    for (int j = 0; j < CH; ++j)
+        for (int j = 0; j < CH; ++j)
 #pragma unroll
-        for (int i = 0; i < NTB; ++i) wf[j][i] = ld_nt_f16x8(wp + i * wstep + j * 512);
+            for (int i = 0; i < NTB; ++i) wf[j][i] = ld_nt_f16x8(wp + i * wstep + j * 512);
+    }
 
     // epilogue operands, requested now (every lane, clamped row: no branch around a load)
     const int crow = (c < p.M) ? c : 0;
-    const int nt_e = blockIdx.x * NTB + ((wave < NTB) ? wave : 0);
+    const int nt_e = tile * NTB + ((wave < NTB) ? wave : 0);
     const int n_e = nt_e * 16 + g * 4;
     float4 bias_e = make_float4(0.f, 0.f, 0.f, 0.f), res_e = bias_e;
     int rc_e = 0, rp_e = 0;
@@ -782,12 +460,7 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
         for (int j = 0; j < LNV; ++j) { gq[j] = g4[64 * j]; bq[j] = b4[64 * j]; }
         const int ldxs = p.K + 8;
         constexpr float invK = 1.0f / (256.0f * LNV);
-#pragma unroll 1
-        for (int r = wave; r < p.M; r += nw) {
-            const float4* x4 = reinterpret_cast<const float4*>(p.X + (long)r * p.ldx) + lane;
-            float4 x[LNV];
-#pragma unroll
-            for (int j = 0; j < LNV; ++j) x[j] = x4[64 * j];
+        auto ln_row = [&](float4 (&x)[LNV], int r) {
             float sm = 0.f;
 #pragma unroll
             for (int j = 0; j < LNV; ++j) sm += (x[j].x + x[j].y) + (x[j].z + x[j].w);
@@ -806,49 +479,74 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
                                   (half_t)(x[j].z * rstd * gq[j].z + bq[j].z), (half_t)(x[j].w * rstd * gq[j].w + bq[j].w)};
                 *reinterpret_cast<f16x4*>(dst + 256 * j) = hv;
             }
+        };
+#pragma unroll 1
+        for (int r = wave; r < p.M; r += 2 * nw) {                          // rows r and r + nw: both requested before either is reduced
+            const int r1 = r + nw;
+            const bool has1 = r1 < p.M;
+            const float4* x4 = reinterpret_cast<const float4*>(p.X + (long)r * p.ldx) + lane;
+            const float4* y4 = reinterpret_cast<const float4*>(p.X + (long)(has1 ? r1 : r) * p.ldx) + lane;
+            float4 x[LNV], y[LNV];
+#pragma unroll
+            for (int j = 0; j < LNV; ++j) { x[j] = x4[64 * j]; y[j] = y4[64 * j]; }
+#pragma unroll 1
+            for (int u = 0; u < (has1 ? 2 : 1); ++u) {                      // rolled: one copy of the row code (code size is latency here)
+                if (u) {
+#pragma unroll
+                    for (int j = 0; j < LNV; ++j) x[j] = y[j];
+                }
+                ln_row(x, u ? r1 : r);
+            }
         }
         WLX_TR_MARK(1);
         __syncthreads();
         const half_t* xr = xs + c * ldxs + kw0 * 32 + g * 8;                // rows >= M: whatever LDS holds (never stored)
 #pragma unroll
         for (int j = 0; j < CH; ++j) xf[j] = *reinterpret_cast<const f16x8*>(xr + j * 32);
-    } else {   // GEMV_IN_XATTN: combine the WLX_XSPLIT (m, l, O) partials of the heads in this wave's K slice
-        const int ldxs = p.KTW * 32;
-        half_t* xw = xs + (long)wave * 16 * ldxs;
-        const int nh = p.KTW >> 1, h0 = kw0 >> 1;
-        const int n_it = p.M * nh * 16;                                     // (row m, head hh, 4-float group q4)
+    } else {   // GEMV_IN_XATTN: every wave of the workgroup (more than the nw MFMA waves) combines the WLX_XSPLIT
+        // partials (normalised fp16 O, fp32 (m, l) contiguous per row): one (row, head, 8-dim group) per thread, 12 16-byte
+        // loads in flight, ONE L2 round trip when M * H * 8 <= blockDim; the fp16 result rows go to LDS like the LayerNorm
+        // rows. (A CU retires one wave-level load instruction per ~11 ns: the fp32 / 4-dim / separate-(m,l) form needed
+        // 240 of them per workgroup, this one 90.)
+        const int ldxs = p.K + 8;
+        const int n_it = p.M * p.H * 8;
+        const float rH = 1.0f / (float)p.H, rR = 1.0f / (float)p.R;
 #pragma unroll 1
-        for (int it = lane; it < n_it; it += 64) {
-            const int q4 = it & 15, t2 = it >> 4;
-            const int m = t2 / nh, hh = t2 - m * nh;
-            const int item = m / p.R, qi = m - item * p.R;
-            const long pb = (((long)item * p.H + h0 + hh) * WLX_XSPLIT) * 16 + qi;
-            const float* mlp = p.part_ml + pb * 2;
-            const float* op = p.part_o + pb * 64 + q4 * 4;
-            float2 ml[WLX_XSPLIT];
-            float4 ov[WLX_XSPLIT];
+        for (int it = tid; it < n_it; it += blockDim.x) {
+            const int q8 = it & 7, hm = it >> 3;
+            const int m = (int)(((float)hm + 0.5f) * rH), hh = hm - m * p.H;
+            const int item = (int)(((float)m + 0.5f) * rR), qi = m - item * p.R;
+            const long ih = (long)item * p.H + hh;
+            const float4* mlp = reinterpret_cast<const float4*>(p.part_ml + (ih * 16 + qi) * (WLX_XSPLIT * 2));
+            const half_t* op = p.part_o + (ih * WLX_XSPLIT * 16 + qi) * 64 + q8 * 8;
+            float4 ml[WLX_XSPLIT / 2];
+            f16x8 ov[WLX_XSPLIT];
+#pragma unroll
+            for (int sp = 0; sp < WLX_XSPLIT / 2; ++sp) ml[sp] = mlp[sp];               // (m, l) of splits 2 sp, 2 sp + 1
+#pragma unroll
+            for (int sp = 0; sp < WLX_XSPLIT; ++sp) ov[sp] = ld_f16x8(op + sp * 1024);
+            float mmax = fmaxf(ml[0].x, ml[0].z);
+#pragma unroll
+            for (int sp = 1; sp < WLX_XSPLIT / 2; ++sp) mmax = fmaxf(mmax, fmaxf(ml[sp].x, ml[sp].z));
+            float den = 0.f;
+            float num[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int sp = 0; sp < WLX_XSPLIT; ++sp) {
-                ml[sp] = *reinterpret_cast<const float2*>(mlp + sp * 32);
-                ov[sp] = *reinterpret_cast<const float4*>(op + sp * 1024);
-            }
-            float mmax = ml[0].x;
+                const float mm = (sp & 1) ? ml[sp >> 1].z : ml[sp >> 1].x, ll = (sp & 1) ? ml[sp >> 1].w : ml[sp >> 1].y;
+                const float w = __expf(mm - mmax) * ll;
+                den += w;
 #pragma unroll
-            for (int sp = 1; sp < WLX_XSPLIT; ++sp) mmax = fmaxf(mmax, ml[sp].x);
-            float den = 0.f, n0 = 0.f, n1 = 0.f, n2 = 0.f, n3 = 0.f;
-#pragma unroll
-            for (int sp = 0; sp < WLX_XSPLIT; ++sp) {
-                const float w = __expf(ml[sp].x - mmax);
-                den += w * ml[sp].y;
-                n0 += w * ov[sp].x; n1 += w * ov[sp].y; n2 += w * ov[sp].z; n3 += w * ov[sp].w;
+                for (int e = 0; e < 8; ++e) num[e] += w * (float)ov[sp][e];
             }
             const float inv = 1.0f / den;
-            const f16x4 hv = {(half_t)(n0 * inv), (half_t)(n1 * inv), (half_t)(n2 * inv), (half_t)(n3 * inv)};
-            *reinterpret_cast<f16x4*>(xw + m * ldxs + hh * 64 + q4 * 4) = hv;
+            const f16x8 hv = {(half_t)(num[0] * inv), (half_t)(num[1] * inv), (half_t)(num[2] * inv), (half_t)(num[3] * inv),
+                              (half_t)(num[4] * inv), (half_t)(num[5] * inv), (half_t)(num[6] * inv), (half_t)(num[7] * inv)};
+            *reinterpret_cast<f16x8*>(xs + m * ldxs + hh * 64 + q8 * 8) = hv;
         }
         WLX_TR_MARK(1);
-        // the wave reads back only what it wrote itself: no barrier, the LDS wait is enough
-        const half_t* xr = xw + c * ldxs + g * 8;
+        __syncthreads();
+        if (wave >= nw) return;                                             // helper waves are done (no later barrier needs them: ended waves leave the barrier count)
+        const half_t* xr = xs + c * ldxs + kw0 * 32 + g * 8;
 #pragma unroll
         for (int j = 0; j < CH; ++j) xf[j] = *reinterpret_cast<const f16x8*>(xr + j * 32);
     }
@@ -863,7 +561,11 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
     for (int i = 0; i < NTB; ++i) *reinterpret_cast<f32x4*>(accred + ((wave * NTB + i) * 64 + lane) * 4) = acc[i];
     WLX_TR_MARK(3);
     __syncthreads();
+#ifdef WLX_TRACE
+    if (wave >= NTB) { WLX_TR_END_WAVES(p.trc); return; }
+#else
     if (wave >= NTB) return;
+#endif
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
     const float* ar = accred + (wave * 64 + lane) * 4;
 #pragma unroll 2
@@ -898,20 +600,21 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
         }
     }
     WLX_TR_MARK(5);
-    WLX_TR_END(p.trc);
+    WLX_TR_END_WAVES(p.trc);
 }
 
 struct Gemv2Cfg { bool ok; int nw, CH, NCH, LNV, NTB; size_t shm; };
 static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     Gemv2Cfg c{};
     c.ok = false;
-    if (g_decode_v1 || g_decode_v2 || p.M > 16 || p.M < 1) return c;
+    if (g_decode_v1 || p.M > 16 || p.M < 1) return c;
     if (p.bias ? (p.N & 15) != 0 : p.out_mode != GEMV_OUT_F32) return c;      // bias <=> not the vocabulary projection
     const bool combo = (p.in_mode == GEMV_IN_LN && (p.out_mode == GEMV_OUT_QKV || p.out_mode == GEMV_OUT_F16 ||
                                                     p.out_mode == GEMV_OUT_GELU_F16 || p.out_mode == GEMV_OUT_F32)) ||
                        (p.in_mode != GEMV_IN_LN && p.out_mode == GEMV_OUT_RESID);
     if (!combo || p.K != p.KT * 32) return c;
-    const int cap = (p.in_mode == GEMV_IN_F16) ? 16 : 8;
+    static const int f16cap = [] { const char* e = getenv("WLX_GEMV_F16_NW"); return e ? atoi(e) : 16; }();
+    const int cap = (p.in_mode == GEMV_IN_F16) ? f16cap : 8;
     // exact factorisation KT = nw * CH * NCH, CH in {6, 5, 4}: fewest chunks first, then the widest chunk
     int best_nch = 1 << 30;
     for (int CH = 6; CH >= 4; --CH) {
@@ -926,7 +629,6 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     }
     if (best_nch == (1 << 30)) return c;
     if (p.in_mode != GEMV_IN_F16 && c.NCH != 1) return c;
-    if (p.in_mode == GEMV_IN_XATTN && ((c.CH * c.NCH) & 1)) return c;        // a wave's K slice holds whole heads
     c.LNV = 0;
     if (p.in_mode == GEMV_IN_LN) {
         if (p.K % 256 || p.K / 256 < 2 || p.K / 256 > 5) return c;
@@ -935,7 +637,7 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     c.NTB = (p.out_mode == GEMV_OUT_F32 && p.N > 8192) ? 2 : 1;
     c.shm = sizeof(float) * (size_t)c.nw * c.NTB * 256;
     if (p.in_mode == GEMV_IN_LN) c.shm += (size_t)16 * (p.K + 8) * sizeof(half_t);
-    if (p.in_mode == GEMV_IN_XATTN) c.shm += (size_t)c.nw * 16 * (c.CH * c.NCH * 32) * sizeof(half_t);
+    if (p.in_mode == GEMV_IN_XATTN) c.shm += (size_t)16 * (p.K + 8) * sizeof(half_t);
     c.ok = true;
     return c;
 }
@@ -969,6 +671,11 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
 #endif
     const int NT_total = (p.N + 15) / 16;
     dim3 grid((NT_total + c.NTB - 1) / c.NTB), block(c.nw * 64);
+    if (p.in_mode == GEMV_IN_XATTN) {      // helper waves for the combine: one thread per (row, head, 4-float group), <= 1024
+        p.nwm = c.nw;
+        const int want = (p.M * p.H * 8 + 63) / 64;
+        block.x = 64 * std::max(c.nw, std::min(16, want));
+    }
     if (p.in_mode == GEMV_IN_LN) {
         if (c.CH == 6 && c.LNV == 3) return gemv2_launch_ln<6, 3>(p, c, grid, block, s);
         if (c.CH == 5 && c.LNV == 5) return gemv2_launch_ln<5, 5>(p, c, grid, block, s);
@@ -993,38 +700,6 @@ static bool gemv2_ok(const GemvParams& p, Gemv2Cfg* out) {
     return true;
 }
 
-struct Gemv1Cfg { int nw, KTW, NTB, maxt; size_t shm; };
-static Gemv1Cfg gemv1_cfg(const GemvParams& p) {
-    Gemv1Cfg c;
-    const int cap = (p.in_mode == GEMV_IN_LN) ? 8 : (p.in_mode == GEMV_IN_XATTN) ? 12 : 16;
-    int nw = (p.KT + GV_CH - 1) / GV_CH;
-    // cross-attention combine: one head (2 k-tiles) per wave when they fit, so the M x 16 x WLX_XSPLIT partial loads of
-    // a head are ONE round of <= 2 items per lane instead of several dependent rounds
-    if (p.in_mode == GEMV_IN_XATTN) nw = p.KT / 2;
-    if (nw < 1) nw = 1;
-    if (nw > cap) nw = cap;
-    int KTW = 2 * ((p.KT + 2 * nw - 1) / (2 * nw));     // even: a wave's K slice holds whole heads
-    nw = (p.KT + KTW - 1) / KTW;
-    c.nw = nw; c.KTW = KTW;
-    c.NTB = (p.out_mode == GEMV_OUT_F32 && p.N > 8192 && nw >= 2) ? 2 : 1;
-    c.maxt = (p.in_mode == GEMV_IN_LN) ? 512 : (p.in_mode == GEMV_IN_XATTN) ? 768 : 1024;
-    c.shm = sizeof(float) * ((size_t)2 * nw * 16 + (size_t)nw * c.NTB * 256);
-    if (p.in_mode == GEMV_IN_XATTN) c.shm += (size_t)nw * 16 * KTW * 32 * sizeof(half_t);
-    if (p.in_mode == GEMV_IN_LN) c.shm += (size_t)16 * (p.K + 8) * sizeof(half_t);          // fp16 LN(x) rows
-    return c;
-}
-static bool gemv1_ok(const GemvParams& p) {
-    if (g_decode_v1 || p.M > 16) return false;
-    if (p.bias ? (p.N & 15) != 0 : p.out_mode != GEMV_OUT_F32) return false;   // bias <=> not the vocabulary projection
-    const bool combo = (p.in_mode == GEMV_IN_LN && (p.out_mode == GEMV_OUT_QKV || p.out_mode == GEMV_OUT_F16 ||
-                                                    p.out_mode == GEMV_OUT_GELU_F16 || p.out_mode == GEMV_OUT_F32)) ||
-                       (p.in_mode != GEMV_IN_LN && p.out_mode == GEMV_OUT_RESID);
-    if (!combo) return false;
-    if (p.in_mode != GEMV_IN_F16 && (p.KT + GV_CH - 1) / GV_CH > 8) return false;
-    if (p.in_mode != GEMV_IN_F16 && gemv1_cfg(p).KTW > GV_CH) return false;
-    return true;
-}
-
 const char* dec_gemv_kernel_name(const GemvParams& p) {
     static thread_local char buf[64];
     const int MT = (p.M + 15) / 16;
@@ -1033,12 +708,7 @@ const char* dec_gemv_kernel_name(const GemvParams& p) {
         snprintf(buf, sizeof(buf), "dec_gemv2_kernel<%d, %d, %d, %d, %d>", c2.CH, c2.LNV ? c2.LNV : 1, p.in_mode, p.out_mode, c2.NTB);
         return buf;
     }
-    if (gemv1_ok(p)) {
-        const Gemv1Cfg c = gemv1_cfg(p);
-        snprintf(buf, sizeof(buf), "dec_gemv1_kernel<%d, %d, %d, %d>", c.NTB, p.in_mode, p.out_mode, c.maxt);
-    } else {
-        snprintf(buf, sizeof(buf), "dec_gemv_kernel<%d, %d, %d>", MT > 4 ? 4 : MT, MT == 1 ? 2 : 1, p.in_mode);
-    }
+    snprintf(buf, sizeof(buf), "dec_gemv_kernel<%d, %d, %d>", MT > 4 ? 4 : MT, MT == 1 ? 2 : 1, p.in_mode);
     return buf;
 }
 
@@ -1054,36 +724,6 @@ static void gemv_dispatch_in(const GemvParams& p, dim3 grid, dim3 block, size_t 
 void launch_dec_gemv(const GemvParams& p0, hipStream_t s) {
     Gemv2Cfg c2;
     if (gemv2_ok(p0, &c2) && gemv2_launch(p0, c2, s)) return;
-    if (gemv1_ok(p0)) {
-        GemvParams p = p0;
-        const Gemv1Cfg c = gemv1_cfg(p);
-        p.KTW = c.KTW;
-#ifdef WLX_TRACE
-        { static thread_local char nm[512][48]; const int q = g_trace_seq < 512 ? g_trace_seq : 511;
-          snprintf(nm[q], 48, "gemv1<%d,%d> N%d K%d", p.in_mode, p.out_mode, p.N, p.K); p.trc = trace_next(nm[q]); }
-#endif
-        const int NT_total = (p.N + 15) / 16;
-        dim3 grid((NT_total + c.NTB - 1) / c.NTB), block(c.nw * 64);
-#define WLX_G1(NTB_, IN_, OUT_, MAXT_) \
-    hipLaunchKernelGGL((dec_gemv1_kernel<NTB_, IN_, OUT_, MAXT_>), grid, block, c.shm, s, p)
-        if (p.in_mode == GEMV_IN_LN) {
-            switch (p.out_mode) {
-                case GEMV_OUT_QKV: WLX_G1(1, GEMV_IN_LN, GEMV_OUT_QKV, 512); break;
-                case GEMV_OUT_F16: WLX_G1(1, GEMV_IN_LN, GEMV_OUT_F16, 512); break;
-                case GEMV_OUT_GELU_F16: WLX_G1(1, GEMV_IN_LN, GEMV_OUT_GELU_F16, 512); break;
-                default:
-                    if (c.NTB == 2) WLX_G1(2, GEMV_IN_LN, GEMV_OUT_F32, 512);
-                    else WLX_G1(1, GEMV_IN_LN, GEMV_OUT_F32, 512);
-                    break;
-            }
-        } else if (p.in_mode == GEMV_IN_F16) {
-            WLX_G1(1, GEMV_IN_F16, GEMV_OUT_RESID, 1024);
-        } else {
-            WLX_G1(1, GEMV_IN_XATTN, GEMV_OUT_RESID, 768);
-        }
-#undef WLX_G1
-        return;
-    }
     const GemvParams& p = p0;
     const int MT = (p.M + 15) / 16;
     const int NT_total = (p.N + 15) / 16;
@@ -1104,419 +744,135 @@ void launch_dec_gemv(const GemvParams& p0, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------ causal self-attention over the KV cache
-// one wave per (row, head); positions 0..pos[row]; history of the row through the ancestry table
-__global__ __launch_bounds__(64) void dec_self_attn_kernel(const half_t* __restrict__ q, long ldq,
-                                                           const half_t* __restrict__ Kc,
-                                                           const half_t* __restrict__ Vc, long crs, int d,
-                                                           const int* __restrict__ pos,
-                                                           const int* __restrict__ ancrow,
-                                                           const short* __restrict__ anc,
-                                                           half_t* __restrict__ out, long ldo,
-                                                           const int* __restrict__ done) {
-    if (done && *done) return;
-    __shared__ float prob[WLX_T_TEXT];
-    __shared__ int crow[WLX_T_TEXT];
-    const int lane = threadIdx.x;
-    const int r = blockIdx.x, h = blockIdx.y;
-    const int len = pos[r] + 1;
-    const short* ar = anc + (long)ancrow[r] * WLX_T_TEXT;
-
-    // q (already scaled) -> registers as 64 floats? keep as 8 x f16x8 broadcast loads
-    f16x8 qv[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) qv[i] = ld_f16x8(q + (long)r * ldq + h * WLX_HEAD_DIM + i * 8);
-
-    float lmax = WLX_NEG_INF;
-    for (int p0 = 0; p0 < len; p0 += 64) {
-        const int p = p0 + lane;
-        float sc = WLX_NEG_INF;
-        if (p < len) {
-            const int cr = ar[p];
-            crow[p] = cr;
-            const half_t* kp = Kc + (long)cr * crs + (long)p * d + h * WLX_HEAD_DIM;
-            float a = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                f16x8 kv = ld_f16x8(kp + i * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a = fmaf((float)kv[e], (float)qv[i][e], a);
-            }
-            sc = a;
-            prob[p] = a;
-        }
-        lmax = fmaxf(lmax, sc);
-    }
-    lmax = wave_max(lmax);
-    float lsum = 0.f;
-    for (int p = lane; p < len; p += 64) {
-        float e = __expf(prob[p] - lmax);
-        prob[p] = e;
-        lsum += e;
-    }
-    lsum = wave_sum(lsum);
-    __syncthreads();
-    // out[dd = lane] = sum_p prob[p] * V[p][dd]
-    float o = 0.f;
-    const half_t* vb = Vc + h * WLX_HEAD_DIM + lane;
-    int p = 0;
-    for (; p + 4 <= len; p += 4) {
-        float v0 = (float)vb[(long)crow[p] * crs + (long)p * d];
-        float v1 = (float)vb[(long)crow[p + 1] * crs + (long)(p + 1) * d];
-        float v2 = (float)vb[(long)crow[p + 2] * crs + (long)(p + 2) * d];
-        float v3 = (float)vb[(long)crow[p + 3] * crs + (long)(p + 3) * d];
-        o = fmaf(prob[p], v0, o); o = fmaf(prob[p + 1], v1, o);
-        o = fmaf(prob[p + 2], v2, o); o = fmaf(prob[p + 3], v3, o);
-    }
-    for (; p < len; ++p) o = fmaf(prob[p], (float)vb[(long)crow[p] * crs + (long)p * d], o);
-    out[(long)r * ldo + h * WLX_HEAD_DIM + lane] = (half_t)(o / lsum);
-}
-
-// second generation: same arithmetic for the scores; the V pass gives every lane a (position group, 8-dim
-// chunk) pair so 8 independent 16-byte loads are in flight per lane (one L2 round trip per 64 positions
-// instead of one per 4), and the done flag / row tables / q are requested before the first wait.
+// One wave per (row, head); positions 0..pos[row]; the history of a row is read through the ancestry table.
+// Flash-style over blocks of 64 positions so one rolled loop serves every length (code size is latency here: the
+// two-pass form was 4.6 KiB of straight-line code, ~1.8 us of cold instruction fetch per launch):
+//   per block: lane p looks up the cache row of position p (one dependent trip), then the K rows (lane = position, whole
+//   128-byte row) AND the V rows (lane = (position group pg, 8-dim chunk dc)) are requested together — one more trip —,
+//   scores by in-lane dot product, block max / sum by DPP, probabilities through LDS to the (pg, dc) lanes, which
+//   accumulate their 8 dims over their 8 positions with the running-max rescale.
+//   tail: the 8 position groups are summed through LDS, lane d writes output dim d.
 __global__ __launch_bounds__(64) void dec_self_attn2_kernel(const half_t* __restrict__ q, long ldq,
                                                             const half_t* __restrict__ Kc,
                                                             const half_t* __restrict__ Vc, long crs, int d,
                                                             const int* __restrict__ pos,
                                                             const int* __restrict__ ancrow,
                                                             const short* __restrict__ anc,
-                                                            half_t* __restrict__ out, long ldo,
-                                                            const int* __restrict__ done WLX_TR_PARAM) {
-    __shared__ float prob[WLX_T_TEXT];
-    __shared__ int crow[WLX_T_TEXT];
+                                                            half_t* __restrict__ out, long ldo WLX_TR_PARAM) {
+    __shared__ float prob[64];
+    __shared__ int crow[64];
+    __shared__ float part[8][64];
     const int lane = threadIdx.x;
     const int r = blockIdx.x, h = blockIdx.y;
     WLX_TR_BEGIN();
-    int dn = 0;
-    if (done) dn = *done;
     const int len = pos[r] + 1;
     const short* ar = anc + (long)ancrow[r] * WLX_T_TEXT;
     f16x8 qv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) qv[i] = ld_f16x8(q + (long)r * ldq + h * WLX_HEAD_DIM + i * 8);
-    if (dn) return;
+    const int pg = lane >> 3, dc = lane & 7;
+    const int hoff = h * WLX_HEAD_DIM;
+    const int icrs = (int)crs;                             // 32-bit element offsets: cache_rows * 448 * d < 2^31
+    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float mrun = WLX_NEG_INF, lrun = 0.f;
     WLX_TR_MARK(1);
-
-    float lmax = WLX_NEG_INF;
+#pragma unroll 1
     for (int p0 = 0; p0 < len; p0 += 64) {
         const int p = p0 + lane;
-        float sc = WLX_NEG_INF;
-        if (p < len) {
-            const int cr = ar[p];
-            crow[p] = cr;
-            const half_t* kp = Kc + (long)cr * crs + (long)p * d + h * WLX_HEAD_DIM;
-            f16x8 kv[8];
+        const bool ok = p < len;
+        const int cr = ar[ok ? p : len - 1];
+        crow[lane] = cr;
+        // K row of position p (lane = position); the LDS write above is visible to this same wave after the wait below
+        const half_t* kp = Kc + (unsigned)(cr * icrs + (ok ? p : len - 1) * d + hoff);
+        f16x8 kv[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) kv[i] = ld_f16x8(kp + i * 8);
-            float a = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) a = fmaf((float)kv[i][e], (float)qv[i][e], a);
-            }
-            sc = a;
-            prob[p] = a;
-        }
-        lmax = fmaxf(lmax, sc);
-    }
-    lmax = wave_max(lmax);
-    float lsum = 0.f;
-    for (int p = lane; p < len; p += 64) {
-        const float e = __expf(prob[p] - lmax);
-        prob[p] = e;
-        lsum += e;
-    }
-    lsum = wave_sum(lsum);
-    __syncthreads();
-    WLX_TR_MARK(2);
-    // out[dd] = sum_p prob[p] * V[p][dd]; lane = (pg, dc): positions p = pg (mod 8), dims dc*8 .. dc*8+7
-    const int pg = lane >> 3, dc = lane & 7;
-    const half_t* vb = Vc + h * WLX_HEAD_DIM + dc * 8;
-    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    for (int p0 = 0; p0 < len; p0 += 64) {
+        for (int i = 0; i < 8; ++i) kv[i] = ld_f16x8(kp + i * 8);
+        // V chunks: positions p0 + u*8 + pg, dims dc*8 .. dc*8+7
         f16x8 vv[8];
-        float pr[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const int p = p0 + u * 8 + pg;
-            const int pc = (p < len) ? p : len - 1;
-            pr[u] = (p < len) ? prob[pc] : 0.f;
-            vv[u] = ld_f16x8(vb + (long)crow[pc] * crs + (long)pc * d);
+            const int pp = p0 + u * 8 + pg;
+            const int pc = (pp < len) ? pp : len - 1;
+            vv[u] = ld_f16x8(Vc + (unsigned)(crow[u * 8 + pg] * icrs + pc * d + hoff + dc * 8));
         }
+        float sc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sc = fmaf((float)kv[i][e], (float)qv[i][e], sc);
+        sc = ok ? sc : WLX_NEG_INF;
+        const float bmax = dpp_wave_max(sc);
+        const float mnew = fmaxf(mrun, bmax);               // finite: position p0 is valid
+        const float alpha = __expf(mrun - mnew);
+        const float pe = __expf(sc - mnew);                 // 0 for masked lanes
+        lrun = lrun * alpha + dpp_wave_sum(pe);
+        mrun = mnew;
+        prob[lane] = pe;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] *= alpha;
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
+            const float pr = prob[u * 8 + pg];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = fmaf(pr[u], (float)vv[u][e], o[e]);
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(pr, (float)vv[u][e], o[e]);
         }
     }
+    WLX_TR_MARK(2);
+    // sum the 8 position groups: part[pg][dim]; lane d then owns output dim d
+    *reinterpret_cast<float4*>(&part[pg][dc * 8]) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(&part[pg][dc * 8 + 4]) = make_float4(o[4], o[5], o[6], o[7]);
+    float acc = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        o[e] += __shfl_xor(o[e], 8, 64);
-        o[e] += __shfl_xor(o[e], 16, 64);
-        o[e] += __shfl_xor(o[e], 32, 64);
-    }
-    if (pg == 0) {
-        const float inv = 1.0f / lsum;
-        const f16x8 hv = {(half_t)(o[0] * inv), (half_t)(o[1] * inv), (half_t)(o[2] * inv), (half_t)(o[3] * inv),
-                          (half_t)(o[4] * inv), (half_t)(o[5] * inv), (half_t)(o[6] * inv), (half_t)(o[7] * inv)};
-        *reinterpret_cast<f16x8*>(out + (long)r * ldo + h * WLX_HEAD_DIM + dc * 8) = hv;
-    }
+    for (int g8 = 0; g8 < 8; ++g8) acc += part[g8][lane];
+    out[(long)r * ldo + hoff + lane] = (half_t)(acc / lrun);
     WLX_TR_MARK(3);
     WLX_TR_END(trc);
 }
 
 void launch_dec_self_attn(const half_t* q, long ldq, const half_t* Kc, const half_t* Vc, long crs, int d, int H,
                           const RowTables& rt, int rows, half_t* out, long ldo, const int* done, hipStream_t s) {
-    if (g_decode_v1)
-        hipLaunchKernelGGL(dec_self_attn_kernel, dim3(rows, H), dim3(64), 0, s, q, ldq, Kc, Vc, crs, d, rt.pos,
-                           rt.ancrow, rt.anc, out, ldo, done);
-    else
-        hipLaunchKernelGGL(dec_self_attn2_kernel, dim3(rows, H), dim3(64), 0, s, q, ldq, Kc, Vc, crs, d, rt.pos,
-                           rt.ancrow, rt.anc, out, ldo, done WLX_TR_ARG("self_attn2"));
+    (void)done;   // a step that runs after the search raised `done` only rewrites scratch (engine.hip decoder_pass)
+    hipLaunchKernelGGL(dec_self_attn2_kernel, dim3(rows, H), dim3(64), 0, s, q, ldq, Kc, Vc, crs, d, rt.pos,
+                       rt.ancrow, rt.anc, out, ldo WLX_TR_ARG("self_attn"));
 }
 
 // ------------------------------------------------------------------ decode cross-attention (flash-decoding split over keys)
-// grid (split, head, item); the R rows of an item share the item's encoder K/V, so they form ONE
-// 16-row MFMA query tile (same transposed-score scheme as attention.hip). Each split writes its
-// un-normalised (m, l, O) partial; the consumer projection combines them in its prologue.
-__global__ __launch_bounds__(64) void dec_cross_attn_kernel(const half_t* __restrict__ q, long ldq,
-                                                            const half_t* __restrict__ Kx, long ldk, long isk,
-                                                            const half_t* __restrict__ Vtx, long ldvt, long isv,
-                                                            int H, int R, int rows,
-                                                            const int* __restrict__ group_item,
-                                                            float* __restrict__ part_o, float* __restrict__ part_ml,
-                                                            const int* __restrict__ done) {
-    if (done && *done) return;
-    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
-    const int sp = blockIdx.x, h = blockIdx.y, grp = blockIdx.z;
-    const int item = group_item[grp];
-    constexpr int T = WLX_T_AUDIO;
-    constexpr int TILES = (T + 31) / 32;                               // 47
-    constexpr int TPS = (TILES + WLX_XSPLIT - 1) / WLX_XSPLIT;         // 6 key tiles per split
-    const int tile0 = sp * TPS;
-    const int tile1 = (tile0 + TPS < TILES) ? tile0 + TPS : TILES;
-
-    const half_t* K = Kx + (long)item * isk + h * WLX_HEAD_DIM;
-    const half_t* Vt = Vtx + (long)item * isv + (long)h * WLX_HEAD_DIM * ldvt;
-
-    int row = grp * R + c;
-    const bool qok = (c < R) && (row < rows);
-    if (!qok) row = grp * R;  // any valid row; result discarded
-    f16x8 qf[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) qf[kt] = ld_f16x8(q + (long)row * ldq + h * WLX_HEAD_DIM + kt * 32 + g * 8);
-
-    f32x4 acc[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float mrun = WLX_NEG_INF, lrun = 0.f;
-    const half_t* kbase = K + (long)c * ldk + g * 8;
-    const half_t* vbase = Vt + (long)c * ldvt + g * 4;
-
-    for (int tile = tile0; tile < tile1; ++tile) {
-        const int key0 = tile * 32;
-        f16x8 kf[2][2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) kf[s2][kt] = ld_f16x8(kbase + (long)(key0 + s2 * 16) * ldk + kt * 32);
-        f16x8 vf[4];
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const half_t* vp = vbase + (long)dt * 16 * ldvt + key0;
-            f16x4 lo = ld_f16x4(vp), hi = ld_f16x4(vp + 16);
-            vf[dt] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        }
-        f32x4 st[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            st[s2] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) st[s2] = mfma16(kf[s2][kt], qf[kt], st[s2]);
-        }
-        float pv[8];
-        float tmax = WLX_NEG_INF;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = key0 + s2 * 16 + g * 4 + r;
-                const float v = (key < T) ? st[s2][r] : WLX_NEG_INF;
-                pv[s2 * 4 + r] = v;
-                tmax = fmaxf(tmax, v);
-            }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mnew = fmaxf(mrun, tmax);
-        const float alpha = __expf(mrun - mnew);
-        float psum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { pv[i] = __expf(pv[i] - mnew); psum += pv[i]; }
-        lrun = lrun * alpha + psum;
-        mrun = mnew;
-        f16x8 pf = {(half_t)pv[0], (half_t)pv[1], (half_t)pv[2], (half_t)pv[3],
-                    (half_t)pv[4], (half_t)pv[5], (half_t)pv[6], (half_t)pv[7]};
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            f32x4 a = acc[dt];
-            a[0] *= alpha; a[1] *= alpha; a[2] *= alpha; a[3] *= alpha;
-            acc[dt] = mfma16(vf[dt], pf, a);
-        }
-    }
-    lrun += __shfl_xor(lrun, 16, 64);
-    lrun += __shfl_xor(lrun, 32, 64);
-    const long pb = (((long)grp * H + h) * WLX_XSPLIT + sp) * 16 + c;
-    if (g == 0) *reinterpret_cast<float2*>(part_ml + pb * 2) = make_float2(mrun, lrun);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-        *reinterpret_cast<f32x4*>(part_o + pb * 64 + dt * 16 + g * 4) = acc[dt];
-}
-
-// second generation: identical arithmetic and partial layout, but the K and V^T fragments of all six key
-// tiles of the split (48 KiB per wave) are requested in one burst before the first MFMA, so the split costs one
-// HBM/L2 round trip instead of six dependent ones. K/V^T are padded to 1536 keys, so every split may read its full
-// six tiles; keys >= 1500 are masked to -inf exactly as before.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void dec_cross_attn2_kernel(const half_t* __restrict__ q, long ldq,
-                                                             const half_t* __restrict__ Kx, long ldk, long isk,
-                                                             const half_t* __restrict__ Vtx, long ldvt, long isv,
-                                                             int H, int R, int rows,
-                                                             const int* __restrict__ group_item,
-                                                             float* __restrict__ part_o, float* __restrict__ part_ml,
-                                                             const int* __restrict__ done WLX_TR_PARAM) {
-    const int lane = threadIdx.x, c = lane & 15, g = lane >> 4;
-    const int sp = blockIdx.x, h = blockIdx.y, grp = blockIdx.z;
-    WLX_TR_BEGIN();
-    int dn = 0;
-    if (done) dn = *done;
-    const int item = group_item[grp];
-    constexpr int T = WLX_T_AUDIO;
-    constexpr int TPS = WLX_T_AUDIO_PAD / 32 / WLX_XSPLIT;     // 6 key tiles per split (48 tiles of 32 keys)
-    static_assert(TPS * WLX_XSPLIT * 32 == WLX_T_AUDIO_PAD, "key padding must cover every split");
-    const int tile0 = sp * TPS;
-
-    const half_t* K = Kx + (long)item * isk + h * WLX_HEAD_DIM;
-    const half_t* Vt = Vtx + (long)item * isv + (long)h * WLX_HEAD_DIM * ldvt;
-    const half_t* kbase = K + (long)c * ldk + g * 8;
-    const half_t* vbase = Vt + (long)c * ldvt + g * 4;
-
-    f16x8 kf[TPS][2][2];
-    f16x4 vlo[TPS][4], vhi[TPS][4];
-#pragma unroll
-    for (int t = 0; t < TPS; ++t) {
-        const int key0 = (tile0 + t) * 32;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) kf[t][s2][kt] = ld_f16x8(kbase + (long)(key0 + s2 * 16) * ldk + kt * 32);
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            const half_t* vp = vbase + (long)dt * 16 * ldvt + key0;
-            vlo[t][dt] = ld_f16x4(vp);
-            vhi[t][dt] = ld_f16x4(vp + 16);
-        }
-    }
-    int row = grp * R + c;
-    const bool qok = (c < R) && (row < rows);
-    if (!qok) row = grp * R;  // any valid row; result discarded
-    f16x8 qf[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) qf[kt] = ld_f16x8(q + (long)row * ldq + h * WLX_HEAD_DIM + kt * 32 + g * 8);
-    if (dn) return;
-    WLX_TR_MARK(1);
-
-    f32x4 acc[4];
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float mrun = WLX_NEG_INF, lrun = 0.f;
-#pragma unroll
-    for (int t = 0; t < TPS; ++t) {
-        const int key0 = (tile0 + t) * 32;
-        f32x4 st[2];
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            st[s2] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt) st[s2] = mfma16(kf[t][s2][kt], qf[kt], st[s2]);
-        }
-        float pv[8];
-        float tmax = WLX_NEG_INF;
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = key0 + s2 * 16 + g * 4 + r;
-                const float v = (key < T) ? st[s2][r] : WLX_NEG_INF;
-                pv[s2 * 4 + r] = v;
-                tmax = fmaxf(tmax, v);
-            }
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-        const float mnew = fmaxf(mrun, tmax);      // finite from the first tile on: every split starts below key 1500
-        const float alpha = __expf(mrun - mnew);
-        float psum = 0.f;
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { pv[i] = __expf(pv[i] - mnew); psum += pv[i]; }
-        lrun = lrun * alpha + psum;
-        mrun = mnew;
-        const f16x8 pf = {(half_t)pv[0], (half_t)pv[1], (half_t)pv[2], (half_t)pv[3],
-                          (half_t)pv[4], (half_t)pv[5], (half_t)pv[6], (half_t)pv[7]};
-#pragma unroll
-        for (int dt = 0; dt < 4; ++dt) {
-            f32x4 a = acc[dt];
-            a[0] *= alpha; a[1] *= alpha; a[2] *= alpha; a[3] *= alpha;
-            const f16x8 vf = {vlo[t][dt][0], vlo[t][dt][1], vlo[t][dt][2], vlo[t][dt][3],
-                              vhi[t][dt][0], vhi[t][dt][1], vhi[t][dt][2], vhi[t][dt][3]};
-            acc[dt] = mfma16(vf, pf, a);
-        }
-    }
-    lrun += __shfl_xor(lrun, 16, 64);
-    lrun += __shfl_xor(lrun, 32, 64);
-    const long pb = (((long)grp * H + h) * WLX_XSPLIT + sp) * 16 + c;
-    if (g == 0) *reinterpret_cast<float2*>(part_ml + pb * 2) = make_float2(mrun, lrun);
-#pragma unroll
-    for (int dt = 0; dt < 4; ++dt)
-        *reinterpret_cast<f32x4*>(part_o + pb * 64 + dt * 16 + g * 4) = acc[dt];
-    WLX_TR_MARK(3);
-    WLX_TR_END(trc);
-}
-
-// third generation: one WORKGROUP of TPS waves per (split, head, group), one 32-key tile per wave. A lone wave pulling
-// its split's 48 KiB was the longest single-wave stream of the step (5.6 us per launch alone); six waves pull 8 KiB each,
-// form their (m, l, O) over one tile and the workgroup merges the six through LDS into the same per-split partial the
-// consumer projection already combines (layout unchanged). Fully masked tiles (keys >= 1500) contribute (m=-inf, l=0, O=0).
-#define XA3_TPS (WLX_T_AUDIO_PAD / 32 / WLX_XSPLIT)
-__global__ __launch_bounds__(XA3_TPS * 64) void dec_cross_attn3_kernel(const half_t* __restrict__ q, long ldq,
-                                                                       const half_t* __restrict__ Kx, long ldk, long isk,
-                                                                       const half_t* __restrict__ Vtx, long ldvt, long isv,
-                                                                       int H, int R, int rows,
-                                                                       const int* __restrict__ group_item,
-                                                                       float* __restrict__ part_o, float* __restrict__ part_ml WLX_TR_PARAM) {
-    constexpr int TPS = XA3_TPS;
+// grid (split, head, group): the R rows of an item share the item's encoder K/V, so they form ONE 16-row MFMA query
+// tile (scores transposed as in attention.hip: S^T = K Q^T, softmax in-lane + 2 DPP steps, O^T = V^T P^T).
+// One WORKGROUP of XA_TPS waves per (split, head, group), one 32-key tile per wave: six waves pull 8 KiB each, form
+// their (m, l, O) over one tile and merge through LDS into the split's partial.
+//   * K and V come TILE-PACKED from the encoder's cross-K/V GEMM epilogue (gemm.hip GEMM_CROSS_KV): per (layer, item,
+//     head, 32-key tile) a 4 KiB image in MFMA operand order, so every load is one contiguous 1 KiB per wave (the
+//     row-major K / transposed V of the first generations cost 12 strided loads of 32-64 byte segments per tile);
+//     keys >= 1500 of the padding are zero in V (never written) and masked to -inf in the scores.
+//   * the partial handed to the consumer projection is the NORMALISED fp16 O plus fp32 (m, l), the (m, l) of a row's
+//     eight splits contiguous: the consumer's combine is bound by load-instruction count per CU, not by bytes.
+#define XA_TPS (WLX_T_AUDIO_PAD / 32 / WLX_XSPLIT)
+__global__ __launch_bounds__(XA_TPS * 64) void dec_cross_attn_kernel(const half_t* __restrict__ q, long ldq,
+                                                                     const half_t* __restrict__ Kp, const half_t* __restrict__ Vp,
+                                                                     long item_stride, int H, int R, int rows,
+                                                                     const int* __restrict__ group_item,
+                                                                     half_t* __restrict__ part_o, float* __restrict__ part_ml WLX_TR_PARAM) {
+    constexpr int TPS = XA_TPS;
     static_assert(TPS * WLX_XSPLIT * 32 == WLX_T_AUDIO_PAD && TPS >= 4, "key padding must cover every split; >= 4 waves combine");
     __shared__ __attribute__((aligned(16))) float Os[TPS][16][68];
     __shared__ float MLs[TPS][16][2];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int sp = blockIdx.x, h = blockIdx.y, grp = blockIdx.z;
     WLX_TR_BEGIN();
     const int item = group_item[grp];
     constexpr int T = WLX_T_AUDIO;
-    const int key0 = (sp * TPS + wave) * 32;
-    const half_t* K = Kx + (long)item * isk + h * WLX_HEAD_DIM;
-    const half_t* Vt = Vtx + (long)item * isv + (long)h * WLX_HEAD_DIM * ldvt;
-    const half_t* kbase = K + (long)c * ldk + g * 8;
-    const half_t* vbase = Vt + (long)c * ldvt + g * 4;
-    f16x8 kf[2][2];
-    f16x4 vlo[4], vhi[4];
+    const int tile = sp * TPS + wave;
+    const int key0 = tile * 32;
+    const long toff = (long)item * item_stride + ((long)h * (WLX_T_AUDIO_PAD / 32) + tile) * 2048 + lane * 8;
+    f16x8 kf[2][2], vf[4];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) kf[s2][kt] = ld_f16x8(kbase + (long)(key0 + s2 * 16) * ldk + kt * 32);
+        for (int kt = 0; kt < 2; ++kt) kf[s2][kt] = ld_f16x8(Kp + toff + (s2 * 2 + kt) * 512);
 #pragma unroll
-    for (int dt = 0; dt < 4; ++dt) {
-        const half_t* vp = vbase + (long)dt * 16 * ldvt + key0;
-        vlo[dt] = ld_f16x4(vp);
-        vhi[dt] = ld_f16x4(vp + 16);
-    }
+    for (int dt = 0; dt < 4; ++dt) vf[dt] = ld_f16x8(Vp + toff + dt * 512);
     int row = grp * R + c;
     const bool qok = (c < R) && (row < rows);
     if (!qok) row = grp * R;  // any valid row; result discarded
@@ -1555,8 +911,7 @@ __global__ __launch_bounds__(XA3_TPS * 64) void dec_cross_attn3_kernel(const hal
                       (half_t)pv[4], (half_t)pv[5], (half_t)pv[6], (half_t)pv[7]};
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) {
-        const f16x8 vf = {vlo[dt][0], vlo[dt][1], vlo[dt][2], vlo[dt][3], vhi[dt][0], vhi[dt][1], vhi[dt][2], vhi[dt][3]};
-        const f32x4 a = mfma16(vf, pf, (f32x4){0.f, 0.f, 0.f, 0.f});
+        const f32x4 a = mfma16(vf[dt], pf, (f32x4){0.f, 0.f, 0.f, 0.f});
         *reinterpret_cast<f32x4*>(&Os[wave][c][dt * 16 + g * 4]) = a;
     }
     if (g == 0) { MLs[wave][c][0] = tmax; MLs[wave][c][1] = psum; }
@@ -1578,26 +933,20 @@ __global__ __launch_bounds__(XA3_TPS * 64) void dec_cross_attn3_kernel(const hal
             const f32x4 t = *reinterpret_cast<const f32x4*>(&Os[w][c][dt * 16 + g * 4]);
             o[0] += e * t[0]; o[1] += e * t[1]; o[2] += e * t[2]; o[3] += e * t[3];
         }
-        const long pb = (((long)grp * H + h) * WLX_XSPLIT + sp) * 16 + c;
-        if (dt == 0 && g == 0) *reinterpret_cast<float2*>(part_ml + pb * 2) = make_float2(M, l);
-        *reinterpret_cast<f32x4*>(part_o + pb * 64 + dt * 16 + g * 4) = o;
+        const long ih = (long)grp * H + h;
+        const float inv = 1.0f / l;               // every split starts below key 1500: l > 0
+        const f16x4 hv = {(half_t)(o[0] * inv), (half_t)(o[1] * inv), (half_t)(o[2] * inv), (half_t)(o[3] * inv)};
+        *reinterpret_cast<f16x4*>(part_o + ((ih * WLX_XSPLIT + sp) * 16 + c) * 64 + dt * 16 + g * 4) = hv;
+        if (dt == 0 && g == 0) *reinterpret_cast<float2*>(part_ml + (ih * 16 + c) * (WLX_XSPLIT * 2) + sp * 2) = make_float2(M, l);
     }
     WLX_TR_MARK(3);
     WLX_TR_END(trc);
 }
 
-void launch_dec_cross_attn(const half_t* q, long ldq, const half_t* Kx, long ldk, long isk, const half_t* Vtx,
-                           long ldvt, long isv, int H, int R, int groups, int rows, const int* group_item,
-                           float* part_o, float* part_ml, const int* done, hipStream_t s) {
-    if (g_decode_v1)
-        hipLaunchKernelGGL(dec_cross_attn_kernel, dim3(WLX_XSPLIT, H, groups), dim3(64), 0, s, q, ldq, Kx, ldk, isk, Vtx,
-                           ldvt, isv, H, R, rows, group_item, part_o, part_ml, done);
-    else if (g_decode_v2)
-        hipLaunchKernelGGL(dec_cross_attn2_kernel, dim3(WLX_XSPLIT, H, groups), dim3(64), 0, s, q, ldq, Kx, ldk, isk, Vtx,
-                           ldvt, isv, H, R, rows, group_item, part_o, part_ml, done WLX_TR_ARG("cross_attn2"));
-    else
-        hipLaunchKernelGGL(dec_cross_attn3_kernel, dim3(WLX_XSPLIT, H, groups), dim3(XA3_TPS * 64), 0, s, q, ldq, Kx, ldk, isk, Vtx,
-                           ldvt, isv, H, R, rows, group_item, part_o, part_ml WLX_TR_ARG("cross_attn3"));
+void launch_dec_cross_attn(const half_t* q, long ldq, const half_t* Kp, const half_t* Vp, long item_stride, int H, int R,
+                           int groups, int rows, const int* group_item, half_t* part_o, float* part_ml, hipStream_t s) {
+    hipLaunchKernelGGL(dec_cross_attn_kernel, dim3(WLX_XSPLIT, H, groups), dim3(XA_TPS * 64), 0, s, q, ldq, Kp, Vp, item_stride,
+                       H, R, rows, group_item, part_o, part_ml WLX_TR_ARG("cross_attn"));
 }
 
 }  // namespace wlx

@@ -54,7 +54,8 @@ struct Slot {
     // decoder
     half_t *kc = nullptr, *vc = nullptr;             // self cache [L][cache_rows][448][d]
     float* xd = nullptr; half_t *qd = nullptr, *attnd = nullptr, *hd = nullptr;
-    float *part_o = nullptr, *part_ml = nullptr, *logits = nullptr;
+    half_t* part_o = nullptr;
+    float *part_ml = nullptr, *logits = nullptr;
     long ldl = 0;
     int *d_token = nullptr, *d_pos = nullptr, *d_cache = nullptr, *d_ancrow = nullptr, *d_group_item = nullptr;
     short* d_anc = nullptr; int* d_intok = nullptr;

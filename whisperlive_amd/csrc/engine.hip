@@ -322,8 +322,6 @@ extern "C" int32_t wlx_engine_create(const wlx_spec* spec, const wlx_tensor* wei
     e->use_graph = !(ng && ng[0] == '1');
     const char* v1 = getenv("WLX_DECODE_V1");
     g_decode_v1 = (v1 && v1[0] == '1');
-    const char* v2 = getenv("WLX_DECODE_V2");
-    g_decode_v2 = (v2 && v2[0] == '1');
     int rc = engine_load(e, weights, n_weights);
     if (rc != WLX_OK) {
         for (void* p : e->allocs) (void)hipFree(p);
@@ -458,6 +456,7 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         CKR(dalloc(s->allocs, &st.scan_stats, (size_t)RC * SC_MAXCH * SC_NSTAT));
         CKR(dalloc(s->allocs, &st.scan_cv, (size_t)RC * (SC_MAXCH + 1) * WLX_MAX_CAND));
         CKR(dalloc(s->allocs, &st.scan_ci, (size_t)RC * (SC_MAXCH + 1) * WLX_MAX_CAND));
+        CKR(dalloc(s->allocs, &st.rule, (size_t)RC * 4));
         CKR(dalloc(s->allocs, &s->d_sp, 1));
         CKR(dalloc(s->allocs, &s->d_suppress, (size_t)(1024 * 52 / 32)));
         CKR(dalloc(s->allocs, &s->d_lang_ids, 256));
@@ -716,7 +715,7 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
         p.Yh = s->qd; p.ldyh = d; p.d = d; p.qscale = 0.125f; p.Kc = kc; p.Vc = vc; p.cache_row_stride = crs;
         p.row_cache = s->d_cache; p.row_pos = s->d_pos; p.done = done;
         pgemv(s, p);
-        plaunch(s, g_decode_v1 ? "dec_self_attn_kernel" : "dec_self_attn2_kernel", 4.0 * rows * d * (s->prof ? s->prof->t + 1 : 1), [&] { launch_dec_self_attn(s->qd, d, kc, vc, crs, d, H, rt, rows, s->attnd, d, done, st); });
+        plaunch(s, "dec_self_attn2_kernel", 4.0 * rows * d * (s->prof ? s->prof->t + 1 : 1), [&] { launch_dec_self_attn(s->qd, d, kc, vc, crs, d, H, rt, rows, s->attnd, d, done, st); });
         p = GemvParams{};
         p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
         p.Wp = w.Wo; p.bias = w.bo; p.Xh = s->attnd; p.ldxh = d; p.Xres = s->xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
@@ -727,10 +726,9 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
         p.Wp = w.Wcq; p.bias = w.bcq; p.X = s->xd; p.ldx = d; p.gamma = w.ln2_g; p.beta = w.ln2_b;
         p.Yh = s->qd; p.ldyh = d; p.qscale = 0.125f; p.done = done;
         pgemv(s, p);
-        plaunch(s, g_decode_v1 ? "dec_cross_attn_kernel" : "dec_cross_attn3_kernel", 4.0 * groups * WLX_T_AUDIO * d, [&] {
-            launch_dec_cross_attn(s->qd, d, s->ck + (size_t)l * s->B * WLX_T_AUDIO_PAD * d, d, (long)WLX_T_AUDIO_PAD * d,
-                                  s->cvt + (size_t)l * s->B * d * WLX_T_AUDIO_PAD, WLX_T_AUDIO_PAD, (long)d * WLX_T_AUDIO_PAD,
-                                  H, R, groups, rows, s->d_group_item, s->part_o, s->part_ml, done, st);
+        plaunch(s, "dec_cross_attn_kernel", 4.0 * groups * WLX_T_AUDIO * d, [&] {
+            launch_dec_cross_attn(s->qd, d, s->ck + (size_t)l * s->B * WLX_T_AUDIO_PAD * d, s->cvt + (size_t)l * s->B * d * WLX_T_AUDIO_PAD,
+                                  (long)WLX_T_AUDIO_PAD * d, H, R, groups, rows, s->d_group_item, s->part_o, s->part_ml, st);
         });
         p = GemvParams{};
         p.in_mode = GEMV_IN_XATTN; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
@@ -817,8 +815,8 @@ static void launch_search(Engine* e, Slot* s, int rows, int groups, bool samplin
         launch_search_rows(s->logits, s->d_sp, rows, s->st, s->stream);
         launch_search_update(s->d_sp, groups, s->st, s->stream);
     } else {
-        launch_search_scan(s->logits, s->ldl, e->spec.vocab, s->d_sp, rows, s->st, s->stream);
-        launch_search_merge_update(s->logits, s->ldl, e->spec.vocab, s->d_sp, groups, s->st, s->stream);
+        launch_search_scan3(s->logits, s->ldl, e->spec.vocab, s->d_sp, rows, s->st, s->stream);
+        launch_search_merge_update3(s->logits, s->ldl, e->spec.vocab, s->d_sp, groups, s->st, s->stream);
     }
 }
 
@@ -948,6 +946,10 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
         }
     }
     CK(hipMemcpyAsync(S.cum, cum.data(), rows * 4, hipMemcpyHostToDevice, st));
+    // rule state before the first generated token: no last token, "one before last" counts as a timestamp, no timestamp yet
+    std::vector<int> rule0((size_t)rows * 4);
+    for (int r = 0; r < rows; ++r) { rule0[4 * r] = 0; rule0[4 * r + 1] = 1; rule0[4 * r + 2] = -1; rule0[4 * r + 3] = 0; }
+    CK(hipMemcpyAsync(S.rule, rule0.data(), rule0.size() * 4, hipMemcpyHostToDevice, st));
     CK(hipMemcpyAsync(S.plen, pl.data(), batch * 4, hipMemcpyHostToDevice, st));
     CKR(set_anc_rows(s, anc, 0, rows));
     // ---- prefill prompt[0 .. plen-2]; no_speech_prob is read at the sot position
@@ -1204,6 +1206,9 @@ extern "C" int32_t wlx_debug_trace_step(wlx_engine* e, int32_t slot, int32_t row
         CKR(upload_rows(s, tk, ps, ca, an, gi));
         CK(hipMemsetAsync(s->st.done, 0, 4, st)); CK(hipMemsetAsync(s->st.item_done, 0, 4, st));
         CK(hipMemsetAsync(s->st.n_hyp, 0, 4, st)); CK(hipMemsetAsync(s->st.n_finished, 0, 4, st));
+        static const int rule0[16 * 4] = {0, 1, -1, 0, 0, 1, -1, 0, 0, 1, -1, 0, 0, 1, -1, 0, 0, 1, -1, 0, 0, 1, -1, 0, 0, 1, -1, 0, 0, 1, -1, 0,
+                                          0, 1, -1, 0, 0, 1, -1, 0, 0, 1, -1, 0, 0, 1, -1, 0, 0, 1, -1, 0, 0, 1, -1, 0, 0, 1, -1, 0, 0, 1, -1, 0};
+        CK(hipMemcpyAsync(s->st.rule, rule0, (size_t)rows * 16, hipMemcpyHostToDevice, st));
         return WLX_OK;
     };
     CKR(reset_state());

@@ -127,17 +127,29 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
                     }
                 } break;
                 case GEMM_CROSS_KV: {
+                    // TILE-PACKED cross K / V for the decode cross-attention (decoder.hip dec_cross_attn_kernel): per
+                    // (layer, item, head, 32-key tile) a 4 KiB image in MFMA operand order —
+                    //   K: [s2][kt2][lane = g*16 + c][e]  = K[key = tile*32 + s2*16 + c][dim = kt2*32 + g*8 + e]
+                    //   V: [dt][lane = g*16 + c][e]       = V[key = tile*32 + (e < 4 ? g*4 + e : 16 + g*4 + e - 4)][dim = dt*16 + c]
                     const int item = m / p.rows_per_item, t = m - item * p.rows_per_item;
                     const int l = n / (2 * p.d), nn = n - l * 2 * p.d;
-                    if (nn < p.d) {
+                    const bool isk = nn < p.d;
+                    const int da = isk ? nn : nn - p.d;
+                    const int hd = da >> 6, dd = da & 63;
+                    const int tile = t >> 5, k32 = t & 31;
+                    const long tbase = ((long)hd * (WLX_T_AUDIO_PAD / 32) + tile) * 2048;
+                    if (isk) {
+                        const int s2 = k32 >> 4, cc = k32 & 15, kt2 = dd >> 5, gg = (dd & 31) >> 3, e0 = dd & 7;
                         f16x4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                        *reinterpret_cast<f16x4*>(p.Kout + (long)l * p.kv_layer_stride_k +
-                                                  (long)item * p.kv_item_stride_k + (long)t * p.ldk + nn) = o;
+                        *reinterpret_cast<f16x4*>(p.Kout + (long)l * p.kv_layer_stride_k + (long)item * p.kv_item_stride_k + tbase +
+                                                  ((s2 * 2 + kt2) * 64 + gg * 16 + cc) * 8 + e0) = o;
                     } else {
-                        half_t* vt = p.Vt + (long)l * p.kv_layer_stride_v + (long)item * p.kv_item_stride_v +
-                                     (long)(nn - p.d) * p.ldvt + t;
+                        const int dt = dd >> 4, c0 = dd & 15;
+                        const int gg = (k32 & 15) >> 2, ee = (k32 & 3) + ((k32 >> 4) << 2);
+                        half_t* vp = p.Vt + (long)l * p.kv_layer_stride_v + (long)item * p.kv_item_stride_v + tbase +
+                                     (dt * 64 + gg * 16 + c0) * 8 + ee;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) vt[(long)r * p.ldvt] = (half_t)v[r];
+                        for (int r = 0; r < 4; ++r) vp[r * 8] = (half_t)v[r];
                     }
                 } break;
                 default: break;

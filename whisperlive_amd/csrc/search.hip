@@ -491,165 +491,132 @@ void launch_search_update(const SearchParams* sp_dev, int items, const SearchSta
 }
 
 
-// ================================================================== second generation (beam mode)
-// search_rows_kernel gives one workgroup per decoder row the whole 52 K-entry logits row: five CUs read
-// 207 KB each and then run ~25 block-wide reductions back to back (~100 us per step on MI355X). Here the row is
-// cut into SC_CHUNK-id chunks, one 256-thread workgroup per (chunk, row) — 130 workgroups for beam 5 — which apply
-// the SAME logits processors, and reduce their chunk to
-//   stats : (max, sum exp) of the text ids and of the timestamp ids, plus the raw pair for no_speech_prob,
-//   lists : the chunk's ncand best (value desc, id asc) allowed ids — and, for the one chunk that straddles
-//           timestamp_begin, a second list restricted to timestamp ids (used when the timestamp rule masks text).
-// search_merge_update_kernel (one workgroup per audio item) merges the chunk results of each beam row with
-// wave-level reductions only (one list per lane, head-pointer merge), which reproduces search_rows' candidate list,
-// and then runs search_update's bookkeeping unchanged from LDS. Sums are re-associated per chunk (fp32, fixed order:
-// deterministic), every comparison and tie-break is the same.
-
-__device__ __forceinline__ void sc_argmax_wave(float& v, int& i) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(v, o, 64);
-        const int oi = __shfl_xor(i, o, 64);
-        if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
-    }
+// ================================================================== beam mode: chunked scan + merge/update
+// search_rows_kernel gives one workgroup per decoder row the whole 52 K-entry logits row (~100 us per step on MI355X).
+// Beam mode instead cuts the row into SC_CHUNK-id chunks, one 256-thread workgroup per (chunk, row), which apply the SAME
+// logits processors and reduce their chunk to (max, sum exp) statistics and its ncand best allowed ids;
+// search_merge_update3_kernel (one workgroup per audio item) merges the chunk results per beam row and runs
+// search_update_kernel's bookkeeping. An earlier form of this pair cost 24 + 37 us per step
+// (profiles/r01e_decode_step_trace.txt): a three-level dependent load chain to rebuild the rule state from the token
+// history, ~6 block-wide reductions with a barrier each, ncand block-wide argmax rounds with a barrier each, 20 scalar
+// dependent loads per lane to fetch a candidate list, and a single-thread merge over a scratch array. Here
+//   * the rule state of a row (was the last / the one-before-last generated token a timestamp; the latest timestamp
+//     token) is carried in SearchState::rule and advanced by the merge kernel from the parent's state — no history walk
+//     (repetition penalty / no-repeat-ngram, off by default in the reference, still walk it);
+//   * reductions are DPP wave reductions; a chunk's statistics cost ONE barrier, its candidate list one more
+//     (per-wave top-ncand with no barrier, then wave 0 merges the four lists);
+//   * the merge kernel fetches lists with vector loads issued up front and merges the beams with a 16-lane argmax.
+// Candidate order, tie-breaks (value desc, id asc; beam merge: score desc, row asc, list position asc) and every rule
+// are those of search_rows_kernel / search_update_kernel; sums are re-associated per chunk exactly as in generation 2.
+__device__ __forceinline__ float s3_wave_sum(float v) { return dpp_wave_sum(v); }
+__device__ __forceinline__ float s3_wave_max(float v) { return dpp_wave_max(v); }
+// (value desc, id asc) argmax over the wave, wave-uniform result: the maximum VALUE first (6 v_max_f32_dpp), then the
+// smallest id among the lanes that hold it (6 v_min_i32_dpp) — branch-free; a compare-and-select on (value, id) pairs
+// compiles to exec-mask control flow, ~20 instructions per butterfly step
+__device__ __forceinline__ void s3_wave_argmax(float& v, int& i) {
+    const float m = dpp_wave_max(v);
+    i = dpp_wave_min_i32((v == m) ? i : 0x7fffffff);
+    v = m;
+}
+// the same over each 16-lane row separately (result in every lane of the row)
+__device__ __forceinline__ void s3_row_argmax(float& v, int& i) {
+    float m = v;
+    WLX_DPP_REDUCE_ROW("v_max_f32_dpp", m);
+    int t = (v == m) ? i : 0x7fffffff;
+    WLX_DPP_REDUCE_ROW("v_min_i32_dpp", t);
+    v = m; i = t;
 }
 
-// block top-k of w[] (ids id0 + i*SC_THREADS + tid, ascending in i), entries with id < lo are not eligible
-__device__ __forceinline__ void sc_topk(float (&w)[SC_NPT], int id0, int lo, int ncand, float* outv, int* outi,
-                                        float (*sv)[4], int (*si)[4]) {
-    const int tid = threadIdx.x;
-    float bv = WLX_NEG_INF; int bi = 0x7fffffff;
+// Chunk layout of generation 3: text ids [0, ts_begin) are cut into SC_CHUNK-id chunks from 0, timestamp ids
+// [ts_begin, V) into chunks from ts_begin, so NO chunk straddles timestamp_begin (generation 2's straddling chunk ran
+// the candidate search twice and was the critical path of the whole scan). SC_MAXCH chunks are launched; the surplus exits.
+__device__ __forceinline__ void s3_chunk(int chunk, int ts_begin, int V, int& id0, int& lim, int& nct, int& nch) {
+    nct = (ts_begin + SC_CHUNK - 1) / SC_CHUNK;
+    nch = nct + (V - ts_begin + SC_CHUNK - 1) / SC_CHUNK;
+    const bool is_ts = chunk >= nct;
+    id0 = is_ts ? ts_begin + (chunk - nct) * SC_CHUNK : chunk * SC_CHUNK;
+    lim = is_ts ? V : ts_begin;
+}
+
+__global__ __launch_bounds__(SC_THREADS) void search_scan3_kernel(const float* __restrict__ logits, long ldl, int V,
+                                                                  const SearchParams* __restrict__ spp, SearchState st WLX_TR_PARAM) {
+    const int chunk = blockIdx.x, r = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    WLX_TR_BEGIN();
+    const SearchParams sp = *spp;
+    int id0, lim, nct, nch_;
+    s3_chunk(chunk, sp.ts_begin, V, id0, lim, nct, nch_);
+    if (chunk >= nch_) return;
+    const float* lrow = logits + (long)r * ldl + id0 + tid;
+    float v[SC_NPT];
 #pragma unroll
-    for (int i = 0; i < SC_NPT; ++i) {
-        const int id = id0 + i * SC_THREADS + tid;
-        if (id < lo) w[i] = WLX_NEG_INF;
-        if (w[i] > bv) { bv = w[i]; bi = id; }
-    }
-    for (int k = 0; k < ncand; ++k) {
-        float wv = bv; int wi = bi;
-        sc_argmax_wave(wv, wi);
-        if ((tid & 63) == 0) { sv[k & 1][tid >> 6] = wv; si[k & 1][tid >> 6] = wi; }
+    for (int i = 0; i < SC_NPT; ++i) v[i] = (id0 + i * SC_THREADS + tid < lim) ? lrow[i * SC_THREADS] : WLX_NEG_INF;
+    const int item = r / sp.R;
+    const int rb = r - item * sp.R;
+    const int4 rule = *reinterpret_cast<const int4*>(st.rule + 4 * r);
+    const int p = st.pos[r], plen = st.plen[item], nsp = st.nsp_row[r];
+    if (st.item_done[item] || rb >= sp.beam) return;
+    const int ngen = p + 1 - plen;
+
+    __shared__ float fs[6][4];
+    __shared__ float wv_s[4][WLX_MAX_CAND];
+    __shared__ int wi_s[4][WLX_MAX_CAND];
+
+    // ---- repetition penalty / no-repeat-ngram (off by default in the reference): history walk, as generation 2
+    if (sp.rep_penalty != 1.0f || sp.no_repeat_ngram > 0) {
+        __shared__ int hist[WLX_T_TEXT];
+        const short* ar = st.anc + (long)r * WLX_T_TEXT;
+        for (int j = tid; j < ngen; j += SC_THREADS) hist[j] = st.intok[(long)ar[plen + j] * WLX_T_TEXT + plen + j];
         __syncthreads();
-        float gv = sv[k & 1][0]; int gi = si[k & 1][0];
-#pragma unroll
-        for (int q = 1; q < SC_THREADS / 64; ++q) {
-            const float ov = sv[k & 1][q]; const int oi = si[k & 1][q];
-            if (ov > gv || (ov == gv && oi < gi)) { gv = ov; gi = oi; }
-        }
-        if (tid == 0) { outv[k] = gv; outi[k] = gi; }
-        if (gi != 0x7fffffff && ((gi - id0) & (SC_THREADS - 1)) == tid) {
-            bv = WLX_NEG_INF; bi = 0x7fffffff;
+        if (sp.rep_penalty != 1.0f) {
 #pragma unroll
             for (int i = 0; i < SC_NPT; ++i) {
                 const int id = id0 + i * SC_THREADS + tid;
-                if (id == gi) w[i] = WLX_NEG_INF;
-                if (w[i] > bv) { bv = w[i]; bi = id; }
+                bool hit = false;
+                for (int j = 0; j < ngen; ++j) hit = hit || (hist[j] == id);
+                if (hit && id < lim) v[i] = (v[i] < 0.f) ? v[i] * sp.rep_penalty : v[i] / sp.rep_penalty;
+            }
+        }
+        if (sp.no_repeat_ngram > 0 && ngen >= sp.no_repeat_ngram - 1) {
+            const int n = sp.no_repeat_ngram;
+            for (int j = 0; j + n - 1 < ngen; ++j) {
+                bool match = true;
+                for (int q = 0; q < n - 1; ++q) match = match && (hist[j + q] == hist[ngen - (n - 1) + q]);
+                if (match) {
+                    const int banned = hist[j + n - 1];
+#pragma unroll
+                    for (int i = 0; i < SC_NPT; ++i)
+                        if (id0 + i * SC_THREADS + tid == banned) v[i] = WLX_NEG_INF;
+                }
             }
         }
     }
-}
-
-__global__ __launch_bounds__(SC_THREADS) void search_scan_kernel(const float* __restrict__ logits, long ldl, int V,
-                                                                 const SearchParams* __restrict__ spp, SearchState st WLX_TR_PARAM) {
-    const int chunk = blockIdx.x, r = blockIdx.y, tid = threadIdx.x;
-    const int id0 = chunk * SC_CHUNK;
-    WLX_TR_BEGIN();
-    // the row slice first: its loads are in flight while the rule state is derived
-    const float* lrow = logits + (long)r * ldl;
-    float v[SC_NPT];
-#pragma unroll
-    for (int i = 0; i < SC_NPT; ++i) {
-        const int id = id0 + i * SC_THREADS + tid;
-        v[i] = (id < V) ? lrow[id] : WLX_NEG_INF;
-    }
-    // (no done test: the scan only writes its own scratch; search_merge_update_kernel holds the gate)
-    const SearchParams sp = *spp;
-    const int item = r / sp.R;
-    const int rb = r - item * sp.R;
-    if (st.item_done[item] || rb >= sp.beam) return;
-
-    __shared__ int hist[WLX_T_TEXT];
-    __shared__ int last_ts_idx;
-    __shared__ float fs[3][4];
-    __shared__ float sv[2][4];
-    __shared__ int si[2][4];
-
-    const int p = st.pos[r];
-    const int plen = st.plen[item];
-    const int ngen = p + 1 - plen;
-    const short* ar = st.anc + (long)r * WLX_T_TEXT;
-    if (tid == 0) last_ts_idx = -1;
-    __syncthreads();
-    for (int j = tid; j < ngen; j += SC_THREADS) {
-        const int tk = st.intok[(long)ar[plen + j] * WLX_T_TEXT + plen + j];
-        hist[j] = tk;
-        if (tk >= sp.ts_begin) atomicMax(&last_ts_idx, j);
-    }
-    __syncthreads();
     WLX_TR_MARK(1);
-    const int wv_ = tid >> 6;
 
-    // ---- raw (max, sum exp) of the chunk for no_speech_prob at the sot position
+    // ---- raw (max, sum exp) for no_speech_prob, BEFORE any rule
     float raw_m = WLX_NEG_INF, raw_s = 0.f;
-    if (st.nsp_row[r] > 0) {
-        float mx = WLX_NEG_INF;
+    if (nsp > 0) {
+        float mx = v[0];
 #pragma unroll
-        for (int i = 0; i < SC_NPT; ++i) mx = fmaxf(mx, v[i]);
-        mx = wave_max(mx);
-        if ((tid & 63) == 0) fs[0][wv_] = mx;
-        __syncthreads();
-        raw_m = fmaxf(fmaxf(fs[0][0], fs[0][1]), fmaxf(fs[0][2], fs[0][3]));
-        float sm = 0.f;
-        if (raw_m > WLX_NEG_INF) {
-#pragma unroll
-            for (int i = 0; i < SC_NPT; ++i) sm += __expf(v[i] - raw_m);
-        }
-        sm = wave_sum(sm);
-        if ((tid & 63) == 0) fs[1][wv_] = sm;
-        __syncthreads();
-        raw_s = fs[1][0] + fs[1][1] + fs[1][2] + fs[1][3];
-        __syncthreads();
+        for (int i = 1; i < SC_NPT; ++i) mx = fmaxf(mx, v[i]);
+        raw_m = mx;                       // per-thread max; reduced together with the rule statistics below
     }
+    const float raw_local = raw_m;
 
-    // ---- repetition penalty / no-repeat-ngram (off by default in the reference): direct history scans
-    if (sp.rep_penalty != 1.0f) {
-#pragma unroll
-        for (int i = 0; i < SC_NPT; ++i) {
-            const int id = id0 + i * SC_THREADS + tid;
-            bool hit = false;
-            for (int j = 0; j < ngen; ++j) hit = hit || (hist[j] == id);
-            if (hit && id < V) v[i] = (v[i] < 0.f) ? v[i] * sp.rep_penalty : v[i] / sp.rep_penalty;
-        }
-    }
-    if (sp.no_repeat_ngram > 0 && ngen >= sp.no_repeat_ngram - 1) {
-        const int n = sp.no_repeat_ngram;
-        for (int j = 0; j + n - 1 < ngen; ++j) {
-            bool match = true;
-            for (int q = 0; q < n - 1; ++q) match = match && (hist[j + q] == hist[ngen - (n - 1) + q]);
-            if (match) {
-                const int banned = hist[j + n - 1];
-#pragma unroll
-                for (int i = 0; i < SC_NPT; ++i)
-                    if (id0 + i * SC_THREADS + tid == banned) v[i] = WLX_NEG_INF;
-            }
-        }
-    }
-
-    // ---- static suppressions + timestamp rules (identical to search_rows_kernel)
+    // ---- static suppressions + timestamp rules from the carried rule state
     const bool ts = sp.apply_ts_rules != 0;
-    const bool last_was_ts = ts && ngen >= 1 && hist[ngen - 1] >= sp.ts_begin;
-    const bool penult_was_ts = ts && (ngen < 2 || hist[ngen - 2] >= sp.ts_begin);
-    int ts_last = -1;  // timestamps in [ts_begin, ts_last) are forbidden
-    if (ts && last_ts_idx >= 0) {
-        const int lt = hist[last_ts_idx];
-        ts_last = (last_was_ts && !penult_was_ts) ? lt : lt + 1;
-    }
+    const bool last_was_ts = ts && rule.x != 0;
+    const bool penult_was_ts = ts && rule.y != 0;
+    int ts_last = -1;                     // timestamps in [ts_begin, ts_last) are forbidden
+    if (ts && rule.z >= 0) ts_last = (last_was_ts && !penult_was_ts) ? rule.z : rule.z + 1;
     const bool first = (ngen == 0);
     const int last_allowed = (sp.max_initial_ts >= 0) ? sp.ts_begin + sp.max_initial_ts : 0x7fffffff;
+    float w[SC_NPT];
 #pragma unroll
     for (int i = 0; i < SC_NPT; ++i) {
         const int id = id0 + i * SC_THREADS + tid;
-        if (id >= V) continue;
-        bool kill = (sp.suppress_mask[id >> 5] >> (id & 31)) & 1u;
+        bool kill = id >= lim;
+        if (!kill) kill = (sp.suppress_mask[id >> 5] >> (id & 31)) & 1u;
         if (first && sp.suppress_blank && (id == sp.blank || id == sp.eot)) kill = true;
         if (ts) {
             if (id == sp.no_timestamps) kill = true;
@@ -663,119 +630,167 @@ __global__ __launch_bounds__(SC_THREADS) void search_scan_kernel(const float* __
                 if (id > last_allowed) kill = true;
             }
         }
-        if (kill) v[i] = WLX_NEG_INF;
+        w[i] = kill ? WLX_NEG_INF : v[i];
     }
 
-    // ---- chunk statistics: text ids [0, ts_begin) and timestamp ids [ts_begin, V)
-    float mx_text = WLX_NEG_INF, mx_ts = WLX_NEG_INF;
+    // ---- chunk statistics (a chunk is all text or all timestamps), one barrier: maximum first (wave DPP), then the sum
+    const bool ts_chunk = chunk >= nct;
+    float mx = w[0];
+#pragma unroll
+    for (int i = 1; i < SC_NPT; ++i) mx = fmaxf(mx, w[i]);
+    mx = s3_wave_max(mx);
+    const float raw_wm = (nsp > 0) ? s3_wave_max(raw_local) : WLX_NEG_INF;
+    if (lane == 0) { fs[0][wave] = mx; fs[2][wave] = raw_wm; }
+    __syncthreads();
+    mx = fmaxf(fmaxf(fs[0][0], fs[0][1]), fmaxf(fs[0][2], fs[0][3]));
+    raw_m = fmaxf(fmaxf(fs[2][0], fs[2][1]), fmaxf(fs[2][2], fs[2][3]));
+    float sm = 0.f;
 #pragma unroll
     for (int i = 0; i < SC_NPT; ++i) {
-        const int id = id0 + i * SC_THREADS + tid;
-        if (id < sp.ts_begin) mx_text = fmaxf(mx_text, v[i]);
-        else mx_ts = fmaxf(mx_ts, v[i]);
+        if (mx > WLX_NEG_INF) sm += __expf(w[i] - mx);
+        if (nsp > 0 && raw_m > WLX_NEG_INF) raw_s += __expf(v[i] - raw_m);
     }
-    mx_text = wave_max(mx_text);
-    mx_ts = wave_max(mx_ts);
-    if ((tid & 63) == 0) { fs[0][wv_] = mx_text; fs[1][wv_] = mx_ts; }
-    __syncthreads();
-    mx_text = fmaxf(fmaxf(fs[0][0], fs[0][1]), fmaxf(fs[0][2], fs[0][3]));
-    mx_ts = fmaxf(fmaxf(fs[1][0], fs[1][1]), fmaxf(fs[1][2], fs[1][3]));
-    __syncthreads();
-    float s_text = 0.f, s_ts = 0.f;
-#pragma unroll
-    for (int i = 0; i < SC_NPT; ++i) {
-        const int id = id0 + i * SC_THREADS + tid;
-        if (id < sp.ts_begin) { if (mx_text > WLX_NEG_INF) s_text += __expf(v[i] - mx_text); }
-        else if (id < V) { if (mx_ts > WLX_NEG_INF) s_ts += __expf(v[i] - mx_ts); }
-    }
-    s_text = wave_sum(s_text);
-    s_ts = wave_sum(s_ts);
-    if ((tid & 63) == 0) { fs[0][wv_] = s_text; fs[1][wv_] = s_ts; }
-    __syncthreads();
-    s_text = fs[0][0] + fs[0][1] + fs[0][2] + fs[0][3];
-    s_ts = fs[1][0] + fs[1][1] + fs[1][2] + fs[1][3];
-    if (tid == 0) {
-        float* so = st.scan_stats + ((long)r * SC_MAXCH + chunk) * SC_NSTAT;
-        so[0] = mx_text; so[1] = s_text; so[2] = mx_ts; so[3] = s_ts; so[4] = raw_m; so[5] = raw_s;
-    }
-
+    sm = s3_wave_sum(sm);
+    if (nsp > 0) raw_s = s3_wave_sum(raw_s);
+    if (lane == 0) { fs[3][wave] = sm; fs[5][wave] = raw_s; }
     WLX_TR_MARK(2);
-    // ---- candidate lists
-    const int hi = (id0 + SC_CHUNK < V) ? id0 + SC_CHUNK : V;
-    const bool mixed = ts && id0 < sp.ts_begin && sp.ts_begin < hi;
-    float w[SC_NPT];
+
+    // ---- candidate lists: each wave's top-ncand (no barrier), then wave 0 (and wave 1 for the timestamp-only list of
+    // the chunk that straddles timestamp_begin) merges the four wave lists
+    float* cv = st.scan_cv + ((long)r * (SC_MAXCH + 1) + chunk) * WLX_MAX_CAND;
+    int* ci = st.scan_ci + ((long)r * (SC_MAXCH + 1) + chunk) * WLX_MAX_CAND;
+    {
+        float bv = WLX_NEG_INF; int bi = 0x7fffffff;
 #pragma unroll
-    for (int i = 0; i < SC_NPT; ++i) w[i] = v[i];
-    sc_topk(w, id0, 0, sp.ncand, st.scan_cv + ((long)r * (SC_MAXCH + 1) + chunk) * WLX_MAX_CAND,
-            st.scan_ci + ((long)r * (SC_MAXCH + 1) + chunk) * WLX_MAX_CAND, sv, si);
-    WLX_TR_MARK(3);
-    if (mixed) {
+        for (int i = 0; i < SC_NPT; ++i) {
+            const int id = id0 + i * SC_THREADS + tid;
+            if (w[i] > bv) { bv = w[i]; bi = id; }        // ids ascend with i: first max = smallest id
+        }
+#pragma unroll 1
+        for (int k = 0; k < sp.ncand; ++k) {
+            float gv = bv; int gi = bi;
+            s3_wave_argmax(gv, gi);
+            if (lane == 0) { wv_s[wave][k] = gv; wi_s[wave][k] = gi; }
+            if (gi != 0x7fffffff && ((gi - id0) & (SC_THREADS - 1)) == tid) {
+                bv = WLX_NEG_INF; bi = 0x7fffffff;
+#pragma unroll
+                for (int i = 0; i < SC_NPT; ++i) {
+                    const int id = id0 + i * SC_THREADS + tid;
+                    if (id == gi) w[i] = WLX_NEG_INF;
+                    if (w[i] > bv) { bv = w[i]; bi = id; }
+                }
+            }
+        }
         __syncthreads();
-#pragma unroll
-        for (int i = 0; i < SC_NPT; ++i) w[i] = v[i];
-        sc_topk(w, id0, sp.ts_begin, sp.ncand, st.scan_cv + ((long)r * (SC_MAXCH + 1) + SC_MAXCH) * WLX_MAX_CAND,
-                st.scan_ci + ((long)r * (SC_MAXCH + 1) + SC_MAXCH) * WLX_MAX_CAND, sv, si);
+        if (wave == 0) {
+            if (lane == 0) {
+                float* so = st.scan_stats + ((long)r * SC_MAXCH + chunk) * SC_NSTAT;
+                const float ssum = fs[3][0] + fs[3][1] + fs[3][2] + fs[3][3];
+                so[0] = ts_chunk ? WLX_NEG_INF : mx; so[1] = ts_chunk ? 0.f : ssum;
+                so[2] = ts_chunk ? mx : WLX_NEG_INF; so[3] = ts_chunk ? ssum : 0.f;
+                so[4] = raw_m;   so[5] = fs[5][0] + fs[5][1] + fs[5][2] + fs[5][3];
+            }
+            // merge the four wave lists: <= 4 * ncand <= 128 candidates, two per lane, knock-out rounds (no rescans, no LDS)
+            const int nc = sp.ncand;
+            const int e0 = lane, e1 = lane + 64;
+            float x0 = WLX_NEG_INF, x1 = WLX_NEG_INF; int i0 = 0x7fffffff, i1 = 0x7fffffff;
+            if (e0 < 4 * nc) { const int q = e0 / nc, k = e0 - q * nc; x0 = wv_s[q][k]; i0 = wi_s[q][k]; }
+            if (e1 < 4 * nc) { const int q = e1 / nc, k = e1 - q * nc; x1 = wv_s[q][k]; i1 = wi_s[q][k]; }
+#pragma unroll 1
+            for (int k = 0; k < nc; ++k) {
+                const bool f1 = (x1 > x0) || (x1 == x0 && i1 < i0);
+                float gv = f1 ? x1 : x0; int gi = f1 ? i1 : i0;
+                s3_wave_argmax(gv, gi);
+                if (lane == 0) { cv[k] = gv; ci[k] = gi; }
+                if (gi != 0x7fffffff) {
+                    if (i0 == gi) { x0 = WLX_NEG_INF; i0 = 0x7fffffff; }
+                    if (i1 == gi) { x1 = WLX_NEG_INF; i1 = 0x7fffffff; }
+                }
+            }
+        }
     }
+    WLX_TR_MARK(3);
     WLX_TR_END(trc);
 }
 
-void launch_search_scan(const float* logits, long ldl, int V, const SearchParams* sp_dev, int rows, const SearchState& st,
-                        hipStream_t s) {
-    const int nch = (V + SC_CHUNK - 1) / SC_CHUNK;
-    hipLaunchKernelGGL(search_scan_kernel, dim3(nch, rows), dim3(SC_THREADS), 0, s, logits, ldl, V, sp_dev, st WLX_TR_ARG("search_scan"));
+void launch_search_scan3(const float* logits, long ldl, int V, const SearchParams* sp_dev, int rows, const SearchState& st,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(search_scan3_kernel, dim3(SC_MAXCH, rows), dim3(SC_THREADS), 0, s, logits, ldl, V, sp_dev, st WLX_TR_ARG("search_scan3"));
 }
 
-__global__ __launch_bounds__(256) void search_merge_update_kernel(const float* __restrict__ logits, long ldl, int V,
-                                                                  const SearchParams* __restrict__ spp, SearchState st WLX_TR_PARAM) {
+#define MU3_THREADS 384
+__global__ __launch_bounds__(MU3_THREADS) void search_merge_update3_kernel(const float* __restrict__ logits, long ldl, int V,
+                                                                           const SearchParams* __restrict__ spp, SearchState st WLX_TR_PARAM) {
     if (*st.done) return;
     WLX_TR_BEGIN();
     const SearchParams sp = *spp;
     const int item = blockIdx.x;
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (item == 0 && tid == 0) atomicAdd(st.step, 1);
     if (st.item_done[item]) return;
     const int r0 = item * sp.R;
     const int plen = st.plen[item];
-    const int nch = (V + SC_CHUNK - 1) / SC_CHUNK;
+    int id0_, lim_, nct, nch;
+    s3_chunk(0, sp.ts_begin, V, id0_, lim_, nct, nch);
+    constexpr int NW = MU3_THREADS / 64;
 
     __shared__ float cand_s[16][WLX_MAX_CAND];
     __shared__ int cand_t[16][WLX_MAX_CAND];
-    __shared__ float lv[4][SC_MAXCH + 1][WLX_MAX_CAND];
-    __shared__ int li[4][SC_MAXCH + 1][WLX_MAX_CAND];
+    __shared__ float lv[NW][SC_MAXCH + 1][WLX_MAX_CAND];
+    __shared__ int li[NW][SC_MAXCH + 1][WLX_MAX_CAND];
     __shared__ short anc_s[16 * WLX_T_TEXT];     // staged ancestry rows of this item (R <= 16)
     __shared__ int parent[16], newtok[16];
     __shared__ float newcum[16];
     __shared__ int hyp_src[16], hyp_extra[16], hyp_slot[16], hyp_n;
     __shared__ int n_active_s, finished_s;
+    __shared__ int ord_b[WLX_MAX_CAND], ord_t[WLX_MAX_CAND];
+    __shared__ float ord_s[WLX_MAX_CAND];
+    __shared__ int4 rule_old[16];
 
-    // ---------------- phase 1: per beam row, merge the chunk results into the row's ncand best continuations
+    // the item's ancestry rows (old state) and rule state: requested first, used last
+    const int p = st.pos[r0];
+    for (int i = tid; i < sp.beam * (p + 1); i += MU3_THREADS) {
+        const int b = i / (p + 1), q = i - b * (p + 1);
+        anc_s[b * WLX_T_TEXT + q] = st.anc[(long)(r0 + b) * WLX_T_TEXT + q];
+    }
+    if (tid < sp.beam) rule_old[tid] = *reinterpret_cast<const int4*>(st.rule + 4 * (r0 + tid));
+
+    // ---------------- phase 1: per beam row (one wave each), merge the chunk results into the row's ncand best
     const bool ts = sp.apply_ts_rules != 0;
-    const int cmix = (ts && sp.ts_begin < V && (sp.ts_begin % SC_CHUNK) != 0) ? sp.ts_begin / SC_CHUNK : -1;
-    for (int rb = wave; rb < sp.beam; rb += 4) {
+    const int nc4 = (sp.ncand + 3) >> 2;
+#pragma unroll 1
+    for (int rb = wave; rb < sp.beam; rb += NW) {
         const int r = r0 + rb;
-        float mt = WLX_NEG_INF, st_ = 0.f, mts = WLX_NEG_INF, sts = 0.f, rm = WLX_NEG_INF, rs = 0.f;
+        float4 s0 = make_float4(WLX_NEG_INF, 0.f, WLX_NEG_INF, 0.f), s1 = make_float4(WLX_NEG_INF, 0.f, 0.f, 0.f);
         if (lane < nch) {
-            const float* so = st.scan_stats + ((long)r * SC_MAXCH + lane) * SC_NSTAT;
-            mt = so[0]; st_ = so[1]; mts = so[2]; sts = so[3]; rm = so[4]; rs = so[5];
+            const float4* so = reinterpret_cast<const float4*>(st.scan_stats + ((long)r * SC_MAXCH + lane) * SC_NSTAT);
+            s0 = so[0]; s1 = so[1];
         }
-        // this lane's candidate list -> LDS (requested before the reductions below)
-        if (lane <= nch) {
-            const int src = (lane < nch) ? lane : SC_MAXCH;
-            const float* cv = st.scan_cv + ((long)r * (SC_MAXCH + 1) + src) * WLX_MAX_CAND;
-            const int* ci = st.scan_ci + ((long)r * (SC_MAXCH + 1) + src) * WLX_MAX_CAND;
-            const bool have = (lane < nch) || (cmix >= 0);
-            for (int k = 0; k < sp.ncand; ++k) {
-                lv[wave][lane][k] = have ? cv[k] : WLX_NEG_INF;
-                li[wave][lane][k] = have ? ci[k] : 0x7fffffff;
-            }
+        const bool have = lane < nch;
+        if (lane < nch) {
+            const int src = lane;
+            const float4* cv = reinterpret_cast<const float4*>(st.scan_cv + ((long)r * (SC_MAXCH + 1) + src) * WLX_MAX_CAND);
+            const int4* ci = reinterpret_cast<const int4*>(st.scan_ci + ((long)r * (SC_MAXCH + 1) + src) * WLX_MAX_CAND);
+            float4 a[WLX_MAX_CAND / 4]; int4 b[WLX_MAX_CAND / 4];
+#pragma unroll
+            for (int k = 0; k < WLX_MAX_CAND / 4; ++k)
+                if (k < nc4) { a[k] = cv[k]; b[k] = ci[k]; }
+#pragma unroll
+            for (int k = 0; k < WLX_MAX_CAND / 4; ++k)
+                if (k < nc4) {
+                    *reinterpret_cast<float4*>(&lv[wave][lane][4 * k]) = have ? a[k] : make_float4(WLX_NEG_INF, WLX_NEG_INF, WLX_NEG_INF, WLX_NEG_INF);
+                    *reinterpret_cast<int4*>(&li[wave][lane][4 * k]) = have ? b[k] : make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);
+                }
         }
-        const float Mtext = wave_max(mt), Mts = wave_max(mts);
+        const float mt = s0.x, st_ = s0.y, mts = s0.z, sts = s0.w, rm = s1.x, rs = s1.y;
+        const float Mtext = s3_wave_max(mt), Mts = s3_wave_max(mts);
         if (st.nsp_row[r] > 0) {
-            const float RM = wave_max(rm);
-            const float RS = wave_sum((rm > WLX_NEG_INF) ? rs * __expf(rm - RM) : 0.f);
+            const float RM = s3_wave_max(rm);
+            const float RS = s3_wave_sum((rm > WLX_NEG_INF) ? rs * __expf(rm - RM) : 0.f);
             if (lane == 0) st.no_speech[item] = __expf(logits[(long)r * ldl + sp.no_speech] - RM) / RS;
         }
-        const float S_ts = wave_sum((mts > WLX_NEG_INF) ? sts * __expf(mts - Mts) : 0.f);
+        const float S_ts = s3_wave_sum((mts > WLX_NEG_INF) ? sts * __expf(mts - Mts) : 0.f);
         const float lse_ts = (Mts > WLX_NEG_INF) ? Mts + __logf(S_ts) : WLX_NEG_INF;
         const bool text_masked = ts && (lse_ts > Mtext);
         float lse_sel;
@@ -785,24 +800,17 @@ __global__ __launch_bounds__(256) void search_merge_update_kernel(const float* _
             const float mx_all = fmaxf(Mtext, Mts);
             const float a = ((mt > WLX_NEG_INF) ? st_ * __expf(mt - mx_all) : 0.f) +
                             ((mts > WLX_NEG_INF) ? sts * __expf(mts - mx_all) : 0.f);
-            lse_sel = mx_all + __logf(wave_sum(a));
+            lse_sel = mx_all + __logf(s3_wave_sum(a));
         }
-        // which lists may contribute: all ids -> the nch "all" lists; timestamps only -> pure-timestamp chunks and
-        // the straddling chunk's timestamp list (slot nch)
-        bool usable = false;
-        if (lane < nch) {
-            if (!text_masked) usable = true;
-            else usable = ((long)lane * SC_CHUNK >= sp.ts_begin);
-        } else if (lane == nch) {
-            usable = text_masked && cmix >= 0;
-        }
+        const bool usable = (lane < nch) && (!text_masked || lane >= nct);   // timestamps only: the timestamp chunks
         const float base = st.cum[r] - lse_sel;
         int hp = 0;
         float hv = usable ? lv[wave][lane][0] : WLX_NEG_INF;
         int hi = usable ? li[wave][lane][0] : 0x7fffffff;
+#pragma unroll 1
         for (int k = 0; k < sp.ncand; ++k) {
             float gv = hv; int gi = hi;
-            sc_argmax_wave(gv, gi);
+            s3_wave_argmax(gv, gi);
             if (lane == 0) {
                 cand_s[rb][k] = (gi < V) ? gv + base : WLX_NEG_INF;
                 cand_t[rb][k] = (gi < V) ? gi : sp.eot;   // row fully masked
@@ -817,28 +825,36 @@ __global__ __launch_bounds__(256) void search_merge_update_kernel(const float* _
     __syncthreads();
     WLX_TR_MARK(1);
 
-    // ---------------- phase 2: search_update_kernel's beam bookkeeping, candidates read from LDS
-    const int p = st.pos[r0];
+    // ---------------- phase 2: merge the beams' sorted lists (score desc, row asc, list position asc) into ord_*
     const int ngen = p + 1 - plen;
     const int max_new = sp.max_length - plen;
     const bool is_last = (ngen + 1 >= max_new);
+    if (wave == 0) {
+        // lane b < beam (<= 16: one DPP row) owns row b's sorted list; round winner = (score desc, b asc), which is the
+        // serial scan's strict '>' over ascending b. A lane with nothing left ranks below every real entry, including
+        // a real -inf score: it ties on value and loses on b.
+        const int b = lane;
+        const bool own = b < sp.beam;
+        int hp = 0;
+#pragma unroll 1
+        for (int k = 0; k < sp.ncand; ++k) {
+            const bool alive = own && hp < sp.ncand;
+            float kv = alive ? cand_s[b][hp] : WLX_NEG_INF;
+            int kb = alive ? b : 0x7fffffff;
+            s3_row_argmax(kv, kb);
+            if (lane == 0) ord_b[k] = (kb == 0x7fffffff) ? -1 : kb;
+            if (alive && b == kb) { ord_s[k] = cand_s[b][hp]; ord_t[k] = cand_t[b][hp]; ++hp; }
+        }
+    }
+    __syncthreads();
     if (tid == 0) {
-        bool used[16 * WLX_MAX_CAND];
-        for (int i = 0; i < sp.beam * sp.ncand; ++i) used[i] = false;
         int n_active = 0, nh_new = 0, n_hyp = st.n_hyp[item];
         bool top_beam_finished = false;
         for (int k = 0; k < sp.ncand; ++k) {
-            float bs = WLX_NEG_INF; int bb = -1, bj = -1;
-            for (int b = 0; b < sp.beam; ++b)
-                for (int j = 0; j < sp.ncand; ++j) {
-                    if (used[b * sp.ncand + j]) continue;
-                    const float sc = cand_s[b][j];
-                    if (bb < 0 || sc > bs) { bs = sc; bb = b; bj = j; }
-                    break;  // each row's list is sorted: only its first unused entry can win
-                }
+            const int bb = ord_b[k];
             if (bb < 0) break;
-            used[bb * sp.ncand + bj] = true;
-            const int tok = cand_t[bb][bj];
+            const float bs = ord_s[k];
+            const int tok = ord_t[k];
             if (tok == sp.eot || is_last) {
                 if (k >= sp.beam) continue;
                 if (n_hyp + nh_new < WLX_MAX_HYP && nh_new < 16) {
@@ -867,17 +883,12 @@ __global__ __launch_bounds__(256) void search_merge_update_kernel(const float* _
         else fin = fin || (n_hyp >= sp.max_cand_hyp);
         finished_s = fin ? 1 : 0;
     }
-    // stage the item's ancestry rows (old state) in LDS while thread 0 merges
-    for (int i = tid; i < sp.beam * (p + 1); i += 256) {
-        const int b = i / (p + 1), q = i - b * (p + 1);
-        anc_s[b * WLX_T_TEXT + q] = st.anc[(long)(r0 + b) * WLX_T_TEXT + q];
-    }
     __syncthreads();
     WLX_TR_MARK(2);
     for (int hh = 0; hh < hyp_n; ++hh) {
         const int b = hyp_src[hh];
         int* dst = st.hyp_tokens + ((long)item * WLX_MAX_HYP + hyp_slot[hh]) * WLX_T_TEXT;
-        for (int j = tid; j < ngen; j += 256)
+        for (int j = tid; j < ngen; j += MU3_THREADS)
             dst[j] = st.intok[(long)anc_s[b * WLX_T_TEXT + plen + j] * WLX_T_TEXT + plen + j];
         if (tid == 0 && hyp_extra[hh] >= 0) dst[ngen] = hyp_extra[hh];
     }
@@ -890,24 +901,34 @@ __global__ __launch_bounds__(256) void search_merge_update_kernel(const float* _
         return;
     }
     const int na = n_active_s;
-    for (int i = tid; i < na * (p + 1); i += 256) {
+    for (int i = tid; i < na * (p + 1); i += MU3_THREADS) {
         const int j = i / (p + 1), q = i - j * (p + 1);
         st.anc[(long)(r0 + j) * WLX_T_TEXT + q] = anc_s[parent[j] * WLX_T_TEXT + q];
     }
     if (tid < sp.beam) {
         const int j = tid;
         st.anc[(long)(r0 + j) * WLX_T_TEXT + p + 1] = (short)(r0 + j);
-        if (j < na) { st.token[r0 + j] = newtok[j]; st.cum[r0 + j] = newcum[j]; }
-        else { st.token[r0 + j] = sp.eot; st.cum[r0 + j] = WLX_NEG_INF; }
+        int4 ru = make_int4(0, 1, -1, 0);
+        if (j < na) {
+            const int tok = newtok[j];
+            const int4 po = rule_old[parent[j]];
+            const int is_ts = tok >= sp.ts_begin ? 1 : 0;
+            // after this token: last = it; one-before-last = the parent's last (none yet when this is the first token)
+            ru.x = is_ts;
+            ru.y = (ngen + 1 < 2) ? 1 : po.x;
+            ru.z = is_ts ? tok : po.z;
+            st.token[r0 + j] = tok; st.cum[r0 + j] = newcum[j];
+        } else { st.token[r0 + j] = sp.eot; st.cum[r0 + j] = WLX_NEG_INF; }
+        *reinterpret_cast<int4*>(st.rule + 4 * (r0 + j)) = ru;
         st.pos[r0 + j] = p + 1;
         st.nsp_row[r0 + j] = 0;
     }
     WLX_TR_END(trc);
 }
 
-void launch_search_merge_update(const float* logits, long ldl, int V, const SearchParams* sp_dev, int items,
-                                const SearchState& st, hipStream_t s) {
-    hipLaunchKernelGGL(search_merge_update_kernel, dim3(items), dim3(256), 0, s, logits, ldl, V, sp_dev, st WLX_TR_ARG("search_merge_update"));
+void launch_search_merge_update3(const float* logits, long ldl, int V, const SearchParams* sp_dev, int items,
+                                 const SearchState& st, hipStream_t s) {
+    hipLaunchKernelGGL(search_merge_update3_kernel, dim3(items), dim3(MU3_THREADS), 0, s, logits, ldl, V, sp_dev, st WLX_TR_ARG("search_merge_update3"));
 }
 
 // ------------------------------------------------------------------ small softmax helpers
