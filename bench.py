@@ -93,6 +93,12 @@ def main():
     ap.add_argument("--decode-steps", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-decode-steps", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=1,
+                    help="windows per step batched into ONE decode (batch_inference.py's batched mode on one GPU): "
+                         "one slot, B items, encoder and every decode step shared by the B x 5 beam rows")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="concurrent streams on this GPU (BASELINE configs[2] = 4): one engine, one slot + HIP stream + "
+                         "host thread per stream, the same step each; value = aggregate over streams")
     args = ap.parse_args()
 
     import torch
@@ -118,20 +124,39 @@ def main():
     spec = get_spec(args.model)
     weights = random_weights(spec, seed=0)
     eng = HipWhisperEngine(spec, weights, device=local)
-    slot = eng.create_slot(1, 5)
+    S = max(1, args.streams)
+    B = max(1, args.batch)
+    slots = [eng.create_slot(B, 5) for _ in range(S)]
+    slot = slots[0]
     ids = token_ids(spec.vocab)
     eids = TokenIds(**ids)
     pcm = olm.speech_like_pcm(WINDOW_S, seed=1234 + rank)
     gen_kw = dict(beam_size=5, patience=1.0, max_length=1 + args.decode_steps, suppress_tokens=suppress_list(ids, True))
 
-    slot.pcm_put(pcm)     # inputs resident in HBM before the timed region
+    for i, sl in enumerate(slots):     # inputs resident in HBM before the timed region
+        for b in range(B):
+            sl.pcm_put(pcm if (i == 0 and b == 0) else olm.speech_like_pcm(WINDOW_S, seed=1234 + rank + 100 * i + b), b)
 
-    def step():
+    def step_on(sl):
         t0 = time.perf_counter()
-        T = slot.logmel_resident()
-        slot.encode(1, seek=[0], seg=[min(T - 1, 3000)])
-        r = slot.generate([[ids["sot"]]], eids, **gen_kw)[0]
+        Ts = [sl.logmel_resident(b) for b in range(B)]
+        sl.encode(B, seek=[0] * B, seg=[min(T - 1, 3000) for T in Ts])
+        r = sl.generate([[ids["sot"]]] * B, eids, **gen_kw)[0]
         return time.perf_counter() - t0, r
+
+    if S == 1:
+        def step():
+            return step_on(slot)
+    else:
+        # one host thread per stream (the reference runs one thread per client, faster_whisper_backend.py:121); ctypes
+        # releases the GIL for the duration of every engine call, the slots' HIP streams overlap on the GPU
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=S)
+
+        def step():
+            t0 = time.perf_counter()
+            res = list(pool.map(step_on, slots))
+            return time.perf_counter() - t0, res[0][1]
 
     for _ in range(args.warmup):
         step()
@@ -166,7 +191,7 @@ def main():
     out = None
     if rank == 0:
         n_tok = len(last.sequences_ids[0])
-        xrt = world * args.steps * WINDOW_S / wall
+        xrt = world * S * B * args.steps * WINDOW_S / wall
         # ---- roofline of the dominant kernel, HIP-event timed inside the engine on the slot stream
         prof = slot.debug_profile_step(rows=5, t=1 + args.decode_steps // 2, iters=20)
         dom = max(prof, key=lambda k: k["total_us"])
@@ -189,10 +214,10 @@ def main():
             "ms_per_step": 1000.0 * wall / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16 (MFMA operands; f32 accumulate, f32 residual stream, f32 log-mel)", "data": "synthetic",
             "p50_chunk_latency_ms": 1000.0 * float(np.median(lat)),
-            "config": {"workload": f"configs[1]: Whisper-{args.model}, 1 stream per GPU, one 30 s window per step "
+            "config": {"workload": f"configs[{1 if S == 1 else 2}]: Whisper-{args.model}, {S} stream{'s' if S > 1 else ''} per GPU, one 30 s window per stream per step "
                                    f"(480000 samples 16 kHz f32 resident in HBM -> log-mel -> encoder -> beam-5 decode, "
                                    f"{n_tok} generated tokens forced by suppressing EOT), seeded random weights",
-                       "streams_per_gpu": 1, "beam_size": 5, "decode_steps": n_tok, "window_s": WINDOW_S},
+                       "streams_per_gpu": S, "batch_per_stream": B, "beam_size": 5, "decode_steps": n_tok, "window_s": WINDOW_S},
             "stage_ms": stage,
             "decode_step": {"graph_replay_ms": step_graph_ms, "sum_kernel_us": step_us, "algorithmic_bytes": sb,
                             "hbm_frac_of_peak": sb / (step_graph_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -202,7 +227,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, weights, pcm, ids, args.cpu_decode_steps, n_tok,
                                                threads=min(16, os.cpu_count() or 1))
-    slot.close()
+    for sl in slots:
+        sl.close()
     eng.close()
     if dist is not None:
         dist.barrier()

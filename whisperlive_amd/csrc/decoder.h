@@ -87,6 +87,7 @@ void launch_dec_cross_attn(const half_t* q, long ldq, const half_t* Kp, const ha
 struct SearchState {            // device pointers, one set per slot
     int* step;                  // [1] decode step counter
     int* done;                  // [1] all items finished
+    int* done_host;             // pinned host word raised together with `done` (the host polls it; no per-step copy)
     int* n_finished;            // [1]
     int* item_done;             // [items]
     int* plen;                  // [items] prompt length (first generated position)

@@ -388,7 +388,7 @@ const char* g_trace_names[512];
 //   * everything rarely needed (ragged K, M > 16, d_model not a multiple of 256) stays in the older kernels.
 __device__ __forceinline__ float wave_sum_dpp(float v) { return dpp_wave_sum(v); }   // common.h: 6 v_add_f32_dpp
 
-template <int CH, int LNV, int IN, int OUT, int NTB>
+template <int CH, int LNV, int IN, int OUT, int NTB, int MT>
 __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
@@ -397,8 +397,9 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
     // with the prologue (and load no weights: their wp is clamped to wave 0's slice, results unused)
     const int nw = (IN == GEMV_IN_XATTN) ? p.nwm : (int)(blockDim.x >> 6);
     WLX_TR_BEGIN();
-    float* accred = smem;                                                  // [nw][NTB][64][4]
-    half_t* xs = reinterpret_cast<half_t*>(smem + nw * NTB * 256);         // LN / XATTN: fp16 activation rows
+    constexpr int NP = NTB * MT;                                           // (n-tile, 16-row tile) pairs of this workgroup
+    float* accred = smem;                                                  // [nw][NP][64][4]
+    half_t* xs = reinterpret_cast<half_t*>(smem + nw * NP * 256);          // fp16 activation rows
 
     // (Tried and dropped: sub-tile workgroups — a 16-column tile shared by 2-4 workgroups, each streaming a quarter of
     // the weight rows with the other lanes masked. It spreads N = 768 layers over 192 CUs but does not reduce the number
@@ -415,40 +416,76 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
             for (int i = 0; i < NTB; ++i) wf[j][i] = ld_nt_f16x8(wp + i * wstep + j * 512);
     }
 
-    // epilogue operands, requested now (every lane, clamped row: no branch around a load)
-    const int crow = (c < p.M) ? c : 0;
-    const int nt_e = tile * NTB + ((wave < NTB) ? wave : 0);
+    // epilogue operands of the FIRST pair this wave finishes (pair = wave: n-tile pair / MT, row tile pair % MT),
+    // requested now (every lane, clamped row: no branch around a load); further pairs (batched rows) load theirs late
+    int crow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) crow[mt] = (mt * 16 + c < p.M) ? mt * 16 + c : p.M - 1;
+    const int pair0 = (wave < NP) ? wave : 0;
+    const int nt_e = tile * NTB + pair0 / MT;
     const int n_e = nt_e * 16 + g * 4;
+    int row_e = (pair0 % MT) * 16 + c;
+    if (row_e >= p.M) row_e = p.M - 1;
     float4 bias_e = make_float4(0.f, 0.f, 0.f, 0.f), res_e = bias_e;
     int rc_e = 0, rp_e = 0;
     if constexpr (OUT != GEMV_OUT_F32) bias_e = *reinterpret_cast<const float4*>(p.bias + n_e);
-    if constexpr (OUT == GEMV_OUT_RESID) res_e = *reinterpret_cast<const float4*>(p.Xres + (long)crow * p.ldxres + n_e);
-    if constexpr (OUT == GEMV_OUT_QKV) { rc_e = p.row_cache[crow]; rp_e = p.row_pos[crow]; }
+    if constexpr (OUT == GEMV_OUT_RESID) res_e = *reinterpret_cast<const float4*>(p.Xres + (long)row_e * p.ldxres + n_e);
+    if constexpr (OUT == GEMV_OUT_QKV) { rc_e = p.row_cache[row_e]; rp_e = p.row_pos[row_e]; }
 
-    f32x4 acc[NTB];
+    f32x4 acc[NTB][MT];
 #pragma unroll
-    for (int i = 0; i < NTB; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f16x8 xf[CH];
+    for (int i = 0; i < NTB; ++i)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f16x8 xf[CH][MT];
 
     if constexpr (IN == GEMV_IN_F16) {
-        const half_t* xp = p.Xh + (long)crow * p.ldxh + kw0 * 32 + g * 8;
+        const half_t* xr[MT];
+        int xstep;                                                          // halfs between k-tiles of a row
+        if constexpr (MT == 1) {
+            // One stream (M <= 16): the fp16 rows go through LDS — fetching B fragments straight from global costs CH
+            // loads per wave of 64-byte pieces (16 waves x 6 = 96 load instructions per workgroup for K = 3072, as many
+            // as the weights; a CU retires one per ~11 ns), the cooperative copy M * K / 8 / 64 = 30.
+            const int ldxs = p.K + 8;
+            const int kv8 = p.K >> 3;                                       // 16-byte units per row
+            for (int u = tid; u < p.M * kv8; u += blockDim.x) {
+                const int m = u / kv8, k8 = u - m * kv8;
+                *reinterpret_cast<f16x8*>(xs + m * ldxs + k8 * 8) = ld_f16x8(p.Xh + (long)m * p.ldxh + k8 * 8);
+            }
+            WLX_TR_MARK(1);
+            __syncthreads();
+            xr[0] = xs + crow[0] * ldxs + kw0 * 32 + g * 8;                 // lanes of rows >= M re-read a valid row (never stored)
+            xstep = 32;
+        } else {
+            // batched rows: M x K fp16 no longer fits the LDS budget for K = 3072 — fragments straight from global
 #pragma unroll
-        for (int j = 0; j < CH; ++j) xf[j] = ld_f16x8(xp + j * 32);
-        WLX_TR_MARK(1);
+            for (int mt = 0; mt < MT; ++mt) xr[mt] = p.Xh + (long)crow[mt] * p.ldxh + kw0 * 32 + g * 8;
+            xstep = 32;
+        }
+#pragma unroll
+        for (int j = 0; j < CH; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xf[j][mt] = *reinterpret_cast<const f16x8*>(xr[mt] + j * xstep);
 #pragma unroll 1
         for (int ch = 1; ch < p.NCH; ++ch) {                               // big-K layers of the larger models only
-            f16x8 wn[CH][NTB], xn[CH];
+            f16x8 wn[CH][NTB], xn[CH][MT];
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
 #pragma unroll
                 for (int i = 0; i < NTB; ++i) wn[j][i] = ld_nt_f16x8(wp + i * wstep + (ch * CH + j) * 512);
-                xn[j] = ld_f16x8(xp + (ch * CH + j) * 32);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xn[j][mt] = *reinterpret_cast<const f16x8*>(xr[mt] + (ch * CH + j) * xstep);
             }
 #pragma unroll
             for (int j = 0; j < CH; ++j) {
 #pragma unroll
-                for (int i = 0; i < NTB; ++i) { acc[i] = mfma16(wf[j][i], xf[j], acc[i]); wf[j][i] = wn[j][i]; }
-                xf[j] = xn[j];
+                for (int i = 0; i < NTB; ++i) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma16(wf[j][i], xf[j][mt], acc[i][mt]);
+                    wf[j][i] = wn[j][i];
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) xf[j][mt] = xn[j][mt];
             }
         }
     } else if constexpr (IN == GEMV_IN_LN) {
@@ -500,9 +537,12 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
         }
         WLX_TR_MARK(1);
         __syncthreads();
-        const half_t* xr = xs + c * ldxs + kw0 * 32 + g * 8;                // rows >= M: whatever LDS holds (never stored)
 #pragma unroll
-        for (int j = 0; j < CH; ++j) xf[j] = *reinterpret_cast<const f16x8*>(xr + j * 32);
+        for (int mt = 0; mt < MT; ++mt) {
+            const half_t* xr = xs + crow[mt] * ldxs + kw0 * 32 + g * 8;     // lanes of rows >= M re-read a valid row (never stored)
+#pragma unroll
+            for (int j = 0; j < CH; ++j) xf[j][mt] = *reinterpret_cast<const f16x8*>(xr + j * 32);
+        }
     } else {   // GEMV_IN_XATTN: every wave of the workgroup (more than the nw MFMA waves) combines the WLX_XSPLIT
         // partials (normalised fp16 O, fp32 (m, l) contiguous per row): one (row, head, 8-dim group) per thread, 12 16-byte
         // loads in flight, ONE L2 round trip when M * H * 8 <= blockDim; the fp16 result rows go to LDS like the LayerNorm
@@ -546,35 +586,56 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
         WLX_TR_MARK(1);
         __syncthreads();
         if (wave >= nw) return;                                             // helper waves are done (no later barrier needs them: ended waves leave the barrier count)
-        const half_t* xr = xs + c * ldxs + kw0 * 32 + g * 8;
 #pragma unroll
-        for (int j = 0; j < CH; ++j) xf[j] = *reinterpret_cast<const f16x8*>(xr + j * 32);
+        for (int mt = 0; mt < MT; ++mt) {
+            const half_t* xr = xs + crow[mt] * ldxs + kw0 * 32 + g * 8;
+#pragma unroll
+            for (int j = 0; j < CH; ++j) xf[j][mt] = *reinterpret_cast<const f16x8*>(xr + j * 32);
+        }
     }
     WLX_TR_MARK(2);
 #pragma unroll
     for (int j = 0; j < CH; ++j)
 #pragma unroll
-        for (int i = 0; i < NTB; ++i) acc[i] = mfma16(wf[j][i], xf[j], acc[i]);
-
-    // ---- cross-wave K reduction through LDS in a fixed order; wave i < NTB finishes tile i
+        for (int i = 0; i < NTB; ++i)
 #pragma unroll
-    for (int i = 0; i < NTB; ++i) *reinterpret_cast<f32x4*>(accred + ((wave * NTB + i) * 64 + lane) * 4) = acc[i];
+            for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma16(wf[j][i], xf[j][mt], acc[i][mt]);
+
+    // ---- cross-wave K reduction through LDS in a fixed order; wave w finishes pairs w, w + nw, ...
+#pragma unroll
+    for (int i = 0; i < NTB; ++i)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            *reinterpret_cast<f32x4*>(accred + ((wave * NP + i * MT + mt) * 64 + lane) * 4) = acc[i][mt];
     WLX_TR_MARK(3);
     __syncthreads();
 #ifdef WLX_TRACE
-    if (wave >= NTB) { WLX_TR_END_WAVES(p.trc); return; }
+    if (wave >= NP) { WLX_TR_END_WAVES(p.trc); return; }
 #else
-    if (wave >= NTB) return;
+    if (wave >= NP) return;
 #endif
+#pragma unroll 1
+    for (int pair = wave; pair < NP; pair += nw) {
+    const int nt_p = tile * NTB + pair / MT;
+    const int n_p = nt_p * 16 + g * 4;
+    const int row_p = (pair % MT) * 16 + c;
+    if (pair != wave) {                        // not the pair whose operands were requested up front
+        const int rr = (row_p < p.M) ? row_p : p.M - 1;
+        if constexpr (OUT != GEMV_OUT_F32) bias_e = *reinterpret_cast<const float4*>(p.bias + n_p);
+        if constexpr (OUT == GEMV_OUT_RESID) res_e = *reinterpret_cast<const float4*>(p.Xres + (long)rr * p.ldxres + n_p);
+        if constexpr (OUT == GEMV_OUT_QKV) { rc_e = p.row_cache[rr]; rp_e = p.row_pos[rr]; }
+    }
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    const float* ar = accred + (wave * 64 + lane) * 4;
+    const float* ar = accred + (pair * 64 + lane) * 4;
 #pragma unroll 2
     for (int w = 0; w < nw; ++w) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(ar + w * (NTB * 256));
+        const f32x4 t = *reinterpret_cast<const f32x4*>(ar + w * (NP * 256));
         v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
     }
     WLX_TR_MARK(4);
-    if (c < p.M && (NTB == 1 || nt_e * 16 < p.N)) {
+    if (row_p < p.M && (NTB == 1 || nt_p * 16 < p.N)) {
+        const int c = row_p;                   // (shadows the lane's column index: below, c is the activation row)
+        const int n_e = n_p;
         float o0 = v[0] + bias_e.x, o1 = v[1] + bias_e.y, o2 = v[2] + bias_e.z, o3 = v[3] + bias_e.w;
         if constexpr (OUT == GEMV_OUT_F16 || OUT == GEMV_OUT_GELU_F16) {
             if constexpr (OUT == GEMV_OUT_GELU_F16) { o0 = gelu_erf(o0); o1 = gelu_erf(o1); o2 = gelu_erf(o2); o3 = gelu_erf(o3); }
@@ -599,15 +660,16 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
             }
         }
     }
+    }
     WLX_TR_MARK(5);
     WLX_TR_END_WAVES(p.trc);
 }
 
-struct Gemv2Cfg { bool ok; int nw, CH, NCH, LNV, NTB; size_t shm; };
+struct Gemv2Cfg { bool ok; int nw, CH, NCH, LNV, NTB, MT; size_t shm; };
 static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     Gemv2Cfg c{};
     c.ok = false;
-    if (g_decode_v1 || p.M > 16 || p.M < 1) return c;
+    if (g_decode_v1 || p.M > 32 || p.M < 1) return c;
     if (p.bias ? (p.N & 15) != 0 : p.out_mode != GEMV_OUT_F32) return c;      // bias <=> not the vocabulary projection
     const bool combo = (p.in_mode == GEMV_IN_LN && (p.out_mode == GEMV_OUT_QKV || p.out_mode == GEMV_OUT_F16 ||
                                                     p.out_mode == GEMV_OUT_GELU_F16 || p.out_mode == GEMV_OUT_F32)) ||
@@ -635,30 +697,31 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
         c.LNV = p.K / 256;
     }
     c.NTB = (p.out_mode == GEMV_OUT_F32 && p.N > 8192) ? 2 : 1;
-    c.shm = sizeof(float) * (size_t)c.nw * c.NTB * 256;
-    if (p.in_mode == GEMV_IN_LN) c.shm += (size_t)16 * (p.K + 8) * sizeof(half_t);
-    if (p.in_mode == GEMV_IN_XATTN) c.shm += (size_t)16 * (p.K + 8) * sizeof(half_t);
+    c.MT = (p.M + 15) / 16;
+    c.shm = sizeof(float) * (size_t)c.nw * c.NTB * c.MT * 256;
+    if (!(p.in_mode == GEMV_IN_F16 && c.MT > 1)) c.shm += (size_t)p.M * (p.K + 8) * sizeof(half_t);   // fp16 activation rows
+    if (c.shm > 64 * 1024) return c;                                   // beyond the default dynamic-LDS limit: older kernel
     c.ok = true;
     return c;
 }
 
-template <int CH, int LNV>
+template <int CH, int LNV, int MT>
 static bool gemv2_launch_ln(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, dim3 block, hipStream_t s) {
     switch (p.out_mode) {
-        case GEMV_OUT_QKV: hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, GEMV_OUT_QKV, 1>), grid, block, c.shm, s, p); return true;
-        case GEMV_OUT_F16: hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, GEMV_OUT_F16, 1>), grid, block, c.shm, s, p); return true;
-        case GEMV_OUT_GELU_F16: hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, GEMV_OUT_GELU_F16, 1>), grid, block, c.shm, s, p); return true;
+        case GEMV_OUT_QKV: hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, GEMV_OUT_QKV, 1, MT>), grid, block, c.shm, s, p); return true;
+        case GEMV_OUT_F16: hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, GEMV_OUT_F16, 1, MT>), grid, block, c.shm, s, p); return true;
+        case GEMV_OUT_GELU_F16: hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, GEMV_OUT_GELU_F16, 1, MT>), grid, block, c.shm, s, p); return true;
         case GEMV_OUT_F32:
-            if (c.NTB == 2) hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, GEMV_OUT_F32, 2>), grid, block, c.shm, s, p);
-            else hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, GEMV_OUT_F32, 1>), grid, block, c.shm, s, p);
+            if (c.NTB == 2) hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, GEMV_OUT_F32, 2, MT>), grid, block, c.shm, s, p);
+            else hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, GEMV_OUT_F32, 1, MT>), grid, block, c.shm, s, p);
             return true;
         default: return false;
     }
 }
-template <int CH>
+template <int CH, int MT>
 static bool gemv2_launch_other(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, dim3 block, hipStream_t s) {
-    if (p.in_mode == GEMV_IN_F16) hipLaunchKernelGGL((dec_gemv2_kernel<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1>), grid, block, c.shm, s, p);
-    else hipLaunchKernelGGL((dec_gemv2_kernel<CH, 1, GEMV_IN_XATTN, GEMV_OUT_RESID, 1>), grid, block, c.shm, s, p);
+    if (p.in_mode == GEMV_IN_F16) hipLaunchKernelGGL((dec_gemv2_kernel<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, MT>), grid, block, c.shm, s, p);
+    else hipLaunchKernelGGL((dec_gemv2_kernel<CH, 1, GEMV_IN_XATTN, GEMV_OUT_RESID, 1, MT>), grid, block, c.shm, s, p);
     return true;
 }
 // the (CH, LNV) pairs of the Whisper family: d_model 512 (4,2), 768 (6,3), 1024 (4,4), 1280 (5,5)
@@ -676,18 +739,22 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
         const int want = (p.M * p.H * 8 + 63) / 64;
         block.x = 64 * std::max(c.nw, std::min(16, want));
     }
+#define WLX_G2_LN(CH_, LNV_) (c.MT == 1 ? gemv2_launch_ln<CH_, LNV_, 1>(p, c, grid, block, s) : gemv2_launch_ln<CH_, LNV_, 2>(p, c, grid, block, s))
+#define WLX_G2_OT(CH_) (c.MT == 1 ? gemv2_launch_other<CH_, 1>(p, c, grid, block, s) : gemv2_launch_other<CH_, 2>(p, c, grid, block, s))
     if (p.in_mode == GEMV_IN_LN) {
-        if (c.CH == 6 && c.LNV == 3) return gemv2_launch_ln<6, 3>(p, c, grid, block, s);
-        if (c.CH == 5 && c.LNV == 5) return gemv2_launch_ln<5, 5>(p, c, grid, block, s);
-        if (c.CH == 4 && c.LNV == 2) return gemv2_launch_ln<4, 2>(p, c, grid, block, s);
-        if (c.CH == 4 && c.LNV == 4) return gemv2_launch_ln<4, 4>(p, c, grid, block, s);
+        if (c.CH == 6 && c.LNV == 3) return WLX_G2_LN(6, 3);
+        if (c.CH == 5 && c.LNV == 5) return WLX_G2_LN(5, 5);
+        if (c.CH == 4 && c.LNV == 2) return WLX_G2_LN(4, 2);
+        if (c.CH == 4 && c.LNV == 4) return WLX_G2_LN(4, 4);
         return false;
     }
     switch (c.CH) {
-        case 6: return gemv2_launch_other<6>(p, c, grid, block, s);
-        case 5: return gemv2_launch_other<5>(p, c, grid, block, s);
-        default: return gemv2_launch_other<4>(p, c, grid, block, s);
+        case 6: return WLX_G2_OT(6);
+        case 5: return WLX_G2_OT(5);
+        default: return WLX_G2_OT(4);
     }
+#undef WLX_G2_LN
+#undef WLX_G2_OT
 }
 static bool gemv2_ok(const GemvParams& p, Gemv2Cfg* out) {
     const Gemv2Cfg c = gemv2_cfg(p);
@@ -705,7 +772,7 @@ const char* dec_gemv_kernel_name(const GemvParams& p) {
     const int MT = (p.M + 15) / 16;
     Gemv2Cfg c2;
     if (gemv2_ok(p, &c2)) {
-        snprintf(buf, sizeof(buf), "dec_gemv2_kernel<%d, %d, %d, %d, %d>", c2.CH, c2.LNV ? c2.LNV : 1, p.in_mode, p.out_mode, c2.NTB);
+        snprintf(buf, sizeof(buf), "dec_gemv2_kernel<%d, %d, %d, %d, %d, %d>", c2.CH, c2.LNV ? c2.LNV : 1, p.in_mode, p.out_mode, c2.NTB, c2.MT);
         return buf;
     }
     snprintf(buf, sizeof(buf), "dec_gemv_kernel<%d, %d, %d>", MT > 4 ? 4 : MT, MT == 1 ? 2 : 1, p.in_mode);

@@ -30,8 +30,10 @@ struct StepGraphKey {
     }
 };
 
-struct ProfRec { const char* name; double bytes; hipEvent_t a, b; };
-struct Prof { std::vector<ProfRec> recs; std::vector<std::string> names; int t = 0; };
+// decode-step profiler (wlx_debug_profile_step): pass 1 only lists the launches of a step (name, algorithmic bytes);
+// pass 2 replays, per kernel name, a captured graph holding just that kernel's launches of the step
+struct ProfRec { std::string name; double bytes; };
+struct Prof { std::vector<ProfRec> recs; bool list_only = true; std::string only; int t = 0; };
 
 struct Slot {
     int B = 0, R = 0, rows_cap = 0, cache_rows = 0, groups_cap = 0;

@@ -464,6 +464,8 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         CKR(dalloc(s->allocs, &s->d_tokprob, (size_t)RC));
         s->h_stage_ints = 1 << 16;
         CK(hipHostMalloc(reinterpret_cast<void**>(&s->h_stage), s->h_stage_ints * sizeof(int), hipHostMallocDefault));
+        // the search kernels raise this pinned word themselves when every item is finished (no per-step D2H copy)
+        s->st.done_host = s->h_stage + (s->h_stage_ints - 4);
         CK(hipDeviceSynchronize());
         return WLX_OK;
     }();
@@ -668,26 +670,19 @@ extern "C" int32_t wlx_encoder_output_get(wlx_engine* e, int32_t slot, int32_t i
 }
 
 // ------------------------------------------------------------------------------------------------
-// per-kernel HIP-event profiler (test hook wlx_debug_profile_step): when s->prof is set every launch of
-// the decoder pass is bracketed by an event pair on the slot stream and tagged with its kernel name
-// (as rocprofv3 prints it) and its ALGORITHMIC bytes (weights / K,V it has to stream once).
+// per-kernel profiler hook (wlx_debug_profile_step): when s->prof is set a launch of the decoder pass is either only
+// listed (name as rocprofv3 prints it + its ALGORITHMIC bytes: weights / K,V it has to stream once) or filtered by name.
 template <class F>
 static inline void plaunch(Slot* s, const char* name, double bytes, F&& f) {
     if (!s->prof) { f(); return; }
-    hipEvent_t a, b;
-    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-    (void)hipEventRecord(a, s->stream);
-    f();
-    (void)hipEventRecord(b, s->stream);
-    s->prof->recs.push_back(ProfRec{name, bytes, a, b});
+    if (s->prof->list_only) { s->prof->recs.push_back(ProfRec{name, bytes}); return; }
+    if (s->prof->only == name) f();
 }
-static std::string gemv_name(const GemvParams& p) { return dec_gemv_kernel_name(p); }
 static double gemv_bytes(const GemvParams& p) { return 2.0 * (double)p.N * (double)p.K + (p.bias ? 4.0 * p.N : 0.0); }
 static void pgemv(Slot* s, const GemvParams& p) {
     if (!s->prof) { launch_dec_gemv(p, s->stream); return; }
-    s->prof->names.push_back(gemv_name(p));
-    const char* nm = s->prof->names.back().c_str();
-    plaunch(s, nm, gemv_bytes(p), [&] { launch_dec_gemv(p, s->stream); });
+    const std::string nm = dec_gemv_kernel_name(p);
+    plaunch(s, nm.c_str(), gemv_bytes(p), [&] { launch_dec_gemv(p, s->stream); });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -983,7 +978,7 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
     // each), so the check costs no GPU idle time; once the flag is set the one extra step already in flight is a
     // chain of early-exit kernels (every decode kernel tests the flag).
     volatile int* h_done = s->h_stage + (s->h_stage_ints - 4);
-    h_done[0] = 0; h_done[1] = 0;
+    h_done[0] = 0;
     int steps_run = 0;
     bool finished = false;
     for (int step = 0; step < max_steps && !finished; ++step) {
@@ -1000,14 +995,16 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
             CKR(run_step(e, s, rows, R, batch, sampling));
         }
         ++steps_run;
-        CK(hipMemcpyAsync(const_cast<int*>(h_done) + (step & 1), S.done, 4, hipMemcpyDeviceToHost, st));
+        // The search kernel of the step that finishes the last item stores 1 to the pinned word h_done itself; an event
+        // after every step tells the host how far the stream got. Step k+1 is enqueued BEFORE the host waits for step
+        // k-1, so the stream never runs dry; at most two steps run past the finish (scratch-only, see decoder_pass).
         CK(hipEventRecord((step & 1) ? s->ev_poll1 : s->ev_poll0, st));
         if (injected_logits) {
             CK(hipStreamSynchronize(st));
-            finished = h_done[step & 1] != 0;
+            finished = h_done[0] != 0;
         } else if (step >= 1) {
             CK(hipEventSynchronize(((step - 1) & 1) ? s->ev_poll1 : s->ev_poll0));
-            finished = h_done[(step - 1) & 1] != 0;
+            finished = h_done[0] != 0;
         }
     }
     CK(hipStreamSynchronize(st));
@@ -1015,13 +1012,16 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
     std::vector<int> n_hyp(batch), hyp_len((size_t)batch * WLX_MAX_HYP);
     std::vector<float> hyp_score((size_t)batch * WLX_MAX_HYP), nspv(batch);
     std::vector<int> hyp_tok((size_t)batch * WLX_MAX_HYP * WLX_T_TEXT);
-    CK(hipMemcpy(n_hyp.data(), S.n_hyp, batch * 4, hipMemcpyDeviceToHost));
-    CK(hipMemcpy(hyp_len.data(), S.hyp_len, hyp_len.size() * 4, hipMemcpyDeviceToHost));
-    CK(hipMemcpy(hyp_score.data(), S.hyp_score, hyp_score.size() * 4, hipMemcpyDeviceToHost));
-    CK(hipMemcpy(hyp_tok.data(), S.hyp_tokens, hyp_tok.size() * 4, hipMemcpyDeviceToHost));
-    CK(hipMemcpy(nspv.data(), S.no_speech, batch * 4, hipMemcpyDeviceToHost));
+    // result readback on the SLOT stream (never the legacy stream: a synchronous hipMemcpy here would try to order the
+    // legacy stream against another slot's stream while that one is capturing its step graph, and fail both)
+    CK(hipMemcpyAsync(n_hyp.data(), S.n_hyp, batch * 4, hipMemcpyDeviceToHost, st));
+    CK(hipMemcpyAsync(hyp_len.data(), S.hyp_len, hyp_len.size() * 4, hipMemcpyDeviceToHost, st));
+    CK(hipMemcpyAsync(hyp_score.data(), S.hyp_score, hyp_score.size() * 4, hipMemcpyDeviceToHost, st));
+    CK(hipMemcpyAsync(hyp_tok.data(), S.hyp_tokens, hyp_tok.size() * 4, hipMemcpyDeviceToHost, st));
+    CK(hipMemcpyAsync(nspv.data(), S.no_speech, batch * 4, hipMemcpyDeviceToHost, st));
     int step_dev = 0;
-    CK(hipMemcpy(&step_dev, S.step, 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpyAsync(&step_dev, S.step, 4, hipMemcpyDeviceToHost, st));
+    CK(hipStreamSynchronize(st));
     const int NH = std::max(1, o->num_hypotheses);
     for (int b = 0; b < batch; ++b) {
         std::vector<int> order(std::min(n_hyp[b], WLX_MAX_HYP));
@@ -1255,30 +1255,46 @@ extern "C" int32_t wlx_debug_profile_step(wlx_engine* e, int32_t slot, int32_t r
     CK(hipStreamSynchronize(st));
     Prof prof;
     prof.t = t;
-    prof.names.reserve((size_t)iters * 128);
     s->prof = &prof;
-    for (int i = 0; i < iters; ++i) decoder_pass(e, s, rows, rows, 1, true, true);
-    s->prof = nullptr;
-    CK(hipStreamSynchronize(st));
-    CK(hipGetLastError());
-    struct Agg { int launches = 0; double us = 0, bytes = 0; };
+    decoder_pass(e, s, rows, rows, 1, true, true);                               // pass 1: list the launches of one step
+    struct Agg { int launches = 0; double bytes = 0, us = 0; };
     std::map<std::string, Agg> agg;
-    for (auto& r : prof.recs) {
+    for (auto& r : prof.recs) { Agg& a = agg[r.name]; a.launches += 1; a.bytes += r.bytes; }
+    // pass 2, per kernel name: a graph with just that kernel's launches of the step (back to back on the slot stream, so
+    // each pays the dependent-launch boundary exactly as inside the real step), replayed `iters` times between one
+    // HIP-event pair. An event pair around every single 2-5 us launch measured the events, not the kernels.
+    prof.list_only = false;
+    int rc = WLX_OK;
+    for (auto& kv : agg) {
+        prof.only = kv.first;
+        hipGraph_t graph; hipGraphExec_t exec;
+        if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { rc = WLX_ERR_HIP; break; }
+        decoder_pass(e, s, rows, rows, 1, true, true);
+        if (hipStreamEndCapture(st, &graph) != hipSuccess) { rc = WLX_ERR_HIP; break; }
+        if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(graph); rc = WLX_ERR_HIP; break; }
+        (void)hipGraphDestroy(graph);
+        for (int i = 0; i < 3; ++i) (void)hipGraphLaunch(exec, st);
+        (void)hipEventRecord(s->ev0, st);
+        for (int i = 0; i < iters; ++i) (void)hipGraphLaunch(exec, st);
+        (void)hipEventRecord(s->ev1, st);
+        (void)hipStreamSynchronize(st);
         float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, r.a, r.b);
-        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
-        Agg& a = agg[r.name];
-        a.launches += 1; a.us += 1000.0 * ms; a.bytes += r.bytes;
+        (void)hipEventElapsedTime(&ms, s->ev0, s->ev1);
+        (void)hipGraphExecDestroy(exec);
+        kv.second.us = 1000.0 * ms / iters;                                       // all launches of this kernel in one step
     }
+    s->prof = nullptr;
+    if (rc != WLX_OK) return fail(rc, "profile capture failed");
+    CK(hipGetLastError());
     int n = 0;
     for (auto& kv : agg) {
         if (n >= cap) break;
         wlx_kernel_stat& o = out[n++];
         memset(&o, 0, sizeof(o));
         snprintf(o.name, sizeof(o.name), "%s", kv.first.c_str());
-        o.launches_per_step = (float)kv.second.launches / (float)iters;
+        o.launches_per_step = (float)kv.second.launches;
         o.avg_us = (float)(kv.second.us / kv.second.launches);
-        o.total_us_per_step = (float)(kv.second.us / iters);
+        o.total_us_per_step = (float)kv.second.us;
         o.bytes_per_launch = kv.second.bytes / kv.second.launches;
     }
     *n_out = n;

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(256) void search_update_kernel(const SearchParams* 
             if (tid == 0) {
                 st.item_done[item] = 1;
                 const int nf = atomicAdd(st.n_finished, 1) + 1;
-                if (nf >= sp.items) *st.done = 1;
+                if (nf >= sp.items) { *st.done = 1; __hip_atomic_store(st.done_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
             }
             return;
         }
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(256) void search_update_kernel(const SearchParams* 
             st.n_hyp[item] = sp.num_hyp;
             st.item_done[item] = 1;
             const int nf = atomicAdd(st.n_finished, 1) + 1;
-            if (nf >= sp.items) *st.done = 1;
+            if (nf >= sp.items) { *st.done = 1; __hip_atomic_store(st.done_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
         }
     }
 }
@@ -896,7 +896,7 @@ __global__ __launch_bounds__(MU3_THREADS) void search_merge_update3_kernel(const
         if (tid == 0) {
             st.item_done[item] = 1;
             const int nf = atomicAdd(st.n_finished, 1) + 1;
-            if (nf >= sp.items) *st.done = 1;
+            if (nf >= sp.items) { *st.done = 1; __hip_atomic_store(st.done_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
         }
         return;
     }
