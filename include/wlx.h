@@ -179,6 +179,17 @@ int32_t wlx_debug_decode_logits(wlx_engine* e, int32_t slot, const int32_t* toke
 int32_t wlx_debug_search(wlx_engine* e, int32_t slot, const float* logits, int32_t steps,
                          const int32_t* prompt, int32_t prompt_len, const wlx_gen_opts* opts,
                          int32_t* tokens_out, int32_t tokens_stride, int32_t* n_tokens_out, float* scores_out);
+/* Word alignment — replaces ctranslate2.models.Whisper.align(encoder_output, start_sequence, text_tokens, num_frames,
+ * median_filter_width) (whisper_live/transcriber/transcriber_faster_whisper.py:1657-1663).
+ * tokens = start_sequence (n_sot ids) + [no_timestamps] + text_tokens + [eot]  (n_tokens <= 448) of encoder item `item`;
+ * heads = n_heads (layer, head) pairs (the model's alignment heads). Outputs: the DTW path as parallel arrays
+ * text_indices / time_indices (n_path <= path_cap entries; time in encoder positions of 20 ms) and
+ * text_token_probs[n_tokens - n_sot - 2] = softmax over ids < eot of each text token. */
+int32_t wlx_align(wlx_engine* e, int32_t slot, int32_t item, const int32_t* tokens, int32_t n_tokens, int32_t n_sot,
+                  int32_t num_frames, int32_t median_filter_width, const int32_t* heads, int32_t n_heads, int32_t eot,
+                  int32_t* text_indices, int32_t* time_indices, int32_t path_cap, int32_t* n_path_out,
+                  float* text_token_probs);
+
 /* time `iters` replays of one full decode step (rows x vocab GEMV chain) with HIP events; returns avg ms */
 int32_t wlx_debug_time_decode_step(wlx_engine* e, int32_t slot, int32_t rows, int32_t t, int32_t iters,
                                    float* avg_ms_out);

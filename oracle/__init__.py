@@ -19,6 +19,9 @@ What is restated, and from where (paths relative to the reference checkout /root
   definition (whisper/decoding.py: SuppressBlank, SuppressTokens, ApplyTimestampRules; identical to
   transformers generation/logits_process.py:1909-2047), beam search / sampling per the CT2 contract
   the caller relies on (score = sum logp incl. EOT / len^length_penalty, :1409-1414).
+* ``alignment.py`` — ctranslate2.models.Whisper.align as called at transcriber_faster_whisper.py:1657-1663 (word
+  timestamps): published openai/whisper timing.py algorithm; median filter and DTW pinned against transformers
+  generation_whisper.py (tests/golden/align_golden.npz).
 * ``vad.py``      — faster_whisper.vad (get_speech_timestamps / collect_chunks / SpeechTimestampsMap)
   as used at transcriber_faster_whisper.py:830-838,1792-1817.
 

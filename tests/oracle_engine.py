@@ -51,6 +51,13 @@ class OracleSlot:
             out.append(GenerationResult(r.sequences_ids, r.scores, r.no_speech_prob))
         return out
 
+    def align(self, tokens, n_sot, num_frames, heads, eot, median_filter_width=7, item=0):
+        from oracle import alignment as oal
+        tokens = list(tokens)
+        ti, fi, probs, _m = oal.align(self.engine.oracle, self.enc[item: item + 1], tokens[:n_sot], tokens[n_sot], tokens[n_sot + 1:-1],
+                                      eot, num_frames, [tuple(h) for h in heads], median_filter_width)
+        return np.asarray(ti), np.asarray(fi), np.asarray(probs, np.float32)
+
     def detect_language(self, batch, sot, lang_ids):
         lg = self.engine.oracle.decode_logits(self.enc[:batch], np.full((batch, 1), sot))[:, 0].numpy()[:, lang_ids]
         e = np.exp(lg - lg.max(axis=1, keepdims=True))

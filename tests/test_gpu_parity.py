@@ -323,3 +323,41 @@ def test_generate_is_deterministic_and_graph_equals_eager(tiny, monkeypatch):
         assert a.sequences_ids == b.sequences_ids and a.scores == b.scores
     finally:
         slot.close()
+
+
+@pytest.mark.parametrize("n_text", [9, 90])
+def test_align_parity(tiny, n_text):
+    """wlx_align (cross-attention scores of the alignment heads on the device, softmax / normalise / median / DTW on
+    the host side of the call) vs oracle/alignment.py: token probabilities to 2e-3 + 2 %; the DTW path must be a valid
+    monotone path whose cost ON THE ORACLE'S MATRIX is within 0.5 % of the optimum (fp16 attention can move a step,
+    DTW is discontinuous) and mostly identical."""
+    from oracle import alignment as oal
+    spec, eng, oracle = tiny
+    ids = H.token_ids_for(spec.vocab)
+    slot = eng.create_slot(1, 5)
+    try:
+        pcm = _pcm(8 * 16000, 12)
+        T = slot.logmel(pcm)
+        feats = slot.features()
+        slot.encode(1, seek=[0], seg=[T - 1])
+        enc = oracle.encode(olm.pad_or_trim(feats[:, : T - 1])[None])
+        rng = np.random.default_rng(n_text)
+        text = rng.integers(300, ids.eot - 1, size=n_text).tolist()
+        sot_seq = [ids.sot]
+        heads = [(l, h) for l in range(spec.dec_layers // 2, spec.dec_layers) for h in range(spec.n_heads)]
+        tokens = sot_seq + [ids.no_timestamps] + text + [ids.eot]
+        ti, fi, probs = slot.align(tokens, len(sot_seq), T - 1, heads, ids.eot, median_filter_width=7)
+        rti, rfi, rprobs, matrix = oal.align(oracle, enc, sot_seq, ids.no_timestamps, text, ids.eot, T - 1, heads, 7)
+        np.testing.assert_allclose(probs, rprobs, atol=2e-3, rtol=2e-2)
+        N, M = matrix.shape
+        assert ti[0] == 0 and fi[0] == 0 and ti[-1] == N - 1 and fi[-1] == M - 1
+        dt, df = np.diff(ti), np.diff(fi)
+        assert ((dt == 0) | (dt == 1)).all() and ((df == 0) | (df == 1)).all() and ((dt + df) >= 1).all()
+        cost = lambda a, b: float((-matrix)[a, b].sum())
+        c_got, c_ref = cost(ti, fi), cost(rti, rfi)
+        assert c_got <= c_ref + 5e-3 * abs(c_ref) + 1e-3, (c_got, c_ref)
+        same = len(set(zip(ti.tolist(), fi.tolist())) & set(zip(rti.tolist(), rfi.tolist()))) / len(rti)
+        print("align", n_text, "path overlap", same, "cost", c_got, c_ref)
+        assert same >= 0.8
+    finally:
+        slot.close()

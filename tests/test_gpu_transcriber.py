@@ -94,6 +94,28 @@ def test_vad_gate_and_streaming_session_on_the_engine(pair):
     assert out == (None, None)
 
 
+def test_word_timestamps_match_oracle_pipeline(pair):
+    """transcribe(word_timestamps=True): alignment on the engine vs the oracle through the SAME host logic"""
+    hip, ora = pair
+    pcm = olm.speech_like_pcm(6.0, seed=13)
+    kw = dict(language="en", temperature=0.0, max_new_tokens=16, vad_filter=False, word_timestamps=True)
+    gs, _ = hip.transcribe(pcm, **kw)
+    rs, _ = ora.transcribe(pcm, **kw)
+    assert gs and all(s.words is not None for s in gs)
+    for s in gs:                                           # structural contract the server relies on (base.py:335-342)
+        for w in s.words:
+            assert w.end >= w.start >= 0.0 and 0.0 <= w.probability <= 1.0 and isinstance(w.word, str)
+        if s.words:
+            assert s.start == s.words[0].start and s.end == s.words[-1].end
+    if [t for s in gs for t in s.tokens] == [t for s in rs for t in s.tokens]:
+        gw = [w for s in gs for w in s.words]
+        rw = [w for s in rs for w in s.words]
+        assert [w.word for w in gw] == [w.word for w in rw]
+        close = sum(abs(a.start - b.start) <= 0.04 and abs(a.end - b.end) <= 0.04 for a, b in zip(gw, rw))
+        assert close >= 0.8 * len(rw), (close, len(rw))
+        np.testing.assert_allclose([w.probability for w in gw], [w.probability for w in rw], atol=5e-3, rtol=5e-2)
+
+
 def test_batch_worker_on_device_equals_single_requests(pair):
     from whisperlive_amd.batching import BatchInferenceWorker, BatchRequest
     hip, _ = pair

@@ -17,7 +17,7 @@ SOURCES = ["pack.hip", "logmel.hip", "gemm.hip", "attention.hip", "decoder.hip",
 EXPORTS = [
     "wlx_abi_version", "wlx_last_error", "wlx_engine_create", "wlx_engine_destroy", "wlx_engine_spec",
     "wlx_slot_create", "wlx_slot_destroy", "wlx_logmel", "wlx_pcm_put", "wlx_logmel_resident", "wlx_features_get", "wlx_features_set", "wlx_encode",
-    "wlx_encoder_output_get", "wlx_generate", "wlx_generate_ex", "wlx_detect_language", "wlx_timings_get", "wlx_sync",
+    "wlx_encoder_output_get", "wlx_generate", "wlx_generate_ex", "wlx_detect_language", "wlx_align", "wlx_timings_get", "wlx_sync",
     "wlx_debug_logits_get", "wlx_debug_decode_logits", "wlx_debug_search", "wlx_debug_time_decode_step", "wlx_debug_profile_step", "wlx_debug_trace_step",
 ]
 
@@ -131,6 +131,7 @@ def load() -> C.CDLL:
     lib.wlx_generate.argtypes = [vp, i32, i32, i32p, i32p, i32, C.POINTER(wlx_gen_opts), i32p, i32, i32p, f32p, f32p]
     lib.wlx_generate_ex.argtypes = [vp, i32, i32, i32p, i32p, i32p, i32, C.POINTER(wlx_gen_opts), i32p, i32, i32p, f32p, f32p]
     lib.wlx_detect_language.argtypes = [vp, i32, i32, i32, i32p, i32, f32p]
+    lib.wlx_align.argtypes = [vp, i32, i32, i32p, i32, i32, i32, i32, i32p, i32, i32, i32p, i32p, i32, i32p, f32p]
     lib.wlx_timings_get.argtypes = [vp, i32, C.POINTER(wlx_timings)]
     lib.wlx_sync.argtypes = [vp, i32]
     lib.wlx_debug_logits_get.argtypes = [vp, i32, f32p, i32, i64]

@@ -83,6 +83,9 @@ void launch_dec_self_attn(const half_t* q, long ldq, const half_t* Kc, const hal
 void launch_dec_cross_attn(const half_t* q, long ldq, const half_t* Kp, const half_t* Vp, long item_stride, int H, int R,
                            int groups, int rows, const int* group_item, half_t* part_o, float* part_ml, hipStream_t s);
 
+// raw cross-attention scores of head h (tile-packed K of one layer AND item) for `rows` query rows -> out[rows][1536] fp32
+void launch_dec_align_scores(const half_t* q, long ldq, const half_t* Kp_item, int h, int rows, float* out, hipStream_t s);
+
 // ---------------------------------------------------------------- search.hip
 struct SearchState {            // device pointers, one set per slot
     int* step;                  // [1] decode step counter
@@ -137,6 +140,8 @@ void launch_search_scan3(const float* logits, long ldl, int V, const SearchParam
                          hipStream_t s);
 void launch_search_merge_update3(const float* logits, long ldl, int V, const SearchParams* sp_dev, int items,
                                  const SearchState& st, hipStream_t s);
+// softmax over ids [0, vlim) of row r, probability of token toks[r] -> out[r]   (text_token_probs of Whisper.align)
+void launch_token_prob_rows(const float* logits, long ldl, int vlim, int rows, const int* toks, float* out, hipStream_t s);
 // softmax prob of token `tok` in given logits rows -> out[rows]
 void launch_token_prob(const float* logits, long ldl, int V, int rows, int tok, float* out, hipStream_t s);
 // softmax restricted to ids -> probs[rows][n]

@@ -1028,6 +1028,45 @@ __global__ __launch_bounds__(XA_TPS * 64) void dec_cross_attn_kernel(const half_
     WLX_TR_END(trc);
 }
 
+// ------------------------------------------------------------------ cross-attention scores of one head, for word alignment
+// (ctranslate2 Whisper.align, called from transcriber_faster_whisper.py:1657: the QK of the alignment heads over a
+// teacher-forced pass). Raw scores q.k (q already carries head_dim^-0.5) of `rows` query rows against the 1536 padded
+// keys of one (item, head), written as fp32 [rows][1536]; the softmax over the first num_frames/2 keys, the
+// normalisation, median filter and DTW run on the host side of wlx_align (they are O(tokens x 1500) scalar work).
+// grid (WLX_XSPLIT key splits, row tiles of 16); XA_TPS waves per workgroup, one tile-packed 32-key tile each.
+__global__ __launch_bounds__(XA_TPS * 64) void dec_align_scores_kernel(const half_t* __restrict__ q, long ldq,
+                                                                       const half_t* __restrict__ Kp, int h, int rows,
+                                                                       float* __restrict__ out) {
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int wave = tid >> 6;
+    const int tile = blockIdx.x * XA_TPS + wave;
+    const int row0 = blockIdx.y * 16;
+    const long toff = ((long)h * (WLX_T_AUDIO_PAD / 32) + tile) * 2048 + lane * 8;
+    f16x8 kf[2][2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) kf[s2][kt] = ld_f16x8(Kp + toff + (s2 * 2 + kt) * 512);
+    int row = row0 + c;
+    const bool ok = row < rows;
+    if (!ok) row = rows - 1;
+    f16x8 qf[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) qf[kt] = ld_f16x8(q + (long)row * ldq + h * WLX_HEAD_DIM + kt * 32 + g * 8);
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) st = mfma16(kf[s2][kt], qf[kt], st);
+        // st[r] = score of key tile*32 + s2*16 + g*4 + r for query row c
+        if (ok) *reinterpret_cast<f32x4*>(out + (long)row * WLX_T_AUDIO_PAD + tile * 32 + s2 * 16 + g * 4) = st;
+    }
+}
+
+void launch_dec_align_scores(const half_t* q, long ldq, const half_t* Kp_item, int h, int rows, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(dec_align_scores_kernel, dim3(WLX_XSPLIT, (rows + 15) / 16), dim3(XA_TPS * 64), 0, s, q, ldq, Kp_item, h, rows, out);
+}
+
 void launch_dec_cross_attn(const half_t* q, long ldq, const half_t* Kp, const half_t* Vp, long item_stride, int H, int R,
                            int groups, int rows, const int* group_item, half_t* part_o, float* part_ml, hipStream_t s) {
     hipLaunchKernelGGL(dec_cross_attn_kernel, dim3(WLX_XSPLIT, H, groups), dim3(XA_TPS * 64), 0, s, q, ldq, Kp, Vp, item_stride,

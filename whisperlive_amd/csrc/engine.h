@@ -70,6 +70,11 @@ struct Slot {
     std::map<StepGraphKey, hipGraphExec_t> graphs;
     wlx_timings tm{};
     Prof* prof = nullptr;
+    // word alignment (wlx_align): while `align` is set, decoder_pass also writes the raw cross-attention scores of the
+    // alignment heads for the rows of the current chunk
+    struct AlignCapture { float* scores; const int32_t* heads; int n_heads, n_tok, row0, item; }* align = nullptr;
+    float* align_scores = nullptr; size_t align_cap = 0;     // [n_heads][n_tok][1536] fp32, grown on demand
+    int* d_align_tgt = nullptr; float* d_align_prob = nullptr;   // [448]
 };
 
 struct Engine {

@@ -2,6 +2,9 @@
 // (one HIP stream + all scratch per concurrent stream), and the host orchestration of
 // log-mel -> encoder -> prefill -> hipGraph-replayed decode steps.
 #include "engine.h"
+#include <limits>
+#include <algorithm>
+#include <cmath>
 
 #include <algorithm>
 #include <cmath>
@@ -334,6 +337,7 @@ extern "C" int32_t wlx_engine_create(const wlx_spec* spec, const wlx_tensor* wei
 
 static void slot_free(Slot* s) {
     if (!s) return;
+    if (s->align_scores) (void)hipFree(s->align_scores);
     for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void* p : s->allocs) (void)hipFree(p);
     if (s->h_stage) (void)hipHostFree(s->h_stage);
@@ -457,6 +461,8 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         CKR(dalloc(s->allocs, &st.scan_cv, (size_t)RC * (SC_MAXCH + 1) * WLX_MAX_CAND));
         CKR(dalloc(s->allocs, &st.scan_ci, (size_t)RC * (SC_MAXCH + 1) * WLX_MAX_CAND));
         CKR(dalloc(s->allocs, &st.rule, (size_t)RC * 4));
+        CKR(dalloc(s->allocs, &s->d_align_tgt, (size_t)WLX_T_TEXT));
+        CKR(dalloc(s->allocs, &s->d_align_prob, (size_t)WLX_T_TEXT));
         CKR(dalloc(s->allocs, &s->d_sp, 1));
         CKR(dalloc(s->allocs, &s->d_suppress, (size_t)(1024 * 52 / 32)));
         CKR(dalloc(s->allocs, &s->d_lang_ids, 256));
@@ -721,6 +727,13 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
         p.Wp = w.Wcq; p.bias = w.bcq; p.X = s->xd; p.ldx = d; p.gamma = w.ln2_g; p.beta = w.ln2_b;
         p.Yh = s->qd; p.ldyh = d; p.qscale = 0.125f; p.done = done;
         pgemv(s, p);
+        if (s->align) {     // word alignment: raw q.k of this layer's alignment heads for the rows of this chunk
+            const Slot::AlignCapture& a = *s->align;
+            for (int hi = 0; hi < a.n_heads; ++hi)
+                if (a.heads[2 * hi] == l)
+                    launch_dec_align_scores(s->qd, d, s->ck + ((size_t)l * s->B + a.item) * WLX_T_AUDIO_PAD * d, a.heads[2 * hi + 1], rows,
+                                            a.scores + ((size_t)hi * a.n_tok + a.row0) * WLX_T_AUDIO_PAD, st);
+        }
         plaunch(s, "dec_cross_attn_kernel", 4.0 * groups * WLX_T_AUDIO * d, [&] {
             launch_dec_cross_attn(s->qd, d, s->ck + (size_t)l * s->B * WLX_T_AUDIO_PAD * d, s->cvt + (size_t)l * s->B * d * WLX_T_AUDIO_PAD,
                                   (long)WLX_T_AUDIO_PAD * d, H, R, groups, rows, s->d_group_item, s->part_o, s->part_ml, st);
@@ -1114,6 +1127,168 @@ extern "C" int32_t wlx_detect_language(wlx_engine* e, int32_t slot, int32_t batc
     CK(hipGetLastError());
     CK(hipMemcpyAsync(probs_out, s->d_probs, (size_t)batch * n_lang * 4, hipMemcpyDeviceToHost, st));
     CK(hipStreamSynchronize(st));
+    return WLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// word alignment: ctranslate2 Whisper.align(encoder_output, start_sequence, text_tokens, num_frames, median_filter_width)
+// (transcriber_faster_whisper.py:1657-1663; CT2's source is not in the reference tree — the algorithm is the published
+// one of openai/whisper timing.py find_alignment / HF generation_whisper.py _extract_token_timestamps):
+//   teacher-forced decoder pass over tokens = sot_sequence + [no_timestamps] + text + [eot];
+//   text_token_probs[i] = softmax(logits[n_sot + i][: eot])[text[i]];
+//   per alignment head: softmax of q.k over the first num_frames/2 encoder positions; (w - mean) / std over the TOKEN axis;
+//   median filter of width `median_filter_width` along time (reflect padding); mean over heads;
+//   rows n_sot .. n_tokens-2; dynamic time warping on the negated matrix -> monotone (text index, time index) path.
+// The decoder pass, the score capture and the token probabilities run on the device; the O(tokens x 1500) scalar
+// post-processing (softmax / normalise / median / DTW) runs here on the host side of the call.
+static void align_postprocess(const std::vector<float>& scores, int n_heads, int n_tok, int n_sot, int nf, int mw,
+                              std::vector<int32_t>& ti, std::vector<int32_t>& fi) {
+    const int TP = WLX_T_AUDIO_PAD;
+    std::vector<float> w((size_t)n_heads * n_tok * nf);
+    for (int h = 0; h < n_heads; ++h)
+        for (int t = 0; t < n_tok; ++t) {
+            const float* sr = &scores[((size_t)h * n_tok + t) * TP];
+            float* wr = &w[((size_t)h * n_tok + t) * nf];
+            float mx = sr[0];
+            for (int f = 1; f < nf; ++f) mx = std::max(mx, sr[f]);
+            double sum = 0.0;
+            for (int f = 0; f < nf; ++f) { wr[f] = std::exp(sr[f] - mx); sum += wr[f]; }
+            const float inv = (float)(1.0 / sum);
+            for (int f = 0; f < nf; ++f) wr[f] *= inv;
+        }
+    // std / mean over the token axis (population std), per head and frame
+    for (int h = 0; h < n_heads; ++h)
+        for (int f = 0; f < nf; ++f) {
+            double m = 0.0;
+            for (int t = 0; t < n_tok; ++t) m += w[((size_t)h * n_tok + t) * nf + f];
+            m /= n_tok;
+            double v = 0.0;
+            for (int t = 0; t < n_tok; ++t) { const double dlt = w[((size_t)h * n_tok + t) * nf + f] - m; v += dlt * dlt; }
+            const double sd = std::sqrt(v / n_tok);
+            for (int t = 0; t < n_tok; ++t) {
+                float& x = w[((size_t)h * n_tok + t) * nf + f];
+                x = (float)((x - m) / sd);
+            }
+        }
+    // median filter along time, reflect padding (skipped, as in the reference implementation, when the row is too short)
+    const int pad = mw / 2;
+    if (mw > 1 && nf > pad) {
+        std::vector<float> row(nf + 2 * pad), win(mw);
+        for (size_t r = 0; r < (size_t)n_heads * n_tok; ++r) {
+            float* wr = &w[r * nf];
+            for (int i = 0; i < pad; ++i) { row[i] = wr[pad - i]; row[pad + nf + i] = wr[nf - 2 - i]; }
+            std::copy(wr, wr + nf, row.begin() + pad);
+            for (int f = 0; f < nf; ++f) {
+                std::copy(row.begin() + f, row.begin() + f + mw, win.begin());
+                std::nth_element(win.begin(), win.begin() + pad, win.end());
+                wr[f] = win[pad];
+            }
+        }
+    }
+    // mean over heads, rows n_sot .. n_tok-2, negated: the DTW cost
+    const int N = n_tok - 1 - n_sot, M = nf;
+    std::vector<float> x((size_t)N * M);
+    for (int i = 0; i < N; ++i)
+        for (int f = 0; f < M; ++f) {
+            float acc = 0.f;
+            for (int h = 0; h < n_heads; ++h) acc += w[((size_t)h * n_tok + n_sot + i) * nf + f];
+            x[(size_t)i * M + f] = -(acc / (float)n_heads);
+        }
+    // dynamic time warping (openai/whisper timing.py dtw_cpu)
+    const float INF = std::numeric_limits<float>::infinity();
+    std::vector<float> cost((size_t)(N + 1) * (M + 1), INF);
+    std::vector<int8_t> trace((size_t)(N + 1) * (M + 1), -1);
+    cost[0] = 0.f;
+    for (int j = 1; j <= M; ++j)
+        for (int i = 1; i <= N; ++i) {
+            const float c0 = cost[(size_t)(i - 1) * (M + 1) + j - 1], c1 = cost[(size_t)(i - 1) * (M + 1) + j], c2 = cost[(size_t)i * (M + 1) + j - 1];
+            float cc; int8_t tt;
+            if (c0 < c1 && c0 < c2) { cc = c0; tt = 0; }
+            else if (c1 < c0 && c1 < c2) { cc = c1; tt = 1; }
+            else { cc = c2; tt = 2; }
+            cost[(size_t)i * (M + 1) + j] = x[(size_t)(i - 1) * M + j - 1] + cc;
+            trace[(size_t)i * (M + 1) + j] = tt;
+        }
+    for (int j = 0; j <= M; ++j) trace[j] = 2;
+    for (int i = 0; i <= N; ++i) trace[(size_t)i * (M + 1)] = 1;
+    int i = N, j = M;
+    ti.clear(); fi.clear();
+    while (i > 0 || j > 0) {
+        ti.push_back(i - 1); fi.push_back(j - 1);
+        const int8_t tt = trace[(size_t)i * (M + 1) + j];
+        if (tt == 0) { --i; --j; } else if (tt == 1) --i; else --j;
+    }
+    std::reverse(ti.begin(), ti.end());
+    std::reverse(fi.begin(), fi.end());
+}
+
+extern "C" int32_t wlx_align(wlx_engine* e, int32_t slot, int32_t item, const int32_t* tokens, int32_t n_tokens, int32_t n_sot,
+                             int32_t num_frames, int32_t median_filter_width, const int32_t* heads, int32_t n_heads, int32_t eot,
+                             int32_t* text_indices, int32_t* time_indices, int32_t path_cap, int32_t* n_path_out,
+                             float* text_token_probs) {
+    Slot* s;
+    CKR(slot_get(e, slot, &s));
+    if (!tokens || !heads || !text_indices || !time_indices || !n_path_out || !text_token_probs) return fail(WLX_ERR_ARG, "null argument");
+    if (item < 0 || item >= s->enc_batch) return fail(WLX_ERR_STATE, "align: item %d not encoded", item);
+    if (n_sot < 1 || n_tokens < n_sot + 3 || n_tokens > WLX_T_TEXT) return fail(WLX_ERR_ARG, "align: %d tokens with a start sequence of %d", n_tokens, n_sot);
+    if (n_heads < 1 || n_heads > e->spec.dec_layers * e->H) return fail(WLX_ERR_ARG, "align: bad head count");
+    for (int i = 0; i < n_heads; ++i)
+        if (heads[2 * i] < 0 || heads[2 * i] >= e->spec.dec_layers || heads[2 * i + 1] < 0 || heads[2 * i + 1] >= e->H)
+            return fail(WLX_ERR_ARG, "align: head (%d, %d) out of range", heads[2 * i], heads[2 * i + 1]);
+    for (int i = 0; i < n_tokens; ++i) if (tokens[i] < 0 || tokens[i] >= e->spec.vocab) return fail(WLX_ERR_ARG, "align: token out of vocabulary");
+    if (eot < 1 || eot > e->spec.vocab || median_filter_width < 1 || (median_filter_width & 1) == 0) return fail(WLX_ERR_ARG, "align: bad eot / filter width");
+    int nf = num_frames / 2;
+    if (nf < 1) nf = 1;
+    if (nf > WLX_T_AUDIO) nf = WLX_T_AUDIO;
+    const int n_text = n_tokens - n_sot - 2;
+    CK(hipSetDevice(e->device));
+    hipStream_t st = s->stream;
+    const size_t need = (size_t)n_heads * n_tokens * WLX_T_AUDIO_PAD;
+    if (need > s->align_cap) {
+        CK(hipStreamSynchronize(st));
+        if (s->align_scores) CK(hipFree(s->align_scores));
+        s->align_scores = nullptr; s->align_cap = 0;
+        CK(hipMalloc(reinterpret_cast<void**>(&s->align_scores), need * sizeof(float)));
+        s->align_cap = need;
+    }
+    const int crow = item * s->R;
+    std::vector<short> anc((size_t)WLX_T_TEXT, (short)crow);
+    CKR(set_anc_rows(s, anc, crow, 1));
+    Slot::AlignCapture cap{s->align_scores, heads, n_heads, n_tokens, 0, item};
+    std::vector<float> probs(n_tokens, 0.f);
+    int rc = WLX_OK;
+    s->align = &cap;
+    for (int c0 = 0; c0 < n_tokens && rc == WLX_OK; c0 += 64) {
+        const int rows = std::min(64, n_tokens - c0);
+        const int groups = (rows + 15) / 16;
+        std::vector<int> tk(rows), ps(rows), ca(rows, crow), an(rows, crow), gi(groups, item), tgt(rows, -1);
+        for (int i = 0; i < rows; ++i) {
+            tk[i] = tokens[c0 + i]; ps[i] = c0 + i;
+            const int p = c0 + i;                       // logits at position p predict tokens[p + 1]
+            if (p >= n_sot && p < n_sot + n_text) tgt[i] = tokens[p + 1];
+        }
+        rc = upload_rows(s, tk, ps, ca, an, gi);
+        if (rc != WLX_OK) break;
+        cap.row0 = c0;
+        decoder_pass(e, s, rows, 16, groups, true, false);
+        if (hipMemcpyAsync(s->d_align_tgt, tgt.data(), (size_t)rows * 4, hipMemcpyHostToDevice, st) != hipSuccess) { rc = WLX_ERR_HIP; break; }
+        launch_token_prob_rows(s->logits, s->ldl, eot, rows, s->d_align_tgt, s->d_align_prob, st);
+        if (hipMemcpyAsync(probs.data() + c0, s->d_align_prob, (size_t)rows * 4, hipMemcpyDeviceToHost, st) != hipSuccess) { rc = WLX_ERR_HIP; break; }
+        if (hipStreamSynchronize(st) != hipSuccess) { rc = WLX_ERR_HIP; break; }   // tgt / staging reuse
+    }
+    s->align = nullptr;
+    if (rc != WLX_OK) return fail(rc, "align: decoder pass failed");
+    CK(hipGetLastError());
+    std::vector<float> scores(need);
+    CK(hipMemcpyAsync(scores.data(), s->align_scores, need * sizeof(float), hipMemcpyDeviceToHost, st));
+    CK(hipStreamSynchronize(st));
+    std::vector<int32_t> ti, fi;
+    align_postprocess(scores, n_heads, n_tokens, n_sot, nf, median_filter_width, ti, fi);
+    if ((int)ti.size() > path_cap) return fail(WLX_ERR_ARG, "align: path of %d steps exceeds the caller's capacity %d", (int)ti.size(), path_cap);
+    memcpy(text_indices, ti.data(), ti.size() * 4);
+    memcpy(time_indices, fi.data(), fi.size() * 4);
+    *n_path_out = (int32_t)ti.size();
+    for (int i = 0; i < n_text; ++i) text_token_probs[i] = probs[n_sot + i];
     return WLX_OK;
 }
 

@@ -944,6 +944,23 @@ __global__ __launch_bounds__(SR_THREADS) void token_prob_kernel(const float* __r
     sm = block_sum(sm, fs);
     if (threadIdx.x == 0) out[blockIdx.x] = __expf(lrow[tok] - mx) / sm;
 }
+__global__ __launch_bounds__(SR_THREADS) void token_prob_rows_kernel(const float* __restrict__ logits, long ldl, int vlim,
+                                                                     const int* __restrict__ toks, float* __restrict__ out) {
+    __shared__ float fs[16];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    const float* lrow = logits + (long)r * ldl;
+    float mx = WLX_NEG_INF;
+    for (int i = tid; i < vlim; i += SR_THREADS) mx = fmaxf(mx, lrow[i]);
+    mx = block_max(mx, fs);
+    float sm = 0.f;
+    for (int i = tid; i < vlim; i += SR_THREADS) sm += __expf(lrow[i] - mx);
+    sm = block_sum(sm, fs);
+    if (tid == 0) { const int t = toks[r]; out[r] = (t >= 0 && t < vlim) ? __expf(lrow[t] - mx) / sm : 0.f; }
+}
+void launch_token_prob_rows(const float* logits, long ldl, int vlim, int rows, const int* toks, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(token_prob_rows_kernel, dim3(rows), dim3(SR_THREADS), 0, s, logits, ldl, vlim, toks, out);
+}
+
 void launch_token_prob(const float* logits, long ldl, int V, int rows, int tok, float* out, hipStream_t s) {
     hipLaunchKernelGGL(token_prob_kernel, dim3(rows), dim3(SR_THREADS), 0, s, logits, ldl, V, tok, out);
 }

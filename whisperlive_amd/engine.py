@@ -5,7 +5,7 @@ from __future__ import annotations
 import ctypes as C
 import threading
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Sequence
+from typing import Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
@@ -193,6 +193,21 @@ class Slot:
             scores = [float(sc[b, h]) for h in range(nh) if np.isfinite(sc[b, h])]
             out.append(GenerationResult(seqs, scores, float(nsp[b])))
         return out
+
+    def align(self, tokens: Sequence[int], n_sot: int, num_frames: int, heads: Sequence[Tuple[int, int]], eot: int,
+              median_filter_width: int = 7, item: int = 0):
+        """ctranslate2 Whisper.align for one encoded item: tokens = start_sequence + [no_timestamps] + text + [eot].
+        Returns (text_indices, time_indices, text_token_probs)."""
+        tk = np.ascontiguousarray(tokens, dtype=np.int32)
+        hd = np.ascontiguousarray(np.asarray(heads, dtype=np.int32).reshape(-1, 2))
+        cap = tk.size + 1500 + 8
+        ti = np.zeros(cap, dtype=np.int32)
+        fi = np.zeros(cap, dtype=np.int32)
+        n_path = C.c_int32(0)
+        probs = np.zeros(max(1, tk.size - n_sot - 2), dtype=np.float32)
+        check(self.lib.wlx_align(self.engine._h, self.sid, item, _i32p(tk), tk.size, n_sot, int(num_frames), int(median_filter_width),
+                                 _i32p(hd), hd.shape[0], int(eot), _i32p(ti), _i32p(fi), cap, C.byref(n_path), _f32p(probs)))
+        return ti[: n_path.value].copy(), fi[: n_path.value].copy(), probs
 
     def detect_language(self, batch: int, sot: int, lang_ids: Sequence[int]) -> np.ndarray:
         li = np.asarray(lang_ids, dtype=np.int32)

@@ -114,6 +114,51 @@ class Tokenizer:
             out.append(self.tokenizer.decode(run))
         return "".join(out)
 
+    # ---- word boundaries for word-level timestamps (faster_whisper.tokenizer.Tokenizer.split_to_word_tokens, used at
+    # transcriber_faster_whisper.py:1670; un-vendored — the published openai/whisper tokenizer.py rules)
+    def split_to_word_tokens(self, tokens: Sequence[int]) -> Tuple[List[str], List[List[int]]]:
+        if self.language_code in ("zh", "ja", "th", "lo", "my", "yue"):
+            # scripts written without spaces: every complete unicode character sequence is its own "word"
+            return self.split_tokens_on_unicode(tokens)
+        return self.split_tokens_on_spaces(tokens)
+
+    def split_tokens_on_unicode(self, tokens: Sequence[int]) -> Tuple[List[str], List[List[int]]]:
+        """cut wherever the tokens decoded so far form valid text (no dangling byte-level fragment, U+FFFD)"""
+        full = self.decode_with_timestamps(tokens)
+        bad = "\ufffd"
+        words: List[str] = []
+        groups: List[List[int]] = []
+        cur: List[int] = []
+        offset = 0
+        for t in tokens:
+            cur.append(t)
+            text = self.decode_with_timestamps(cur)
+            at = text.find(bad)
+            # a replacement character is only genuine if the full decoding has one at the same place
+            if at < 0 or (offset + at < len(full) and full[offset + at] == bad):
+                words.append(text)
+                groups.append(cur)
+                cur = []
+                offset += len(text)
+        return words, groups
+
+    def split_tokens_on_spaces(self, tokens: Sequence[int]) -> Tuple[List[str], List[List[int]]]:
+        """unicode pieces merged into words: a piece opens a new word if it is a special token, starts with a space or
+        is bare punctuation; anything else continues the previous word"""
+        import string
+        pieces, piece_tokens = self.split_tokens_on_unicode(tokens)
+        words: List[str] = []
+        groups: List[List[int]] = []
+        for piece, toks in zip(pieces, piece_tokens):
+            opens = toks[0] >= self.eot or piece.startswith(" ") or piece.strip() in string.punctuation or not words
+            if opens:
+                words.append(piece)
+                groups.append(list(toks))
+            else:
+                words[-1] += piece
+                groups[-1].extend(toks)
+        return words, groups
+
     @cached_property
     def non_speech_tokens(self) -> Tuple[int, ...]:
         """Ids of symbol / bracket / music-note tokens that Whisper suppresses by default (the published OpenAI

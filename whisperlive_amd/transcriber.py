@@ -30,6 +30,7 @@ from typing import Dict, Iterable, List, Optional, Sequence, Tuple, Union
 import numpy as np
 
 from . import vad as _vad
+from . import word_timing as _wt
 from .engine import GenerationResult, HipWhisperEngine, Slot, TokenIds
 from .specs import WhisperSpec, get_spec, spec_from_state_dict
 from .tokenizer import LANGUAGE_CODES, Tokenizer
@@ -99,6 +100,13 @@ class DeviceFeatures:
 
     def numpy(self) -> np.ndarray:
         return self.slot.features(self.item)
+
+
+@dataclass
+class AlignmentResult:
+    """shape of ctranslate2.models.WhisperAlignmentResult"""
+    alignments: List[Tuple[int, int]]
+    text_token_probs: List[float]
 
 
 @dataclass
@@ -197,6 +205,27 @@ class _EngineModel:
             r.sequences = [[hf.id_to_token(t) for t in seq] for seq in r.sequences_ids]
         return res
 
+    def align(self, encoder_output: EncoderOutput, start_sequence: Sequence[int], text_tokens: Sequence[Sequence[int]],
+              num_frames: Union[int, Sequence[int]], *, median_filter_width: int = 7) -> List["AlignmentResult"]:
+        """ctranslate2 Whisper.align (:1657-1663): one result per item with .alignments [(text index, time index)] and
+        .text_token_probs"""
+        o = self._o
+        slot = encoder_output.slot
+        if encoder_output.generation != slot._enc_generation:
+            raise RuntimeError("stale encoder output: the slot has encoded another batch since")
+        if len(text_tokens) != encoder_output.batch:
+            raise ValueError(f"{len(text_tokens)} token lists for an encoder batch of {encoder_output.batch}")
+        frames = [num_frames] * len(text_tokens) if isinstance(num_frames, int) else list(num_frames)
+        bt = o._base_tokenizer
+        out = []
+        for i, toks in enumerate(text_tokens):
+            seq = list(start_sequence) + [bt.no_timestamps] + list(toks) + [bt.eot]
+            ti, fi, probs = slot.align(seq, len(start_sequence), frames[i], o.alignment_heads, bt.eot,
+                                       median_filter_width=median_filter_width,
+                                       item=encoder_output.items[i] if encoder_output.items is not None else i)
+            out.append(AlignmentResult(list(zip(ti.tolist(), fi.tolist())), probs.tolist()))
+        return out
+
     def detect_language(self, encoder_output: EncoderOutput) -> List[List[Tuple[str, float]]]:
         o = self._o
         if not isinstance(encoder_output, EncoderOutput):
@@ -268,6 +297,20 @@ class WhisperModelHIP:
         self.feat_kwargs = feat_kwargs
         self.feature_extractor = FeatureExtractorHIP(self, **feat_kwargs)
         self.model = _EngineModel(self)
+        # alignment heads for word timestamps: the checkpoint's own list (generation_config.json / config.json
+        # "alignment_heads", as CT2's converter stores it) or the published default (upper half of the decoder)
+        self.alignment_heads = _wt.default_alignment_heads(self.spec.dec_layers, self.spec.n_heads)
+        if os.path.isdir(model_size_or_path):
+            for name in ("generation_config.json", "config.json"):
+                fp = os.path.join(model_size_or_path, name)
+                try:
+                    with open(fp, encoding="utf-8") as f:
+                        heads = json.load(f).get("alignment_heads")
+                    if heads:
+                        self.alignment_heads = [(int(l), int(h)) for l, h in heads]
+                        break
+                except (OSError, ValueError, TypeError):
+                    continue
         self.input_stride = 2
         self.num_samples_per_token = self.feature_extractor.hop_length * self.input_stride
         self.frames_per_second = self.feature_extractor.sampling_rate // self.feature_extractor.hop_length
@@ -279,7 +322,6 @@ class WhisperModelHIP:
         self._slots: List[Slot] = []
         self._slots_lock = threading.Lock()
         self._seed = itertools.count(0x5EED)
-        self._warned_words = False
 
     # ---- slots: one per calling thread (the reference runs one transcription thread per client)
     def _slot(self) -> Slot:
@@ -366,10 +408,6 @@ class WhisperModelHIP:
             multilingual = False
         if not isinstance(audio, np.ndarray):
             raise TypeError("audio must be a float32 numpy waveform at 16 kHz (file decoding is outside the hot path)")
-        if word_timestamps and not self._warned_words:
-            self._warned_words = True
-            self.logger.warning("word_timestamps: cross-attention alignment (ctranslate2 Whisper.align) is not built yet; "
-                                "segments are returned without words")
         audio = np.ascontiguousarray(audio, dtype=np.float32)
         duration = audio.shape[0] / sr
         duration_after_vad = duration
@@ -418,7 +456,7 @@ class WhisperModelHIP:
                 initial_prompt=initial_prompt, prefix=prefix, suppress_blank=suppress_blank,
                 suppress_tokens=get_suppressed_tokens(tokenizer, suppress_tokens) if suppress_tokens else suppress_tokens,
                 without_timestamps=without_timestamps, max_initial_timestamp=max_initial_timestamp,
-                word_timestamps=False, prepend_punctuations=prepend_punctuations,
+                word_timestamps=word_timestamps, prepend_punctuations=prepend_punctuations,
                 append_punctuations=append_punctuations, multilingual=multilingual, max_new_tokens=max_new_tokens,
                 clip_timestamps=clip_timestamps, hallucination_silence_threshold=hallucination_silence_threshold,
                 hotwords=hotwords)
@@ -491,6 +529,8 @@ class WhisperModelHIP:
             else:
                 all_tokens.extend(options.initial_prompt)
         all_segments: List[Segment] = []
+        last_speech_timestamp = 0.0
+        content_duration = float(content_frames * fe.time_per_frame)
         while clip_idx < len(clips):
             clip_start, clip_end = clips[clip_idx]
             clip_end = min(clip_end, content_frames)
@@ -502,6 +542,7 @@ class WhisperModelHIP:
                     seek = clips[clip_idx][0]
                 continue
             time_offset = seek * fe.time_per_frame
+            window_end_time = float((seek + fe.nb_max_frames) * fe.time_per_frame)
             segment_size = min(fe.nb_max_frames, content_frames - seek, clip_end - seek)
             segment_duration = segment_size * fe.time_per_frame
             previous_tokens = all_tokens[prompt_reset_since:]
@@ -525,9 +566,58 @@ class WhisperModelHIP:
                     continue
             tokens = result.sequences_ids[0]
             previous_seek = seek
-            current, seek, _single = self._split_segments_by_timestamps(
+            current, seek, single_ts_ending = self._split_segments_by_timestamps(
                 tokenizer=tokenizer, tokens=tokens, time_offset=time_offset, segment_size=segment_size,
                 segment_duration=segment_duration, seek=seek)
+            if options.word_timestamps:
+                # (:1226-1291) cross-attention alignment of this window's text, then the seek / hallucination rules
+                # that only exist with word timings
+                enc_now = encoder_output
+
+                def align_fn(text_tokens, num_frames, _window):
+                    r = self.model.align(enc_now, tokenizer.sot_sequence, [text_tokens], num_frames)[0]
+                    pairs = np.asarray(r.alignments, dtype=np.int64).reshape(-1, 2)
+                    return pairs[:, 0], pairs[:, 1], np.asarray(r.text_token_probs, dtype=np.float32)
+
+                upd = _wt.add_word_timestamps([current], tokenizer, align_fn, segment_size, self.tokens_per_second,
+                                              self.frames_per_second, options.prepend_punctuations,
+                                              options.append_punctuations, last_speech_timestamp)
+                if upd is not None:
+                    last_speech_timestamp = upd
+                if not single_ts_ending:
+                    lwe = _wt.last_word_end(current)
+                    if lwe is not None and lwe > time_offset:
+                        seek = round(lwe * self.frames_per_second)
+                if options.hallucination_silence_threshold is not None:
+                    thr = options.hallucination_silence_threshold
+                    first = _wt.next_words_segment(current)
+                    if first is not None and _wt.is_segment_anomaly(first):
+                        gap = first["start"] - time_offset
+                        if gap > thr:                      # leading silence before a probable hallucination: skip it
+                            seek = previous_seek + round(gap * self.frames_per_second)
+                            continue
+                    hal_last_end = last_speech_timestamp
+                    for si in range(len(current)):
+                        sgm = current[si]
+                        if not sgm["words"]:
+                            continue
+                        if _wt.is_segment_anomaly(sgm):
+                            nxt = _wt.next_words_segment(current[si + 1:])
+                            hal_next_start = nxt["words"][0]["start"] if nxt is not None else time_offset + segment_duration
+                            silence_before = (sgm["start"] - hal_last_end > thr or sgm["start"] < thr
+                                              or sgm["start"] - time_offset < 2.0)
+                            silence_after = (hal_next_start - sgm["end"] > thr or _wt.is_segment_anomaly(nxt)
+                                             or window_end_time - sgm["end"] < 2.0)
+                            if silence_before and silence_after:
+                                seek = round(max(time_offset + 1, sgm["start"]) * self.frames_per_second)
+                                if content_duration - sgm["end"] < thr:
+                                    seek = content_frames
+                                current[si:] = []
+                                break
+                        hal_last_end = sgm["end"]
+                lwe = _wt.last_word_end(current)
+                if lwe is not None:
+                    last_speech_timestamp = lwe
             for sg in current:
                 text = tokenizer.decode(sg["tokens"])
                 if sg["start"] == sg["end"] or not text.strip():
@@ -537,7 +627,7 @@ class WhisperModelHIP:
                 all_segments.append(Segment(id=idx, seek=previous_seek, start=sg["start"], end=sg["end"], text=text,
                                             tokens=sg["tokens"], temperature=temperature, avg_logprob=avg_logprob,
                                             compression_ratio=compression_ratio, no_speech_prob=result.no_speech_prob,
-                                            words=None))
+                                            words=([Word(**w) for w in sg["words"]] if options.word_timestamps else None)))
             if not options.condition_on_previous_text or temperature > options.prompt_reset_on_temperature:
                 prompt_reset_since = len(all_tokens)
         return all_segments
