@@ -264,9 +264,9 @@ class WhisperModelHIP:
                 if not os.path.isdir(model_size_or_path):
                     raise FileNotFoundError(
                         f"'{model_size_or_path}' is not a model directory: no network in this deployment — pass a local "
-                        "Hugging Face Whisper checkpoint directory, or weights=/spec=")
-                from .weights import load_hf_dir
-                weights = load_hf_dir(model_size_or_path)
+                        "CTranslate2 (model.bin) or Hugging Face (model.safetensors) Whisper directory, or weights=/spec=")
+                from .weights import load_model_dir
+                weights = load_model_dir(model_size_or_path)      # CTranslate2 model.bin or Hugging Face safetensors
             self.spec = spec or spec_from_state_dict(weights)
             self.engine = HipWhisperEngine(self.spec, weights, device=device_index)
         if hf_tokenizer is None:
