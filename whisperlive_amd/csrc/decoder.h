@@ -83,6 +83,12 @@ void launch_dec_self_attn(const half_t* q, long ldq, const half_t* Kc, const hal
 void launch_dec_cross_attn(const half_t* q, long ldq, const half_t* Kp, const half_t* Vp, long item_stride, int H, int R,
                            int groups, int rows, const int* group_item, half_t* part_o, float* part_ml, hipStream_t s);
 
+// fused LayerNorm + cross-attention query projection + cross-attention partials: one launch for the two above it when
+// dec_cq_cross_attn_eligible (Whisper-small shapes)
+bool dec_cq_cross_attn_eligible(int d, int H, int R);
+void launch_dec_cq_cross_attn(const float* X, long ldx, const float* gamma, const float* beta, const half_t* Wp, const float* bias,
+                              float qscale, int d, const half_t* Kp, const half_t* Vp, long item_stride, int H, int R, int groups,
+                              int rows, const int* group_item, half_t* part_o, float* part_ml, hipStream_t s);
 // raw cross-attention scores of head h (tile-packed K of one layer AND item) for `rows` query rows -> out[rows][1536] fp32
 void launch_dec_align_scores(const half_t* q, long ldq, const half_t* Kp_item, int h, int rows, float* out, hipStream_t s);
 

@@ -1028,6 +1028,220 @@ __global__ __launch_bounds__(XA_TPS * 64) void dec_cross_attn_kernel(const half_
     WLX_TR_END(trc);
 }
 
+// ------------------------------------------------------------------ fused LayerNorm + cross-attention query + cross-attention
+// One launch instead of two (LN2 + q projection, then attention): the workgroup of (split, head, group) computes the
+// 64 query columns of ITS head for the group's <= 16 rows itself — LayerNorm of the rows (one wave per row, DPP), the
+// head's 4 n-tiles x KT k-tiles of Wcq streamed by its six waves (KT/6 k-tiles x 4 n-tiles each), K-reduction through
+// LDS — and goes straight on to its 32-key tiles. The eight split-workgroups of a head repeat the head's 96 KiB of Wcq;
+// the blockIdx -> (head, split) map puts them on ONE XCD (workgroup ids are dealt round-robin over the 8 XCDs), so the
+// repeats are L2 hits, not HBM reads. What it buys: one launch boundary (1.6 us) and one launch's fixed latency per
+// layer; what it costs: ~200 load instructions per CU instead of ~60 (2.2 us of issue at ~11 ns each).
+// Eligibility (launcher): d_model = 256 * LNV with KT % 6 == 0 — Whisper-small; other sizes keep the two launches.
+template <int LNV, int KPW>
+__global__ __launch_bounds__(XA_TPS * 64) void dec_cq_cross_attn_kernel(
+    const float* __restrict__ X, long ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+    const half_t* __restrict__ Wp, const float* __restrict__ bias, float qscale, int KT,
+    const half_t* __restrict__ Kp, const half_t* __restrict__ Vp, long item_stride, int H, int R, int rows,
+    const int* __restrict__ group_item, half_t* __restrict__ part_o, float* __restrict__ part_ml WLX_TR_PARAM) {
+    constexpr int TPS = XA_TPS;
+    static_assert(TPS == 6, "six waves: KT/6 k-tiles of the query projection and one key tile each");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    WLX_TR_BEGIN();
+    // ---- (head, split) of this workgroup: the 8 splits of a head share blockIdx % 8, i.e. one XCD
+    const int per_grp = H * WLX_XSPLIT;
+    const int grp = blockIdx.x / per_grp, wg = blockIdx.x - grp * per_grp;
+    int h, sp;
+    {
+        const int x = wg & 7, j = wg >> 3, full = H >> 3, rem = H & 7;
+        if (rem == 0 || rem == 4) {
+            if (j < 8 * full) { h = (j >> 3) * 8 + x; sp = j & 7; }
+            else { h = 8 * full + (x >> 1); sp = (x & 1) * 4 + (j - 8 * full); }
+        } else { h = wg >> 3; sp = wg & 7; }
+    }
+    const int d = KT * 32;
+    const int ldxs = d + 8;
+    // LDS: [0, xs_bytes) fp16 LayerNorm rows; then a region shared in time by the K-reduction partials and the
+    // attention merge buffers; then the 16 x 64 fp16 query tile
+    half_t* xs = reinterpret_cast<half_t*>(smem);
+    float* regB = smem + ((R * ldxs * 2 + 15) / 16) * 4;
+    float* accred = regB;                                                  // [6][4][64][4]
+    float (*Os)[16][68] = reinterpret_cast<float (*)[16][68]>(regB);       // [6][16][68]
+    float* MLs = regB + TPS * 16 * 68;                                     // [6][16][2]
+    half_t* qs = reinterpret_cast<half_t*>(MLs + TPS * 16 * 2);            // [16][72]
+
+    // ---- everything this wave will ever load, requested up front
+    const int kw0 = wave * KPW;
+    const half_t* wp = Wp + ((long)(h * 4) * KT + kw0) * 512 + lane * 8;
+    f16x8 wf[KPW][4];
+#pragma unroll
+    for (int j = 0; j < KPW; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) wf[j][i] = ld_nt_f16x8(wp + (long)i * KT * 512 + j * 512);
+    const int item = group_item[grp];
+    const int tile = sp * TPS + wave;
+    const int key0 = tile * 32;
+    const long toff = (long)item * item_stride + ((long)h * (WLX_T_AUDIO_PAD / 32) + tile) * 2048 + lane * 8;
+    f16x8 kf[2][2], vf[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) kf[s2][kt] = ld_f16x8(Kp + toff + (s2 * 2 + kt) * 512);
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) vf[dt] = ld_f16x8(Vp + toff + dt * 512);
+    const float4 bq4 = *reinterpret_cast<const float4*>(bias + h * 64 + (wave & 3) * 16 + g * 4);
+    const int nrow = (rows - grp * R < R) ? rows - grp * R : R;           // live rows of this group
+    {   // LayerNorm: wave w normalises rows w, w + 6, ... of the group
+        const float4* g4 = reinterpret_cast<const float4*>(gamma) + lane;
+        const float4* b4 = reinterpret_cast<const float4*>(beta) + lane;
+        float4 gq[LNV], bq[LNV];
+#pragma unroll
+        for (int j = 0; j < LNV; ++j) { gq[j] = g4[64 * j]; bq[j] = b4[64 * j]; }
+        constexpr float invK = 1.0f / (256.0f * LNV);
+#pragma unroll 1
+        for (int r = wave; r < nrow; r += TPS) {
+            const float4* x4 = reinterpret_cast<const float4*>(X + (long)(grp * R + r) * ldx) + lane;
+            float4 x[LNV];
+#pragma unroll
+            for (int j = 0; j < LNV; ++j) x[j] = x4[64 * j];
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < LNV; ++j) sm += (x[j].x + x[j].y) + (x[j].z + x[j].w);
+            const float mean = dpp_wave_sum(sm) * invK;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < LNV; ++j) {
+                x[j].x -= mean; x[j].y -= mean; x[j].z -= mean; x[j].w -= mean;
+                q += (x[j].x * x[j].x + x[j].y * x[j].y) + (x[j].z * x[j].z + x[j].w * x[j].w);
+            }
+            const float rstd = rsqrtf(dpp_wave_sum(q) * invK + 1e-5f);
+            half_t* dst = xs + r * ldxs + lane * 4;
+#pragma unroll
+            for (int j = 0; j < LNV; ++j) {
+                const f16x4 hv = {(half_t)(x[j].x * rstd * gq[j].x + bq[j].x), (half_t)(x[j].y * rstd * gq[j].y + bq[j].y),
+                                  (half_t)(x[j].z * rstd * gq[j].z + bq[j].z), (half_t)(x[j].w * rstd * gq[j].w + bq[j].w)};
+                *reinterpret_cast<f16x4*>(dst + 256 * j) = hv;
+            }
+        }
+    }
+    WLX_TR_MARK(1);
+    __syncthreads();
+    // ---- the head's query columns: this wave's K slice of all 4 n-tiles
+    const int crow = (c < nrow) ? c : nrow - 1;
+    f32x4 acc[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        const half_t* xr = xs + crow * ldxs + kw0 * 32 + g * 8;
+#pragma unroll
+        for (int j = 0; j < KPW; ++j) {
+            const f16x8 xf = *reinterpret_cast<const f16x8*>(xr + j * 32);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = mfma16(wf[j][i], xf, acc[i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(accred + ((wave * 4 + i) * 64 + lane) * 4) = acc[i];
+    __syncthreads();
+    if (wave < 4) {      // wave i finishes n-tile i: fixed-order sum over the six K slices, bias, q scale -> fp16 query tile
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < TPS; ++w) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(accred + ((w * 4 + wave) * 64 + lane) * 4);
+            v[0] += t[0]; v[1] += t[1]; v[2] += t[2]; v[3] += t[3];
+        }
+        const f16x4 hv = {(half_t)((v[0] + bq4.x) * qscale), (half_t)((v[1] + bq4.y) * qscale),
+                          (half_t)((v[2] + bq4.z) * qscale), (half_t)((v[3] + bq4.w) * qscale)};
+        *reinterpret_cast<f16x4*>(qs + c * 72 + wave * 16 + g * 4) = hv;     // query row c, head dims wave*16 + g*4 ..
+    }
+    WLX_TR_MARK(2);
+    __syncthreads();                                                        // qs complete; accred dead (Os aliases it)
+    f16x8 qf[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) qf[kt] = *reinterpret_cast<const f16x8*>(qs + c * 72 + kt * 32 + g * 8);
+
+    // ---- attention over this wave's tile: identical to dec_cross_attn_kernel from here on
+    constexpr int T = WLX_T_AUDIO;
+    f32x4 st[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        st[s2] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) st[s2] = mfma16(kf[s2][kt], qf[kt], st[s2]);
+    }
+    float pv[8];
+    float tmax = WLX_NEG_INF;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int key = key0 + s2 * 16 + g * 4 + r;
+            const float v = (key < T) ? st[s2][r] : WLX_NEG_INF;
+            pv[s2 * 4 + r] = v;
+            tmax = fmaxf(tmax, v);
+        }
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    const float msafe = (tmax == WLX_NEG_INF) ? 0.f : tmax;
+    float psum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { pv[i] = __expf(pv[i] - msafe); psum += pv[i]; }
+    psum += __shfl_xor(psum, 16, 64);
+    psum += __shfl_xor(psum, 32, 64);
+    const f16x8 pf = {(half_t)pv[0], (half_t)pv[1], (half_t)pv[2], (half_t)pv[3],
+                      (half_t)pv[4], (half_t)pv[5], (half_t)pv[6], (half_t)pv[7]};
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+        const f32x4 a = mfma16(vf[dt], pf, (f32x4){0.f, 0.f, 0.f, 0.f});
+        *reinterpret_cast<f32x4*>(&Os[wave][c][dt * 16 + g * 4]) = a;
+    }
+    if (g == 0) { MLs[(wave * 16 + c) * 2] = tmax; MLs[(wave * 16 + c) * 2 + 1] = psum; }
+    __syncthreads();
+    if (wave < 4) {
+        const int dt = wave;
+        float mw[TPS], lw[TPS];
+        float M = WLX_NEG_INF;
+#pragma unroll
+        for (int w = 0; w < TPS; ++w) { mw[w] = MLs[(w * 16 + c) * 2]; lw[w] = MLs[(w * 16 + c) * 2 + 1]; M = fmaxf(M, mw[w]); }
+        float l = 0.f;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < TPS; ++w) {
+            const float e = (mw[w] == WLX_NEG_INF) ? 0.f : __expf(mw[w] - M);
+            l += e * lw[w];
+            const f32x4 t = *reinterpret_cast<const f32x4*>(&Os[w][c][dt * 16 + g * 4]);
+            o[0] += e * t[0]; o[1] += e * t[1]; o[2] += e * t[2]; o[3] += e * t[3];
+        }
+        const long ih = (long)grp * H + h;
+        const float inv = 1.0f / l;
+        const f16x4 hv = {(half_t)(o[0] * inv), (half_t)(o[1] * inv), (half_t)(o[2] * inv), (half_t)(o[3] * inv)};
+        *reinterpret_cast<f16x4*>(part_o + ((ih * WLX_XSPLIT + sp) * 16 + c) * 64 + dt * 16 + g * 4) = hv;
+        if (dt == 0 && g == 0) *reinterpret_cast<float2*>(part_ml + (ih * 16 + c) * (WLX_XSPLIT * 2) + sp * 2) = make_float2(M, l);
+    }
+    WLX_TR_MARK(3);
+    WLX_TR_END(trc);
+}
+
+// eligibility: d_model 768 (LNV = 3, KT = 24 = 6 waves x 4 k-tiles), groups of <= 16 rows; WLX_NO_FUSED_CQ=1 forces the
+// two separate launches (A/B)
+bool dec_cq_cross_attn_eligible(int d, int H, int R) {
+    static const bool off = [] { const char* e = getenv("WLX_NO_FUSED_CQ"); return e && e[0] == '1'; }();
+    if (off || g_decode_v1 || d != 768 || H * 64 != d || R < 1 || R > 16) return false;
+    const size_t xs_floats = (size_t)((R * (d + 8) * 2 + 15) / 16) * 4;
+    const size_t shm = sizeof(float) * (xs_floats + (size_t)XA_TPS * 16 * 68 + XA_TPS * 16 * 2) + 16 * 72 * sizeof(half_t);
+    return shm <= 64 * 1024;
+}
+void launch_dec_cq_cross_attn(const float* X, long ldx, const float* gamma, const float* beta, const half_t* Wp, const float* bias,
+                              float qscale, int d, const half_t* Kp, const half_t* Vp, long item_stride, int H, int R, int groups,
+                              int rows, const int* group_item, half_t* part_o, float* part_ml, hipStream_t s) {
+    const int KT = d / 32;
+    const size_t xs_floats = (size_t)((R * (d + 8) * 2 + 15) / 16) * 4;
+    const size_t shm = sizeof(float) * (xs_floats + (size_t)XA_TPS * 16 * 68 + XA_TPS * 16 * 2) + 16 * 72 * sizeof(half_t);
+    hipLaunchKernelGGL((dec_cq_cross_attn_kernel<3, 4>), dim3(H * WLX_XSPLIT * groups), dim3(XA_TPS * 64), shm, s, X, ldx, gamma, beta,
+                       Wp, bias, qscale, KT, Kp, Vp, item_stride, H, R, rows, group_item, part_o, part_ml WLX_TR_ARG("cq_cross_attn"));
+}
+
 // ------------------------------------------------------------------ cross-attention scores of one head, for word alignment
 // (ctranslate2 Whisper.align, called from transcriber_faster_whisper.py:1657: the QK of the alignment heads over a
 // teacher-forced pass). Raw scores q.k (q already carries head_dim^-0.5) of `rows` query rows against the 1536 padded

@@ -721,23 +721,33 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
         p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
         p.Wp = w.Wo; p.bias = w.bo; p.Xh = s->attnd; p.ldxh = d; p.Xres = s->xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
         pgemv(s, p);
-        // LN2 + cross-attention query
-        p = GemvParams{};
-        p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_F16; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
-        p.Wp = w.Wcq; p.bias = w.bcq; p.X = s->xd; p.ldx = d; p.gamma = w.ln2_g; p.beta = w.ln2_b;
-        p.Yh = s->qd; p.ldyh = d; p.qscale = 0.125f; p.done = done;
-        pgemv(s, p);
-        if (s->align) {     // word alignment: raw q.k of this layer's alignment heads for the rows of this chunk
-            const Slot::AlignCapture& a = *s->align;
-            for (int hi = 0; hi < a.n_heads; ++hi)
-                if (a.heads[2 * hi] == l)
-                    launch_dec_align_scores(s->qd, d, s->ck + ((size_t)l * s->B + a.item) * WLX_T_AUDIO_PAD * d, a.heads[2 * hi + 1], rows,
-                                            a.scores + ((size_t)hi * a.n_tok + a.row0) * WLX_T_AUDIO_PAD, st);
+        // LN2 + cross-attention query + cross-attention partials: one fused launch when the shape allows and nobody needs
+        // the query rows (word alignment captures them), else projection and attention separately
+        const half_t* ckl = s->ck + (size_t)l * s->B * WLX_T_AUDIO_PAD * d;
+        const half_t* cvl = s->cvt + (size_t)l * s->B * d * WLX_T_AUDIO_PAD;
+        const bool fused = !s->align && dec_cq_cross_attn_eligible(d, H, R);
+        if (fused)
+            plaunch(s, "dec_cq_cross_attn_kernel", 2.0 * d * d + 4.0 * groups * WLX_T_AUDIO * d, [&] {
+                launch_dec_cq_cross_attn(s->xd, d, w.ln2_g, w.ln2_b, w.Wcq, w.bcq, 0.125f, d, ckl, cvl, (long)WLX_T_AUDIO_PAD * d, H, R,
+                                         groups, rows, s->d_group_item, s->part_o, s->part_ml, st);
+            });
+        if (!fused) {
+            p = GemvParams{};
+            p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_F16; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
+            p.Wp = w.Wcq; p.bias = w.bcq; p.X = s->xd; p.ldx = d; p.gamma = w.ln2_g; p.beta = w.ln2_b;
+            p.Yh = s->qd; p.ldyh = d; p.qscale = 0.125f; p.done = done;
+            pgemv(s, p);
+            if (s->align) {     // word alignment: raw q.k of this layer's alignment heads for the rows of this chunk
+                const Slot::AlignCapture& a = *s->align;
+                for (int hi = 0; hi < a.n_heads; ++hi)
+                    if (a.heads[2 * hi] == l)
+                        launch_dec_align_scores(s->qd, d, s->ck + ((size_t)l * s->B + a.item) * WLX_T_AUDIO_PAD * d, a.heads[2 * hi + 1], rows,
+                                                a.scores + ((size_t)hi * a.n_tok + a.row0) * WLX_T_AUDIO_PAD, st);
+            }
+            plaunch(s, "dec_cross_attn_kernel", 4.0 * groups * WLX_T_AUDIO * d, [&] {
+                launch_dec_cross_attn(s->qd, d, ckl, cvl, (long)WLX_T_AUDIO_PAD * d, H, R, groups, rows, s->d_group_item, s->part_o, s->part_ml, st);
+            });
         }
-        plaunch(s, "dec_cross_attn_kernel", 4.0 * groups * WLX_T_AUDIO * d, [&] {
-            launch_dec_cross_attn(s->qd, d, s->ck + (size_t)l * s->B * WLX_T_AUDIO_PAD * d, s->cvt + (size_t)l * s->B * d * WLX_T_AUDIO_PAD,
-                                  (long)WLX_T_AUDIO_PAD * d, H, R, groups, rows, s->d_group_item, s->part_o, s->part_ml, st);
-        });
         p = GemvParams{};
         p.in_mode = GEMV_IN_XATTN; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
         p.Wp = w.Wco; p.bias = w.bco; p.part_o = s->part_o; p.part_ml = s->part_ml; p.H = H; p.R = R;
