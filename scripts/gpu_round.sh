@@ -1,6 +1,6 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): GPU parity tests, bench line, A/B against the first-generation decode
-# kernels, rocprofv3 kernel stats of the same bench command.  usage: scripts/gpu_round.sh <tag> [--skip-tests]
+# Runs on the GPU box (via gpurun): GPU parity tests, bench line, rocprofv3 kernel stats of the same bench command,
+# the FETCH_SIZE PMC pass (its own run), and the batched / large-v3 bench lines.  usage: scripts/gpu_round.sh <tag> [--skip-tests]
 set -u
 TAG=${1:-r01}; shift || true
 SKIP_TESTS=0; [ "${1:-}" = "--skip-tests" ] && SKIP_TESTS=1
@@ -41,4 +41,10 @@ cd "$REPO"
 python scripts/pmc_summary.py "$OUT/pmc_fetch" > "$OUT/pmc_fetch_summary.csv" 2>&1; head -30 "$OUT/pmc_fetch_summary.csv"
 find "$OUT" -name '*kernel_trace.csv' -size +5M -delete
 find "$OUT" -name '*counter_collection.csv' -size +5M -delete
+for B in 4 6; do
+  timeout 300 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --batch $B > "$OUT/bench_batch$B.json" 2> "$OUT/bench_batch$B.err"
+  python -c "import json; d=json.loads(open('$OUT/bench_batch$B.json').read().strip().splitlines()[-1]); print('batch', $B, 'xRT', round(d['value'],1), 'ms/step', round(d['ms_per_step'],2))" || tail -3 "$OUT/bench_batch$B.err"
+done
+timeout 500 python bench.py --model large-v3 --steps 3 --warmup 1 --no-cpu-baseline > "$OUT/bench_large_v3.json" 2> "$OUT/bench_large_v3.err"
+python -c "import json; d=json.loads(open('$OUT/bench_large_v3.json').read().strip().splitlines()[-1]); print('large-v3 xRT', round(d['value'],1), 'ms/step', round(d['ms_per_step'],2), d['stage_ms'], 'step graph ms', d['decode_step']['graph_replay_ms'])" || tail -3 "$OUT/bench_large_v3.err"
 du -sh "$OUT"

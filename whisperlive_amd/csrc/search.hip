@@ -515,7 +515,13 @@ __device__ __forceinline__ float s3_wave_max(float v) { return dpp_wave_max(v); 
 // compiles to exec-mask control flow, ~20 instructions per butterfly step
 __device__ __forceinline__ void s3_wave_argmax(float& v, int& i) {
     const float m = dpp_wave_max(v);
-    i = dpp_wave_min_i32((v == m) ? i : 0x7fffffff);
+    // the lanes that hold the maximum: almost always exactly one -> read its id directly; only a tie (or an exhausted
+    // wave: every lane at -inf) needs the second reduction for the smallest id
+    const unsigned long long hit = __ballot(v == m);
+    int id;
+    if (__builtin_popcountll(hit) == 1) id = __builtin_amdgcn_readlane(i, (int)__builtin_ctzll(hit));
+    else id = dpp_wave_min_i32((v == m) ? i : 0x7fffffff);
+    i = id;
     v = m;
 }
 // the same over each 16-lane row separately (result in every lane of the row)
@@ -672,16 +678,26 @@ __global__ __launch_bounds__(SC_THREADS) void search_scan3_kernel(const float* _
             s3_wave_argmax(gv, gi);
             if (lane == 0) { wv_s[wave][k] = gv; wi_s[wave][k] = gi; }
             if (gi != 0x7fffffff && ((gi - id0) & (SC_THREADS - 1)) == tid) {
-                bv = WLX_NEG_INF; bi = 0x7fffffff;
+                // the owner retires the winner and finds its next best: pairwise tree (depth 3) instead of a chain of 8;
+                // a tie keeps the LEFT operand = the smaller id (ids ascend with i)
+                float tv[SC_NPT]; int ti_[SC_NPT];
 #pragma unroll
                 for (int i = 0; i < SC_NPT; ++i) {
                     const int id = id0 + i * SC_THREADS + tid;
                     if (id == gi) w[i] = WLX_NEG_INF;
-                    if (w[i] > bv) { bv = w[i]; bi = id; }
+                    tv[i] = w[i]; ti_[i] = (w[i] > WLX_NEG_INF) ? id : 0x7fffffff;
                 }
+#pragma unroll
+                for (int stp = 1; stp < SC_NPT; stp <<= 1)
+#pragma unroll
+                    for (int i = 0; i + stp < SC_NPT; i += 2 * stp)
+                        if (tv[i + stp] > tv[i]) { tv[i] = tv[i + stp]; ti_[i] = ti_[i + stp]; }
+                bv = tv[0]; bi = ti_[0];
             }
         }
+        WLX_TR_MARK(3);
         __syncthreads();
+        WLX_TR_MARK(4);
         if (wave == 0) {
             if (lane == 0) {
                 float* so = st.scan_stats + ((long)r * SC_MAXCH + chunk) * SC_NSTAT;
@@ -709,7 +725,7 @@ __global__ __launch_bounds__(SC_THREADS) void search_scan3_kernel(const float* _
             }
         }
     }
-    WLX_TR_MARK(3);
+    WLX_TR_MARK(5);
     WLX_TR_END(trc);
 }
 
