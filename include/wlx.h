@@ -202,7 +202,7 @@ typedef struct {
     double bytes_per_launch;
 } wlx_kernel_stat;
 /* In-kernel timeline of one decode step. Only libwlx_trace.so (the same sources built with -DWLX_TRACE) records;
- * the production library returns WLX_ERR_STATE. out: [n_launches][(2048 + 1) * 8] u64 (n_launches <= 128), names: [n_launches][48]. */
+ * the production library returns WLX_ERR_STATE. out: [n_launches][(2048 + 1) * 8] u64 (n_launches <= 320), names: [n_launches][48]. */
 int32_t wlx_debug_trace_step(wlx_engine* e, int32_t slot, int32_t rows, int32_t t, int32_t with_search,
                              uint64_t* out, int64_t cap_u64, char* names, int32_t* n_launches_out);
 

@@ -35,6 +35,7 @@ struct GemvParams {
     int KTW;                                 // (set by the launcher) k-tiles per wave, even
     int NCH;                                 // (set by the launcher, lean kernel) chunks of CH k-tiles per wave
     int nwm;                                 // (set by the launcher, lean kernel, XATTN) waves that stream weights
+    int xstage;                              // (set by the launcher, lean kernel, F16) activation rows staged through LDS
     const half_t* Wp; const float* bias;
     // GEMV_IN_LN
     const float* X; long ldx; const float* gamma; const float* beta;

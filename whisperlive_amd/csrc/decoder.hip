@@ -464,7 +464,7 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
     if constexpr (IN == GEMV_IN_F16) {
         const half_t* xr[MT];
         int xstep;                                                          // halfs between k-tiles of a row
-        if constexpr (MT == 1) {
+        if (MT == 1 && p.xstage) {
             // One stream (M <= 16): the fp16 rows go through LDS — fetching B fragments straight from global costs CH
             // loads per wave of 64-byte pieces (16 waves x 6 = 96 load instructions per workgroup for K = 3072, as many
             // as the weights; a CU retires one per ~11 ns), the cooperative copy M * K / 8 / 64 = 30.
@@ -475,7 +475,8 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
             xr[0] = xs + crow[0] * ldxs + kw0 * 32 + g * 8;                 // lanes of rows >= M re-read a valid row (never stored)
             xstep = 32;
         } else {
-            // batched rows: M x K fp16 no longer fits the LDS budget for K = 3072 — fragments straight from global
+            // batched rows, or K too large for the LDS budget (large-v3 fc2: 5 x 5120 fp16 + partials > 64 KiB):
+            // fragments straight from global
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) xr[mt] = p.Xh + (long)crow[mt] * p.ldxh + kw0 * 32 + g * 8;
             xstep = 32;
@@ -683,7 +684,7 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
     WLX_TR_END_WAVES(p.trc);
 }
 
-struct Gemv2Cfg { bool ok; int nw, CH, NCH, LNV, NTB, MT; size_t shm; };
+struct Gemv2Cfg { bool ok, xstage; int nw, CH, NCH, LNV, NTB, MT; size_t shm; };
 static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     Gemv2Cfg c{};
     c.ok = false;
@@ -717,7 +718,10 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     c.NTB = (p.out_mode == GEMV_OUT_F32 && p.N > 8192) ? 2 : 1;
     c.MT = (p.M + 15) / 16;
     c.shm = sizeof(float) * (size_t)c.nw * c.NTB * c.MT * 256;
-    if (!(p.in_mode == GEMV_IN_F16 && c.MT > 1)) c.shm += (size_t)p.M * (p.K + 8) * sizeof(half_t);   // fp16 activation rows
+    const size_t xs_bytes = (size_t)p.M * (p.K + 8) * sizeof(half_t);  // fp16 activation rows
+    c.xstage = true;
+    if (p.in_mode == GEMV_IN_F16 && (c.MT > 1 || c.shm + xs_bytes > 64 * 1024)) c.xstage = false;   // fragments from global instead
+    if (c.xstage) c.shm += xs_bytes;
     if (c.shm > 64 * 1024) return c;                                   // beyond the default dynamic-LDS limit: older kernel
     c.ok = true;
     return c;
@@ -745,7 +749,7 @@ static bool gemv2_launch_other(const GemvParams& p, const Gemv2Cfg& c, dim3 grid
 // the (CH, LNV) pairs of the Whisper family: d_model 512 (4,2), 768 (6,3), 1024 (4,4), 1280 (5,5)
 static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s) {
     GemvParams p = p0;
-    p.KTW = c.CH * c.NCH; p.NCH = c.NCH;
+    p.KTW = c.CH * c.NCH; p.NCH = c.NCH; p.xstage = c.xstage ? 1 : 0;
 #ifdef WLX_TRACE
     { static thread_local char nm[512][48]; const int q = g_trace_seq < 512 ? g_trace_seq : 511;
       snprintf(nm[q], 48, "gemv2<%d,%d> N%d K%d", p.in_mode, p.out_mode, p.N, p.K); p.trc = trace_next(nm[q]); }

@@ -1381,7 +1381,7 @@ extern "C" int32_t wlx_debug_trace_step(wlx_engine* e, int32_t slot, int32_t row
     std::vector<int> tk(rows, 0), ps(rows, t), ca(rows), an(rows), gi(1, 0);
     std::vector<short> anc((size_t)rows * WLX_T_TEXT);
     for (int r = 0; r < rows; ++r) { ca[r] = an[r] = r; for (int p = 0; p < WLX_T_TEXT; ++p) anc[(size_t)r * WLX_T_TEXT + p] = (short)r; }
-    const size_t max_launch = 128;
+    const size_t max_launch = 320;
     unsigned long long* buf = nullptr;
     CK(hipMalloc(&buf, max_launch * WLX_TR_STRIDE * 8));
     g_trace_buf = buf; g_trace_seq = 0;
@@ -1405,6 +1405,7 @@ extern "C" int32_t wlx_debug_trace_step(wlx_engine* e, int32_t slot, int32_t row
     CK(hipGraphDestroy(graph));
     const int n = g_trace_seq;
     g_trace_buf = nullptr;
+    if (n > (int)max_launch) { (void)hipGraphExecDestroy(exec); (void)hipFree(buf); return fail(WLX_ERR_ARG, "trace: %d launches exceed the trace buffer (%d)", n, (int)max_launch); }
     for (int i = 0; i < 3; ++i) { CKR(reset_state()); CK(hipGraphLaunch(exec, st)); }
     CKR(reset_state());
     CK(hipMemsetAsync(buf, 0, max_launch * WLX_TR_STRIDE * 8, st));

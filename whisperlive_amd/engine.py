@@ -260,7 +260,7 @@ class Slot:
     def debug_trace_step(self, rows: int, t: int, with_search: bool = True):
         """In-kernel timeline of one decode step (libwlx_trace.so only). Returns (names, records[n][2049][8] u64); record 0 of a launch is unused."""
         stride = (2048 + 1) * 8
-        cap_launch = 128
+        cap_launch = 320
         buf = np.zeros(cap_launch * stride, dtype=np.uint64)
         names = C.create_string_buffer(cap_launch * 48)
         n = C.c_int32(0)
