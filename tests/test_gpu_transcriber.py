@@ -139,3 +139,50 @@ def test_batch_worker_on_device_equals_single_requests(pair):
     [t.start() for t in ths]; [t.join(60) for t in ths]
     seq = [hip.transcribe(clips[i], language="en", temperature=0.0, max_new_tokens=12)[0] for i in range(3)]
     assert [[s.tokens for s in o] for o in outs] == [[s.tokens for s in o] for o in seq]
+
+
+def test_websocket_server_end_to_end_on_the_engine(pair):
+    """Stock-protocol clients over loopback sockets -> TranscriptionServer -> ServeClientHIP -> libwlx.so. The first
+    transcript each client receives must carry exactly the text the transcriber returns for that audio when called
+    directly (the server adds transport, not arithmetic)."""
+    import json
+    from whisperlive_amd import metrics, ws
+    from whisperlive_amd.serve_client import ServeClientHIP
+    from whisperlive_amd.server import TranscriptionServer
+    hip, _ = pair
+    metrics.snapshot(reset=True)
+    ServeClientHIP.MODELS.clear()
+    srv, ready = TranscriptionServer(), threading.Event()
+    t = threading.Thread(target=srv.run, args=("127.0.0.1",), daemon=True,
+                         kwargs=dict(port=0, ready=ready, single_model=True, max_clients=2, model_factory=lambda m, d: hip))
+    t.start()
+    assert ready.wait(10)
+    try:
+        pcms = [olm.speech_like_pcm(6.0, seed=s) for s in (31, 32)]
+        want = []
+        for pcm in pcms:
+            segs, _info = hip.transcribe(pcm, language="en", task="transcribe", vad_filter=False)
+            assert segs
+            kept = [s for s in segs[:-1] if s.start < min(6.0, s.end)] + [segs[-1]]   # update_segments' commit rule
+            want.append("".join(s.text for s in kept))
+        conns = []
+        for i, pcm in enumerate(pcms):
+            c = ws.connect(f"ws://127.0.0.1:{srv.port}")
+            c.send(json.dumps(dict(uid=f"c{i}", language="en", task="transcribe", model="x.en", use_vad=False,
+                                   no_speech_thresh=1.0)))
+            assert json.loads(c.recv(timeout=20))["message"] == "SERVER_READY"
+            conns.append(c)
+        for c, pcm in zip(conns, pcms):
+            c.send(pcm.tobytes())                          # one 6 s packet: the first chunk is exactly this audio
+        for i, c in enumerate(conns):
+            msg = json.loads(c.recv(timeout=30))
+            assert msg["uid"] == f"c{i}" and msg["segments"]
+            got = "".join(s["text"] for s in msg["segments"])
+            assert got == want[i], (got, want[i])
+            c.send(b"END_OF_AUDIO")
+        snap = metrics.snapshot()
+        assert snap["errors"] == {} and snap["chunks"] >= 2 and snap["connections"]["opened"] == 2, snap
+    finally:
+        srv.shutdown()
+        t.join(5)
+        ServeClientHIP.MODELS.clear()

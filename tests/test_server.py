@@ -1,0 +1,405 @@
+"""CPU tests of the WebSocket server shell. The contract is the reference's own
+tests/test_server_extended.py (ClientManager add/remove/full/timeout/wait-time :14-170, BackendType :172-196, run()
+argument validation :198-245, get_audio_from_websocket formats :247-296, handle_new_connection :298-325, cleanup
+:327-340, WebSocket auth :658-700) plus what the reference gets from the `websockets` package and we have to supply
+ourselves: RFC 6455 framing, and an end-to-end session over a real loopback socket (the shape of
+tests/test_server.py:73-118 with a scripted transcriber instead of base.en)."""
+import json
+import socket
+import struct
+import threading
+import time
+from types import SimpleNamespace
+from unittest.mock import MagicMock
+
+import numpy as np
+import pytest
+
+from whisperlive_amd import metrics, ws
+from whisperlive_amd.serve_client import ServeClientHIP
+from whisperlive_amd.server import BackendType, ClientManager, TranscriptionServer, _websocket_auth
+
+
+# ---- ClientManager ---------------------------------------------------------------------------------------------------
+def test_client_manager_add_get_remove():
+    m = ClientManager(max_clients=2, max_connection_time=10)
+    w, c = MagicMock(), MagicMock()
+    assert m.get_client(w) is False
+    m.add_client(w, c)
+    assert m.get_client(w) is c and w in m.start_times
+    m.remove_client(w)
+    c.cleanup.assert_called_once()
+    assert m.get_client(w) is False and w not in m.start_times
+    m.remove_client(MagicMock())                        # unknown socket: no error
+
+
+def test_client_manager_concurrent_add_remove():
+    m = ClientManager(max_clients=1000)
+    socks = [MagicMock() for _ in range(64)]
+    errs = []
+
+    def work(lo):
+        try:
+            for w in socks[lo: lo + 16]:
+                m.add_client(w, MagicMock())
+                assert m.get_client(w)
+                m.remove_client(w)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ts = [threading.Thread(target=work, args=(i * 16,)) for i in range(4)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errs and not m.clients and not m.start_times
+
+
+def test_client_manager_full_sends_wait_in_minutes():
+    m = ClientManager(max_clients=1, max_connection_time=600)
+    new = MagicMock()
+    assert m.is_server_full(new, {"uid": "a"}) is False
+    new.send.assert_not_called()
+    m.add_client(MagicMock(), MagicMock())
+    assert m.is_server_full(new, {"uid": "b"}) is True
+    msg = json.loads(new.send.call_args[0][0])
+    assert msg["uid"] == "b" and msg["status"] == "WAIT" and 9.9 < msg["message"] <= 10.0
+
+
+def test_client_manager_timeout_disconnects():
+    m = ClientManager(max_clients=2, max_connection_time=5)
+    w, c = MagicMock(), MagicMock()
+    m.add_client(w, c)
+    assert m.is_client_timeout(w) is False
+    c.disconnect.assert_not_called()
+    m.start_times[w] -= 6
+    assert m.is_client_timeout(w) is True
+    c.disconnect.assert_called_once()
+
+
+def test_client_manager_wait_time_is_minimum_remaining():
+    m = ClientManager(max_clients=4, max_connection_time=600)
+    assert m.get_wait_time() == 0
+    a, b = MagicMock(), MagicMock()
+    m.add_client(a, MagicMock())
+    m.add_client(b, MagicMock())
+    m.start_times[a] -= 300
+    m.start_times[b] -= 480
+    assert abs(m.get_wait_time() - 2.0) < 0.05
+
+
+# ---- BackendType / run() validation -----------------------------------------------------------------------------------
+def test_backend_type():
+    assert set(BackendType.valid_types()) == {"faster_whisper", "tensorrt", "openvino", "hip"}
+    assert BackendType.is_valid("hip") and BackendType.is_valid("faster_whisper") and not BackendType.is_valid("x")
+    assert BackendType("tensorrt").is_tensorrt() and BackendType.HIP.is_hip() and BackendType.OPENVINO.is_openvino()
+    assert BackendType("faster_whisper").is_faster_whisper() and not BackendType.HIP.is_faster_whisper()
+    with pytest.raises(ValueError):
+        BackendType("nope")
+
+
+def test_server_defaults_and_run_validation(tmp_path):
+    s = TranscriptionServer()
+    assert s.client_manager is None and s.use_vad is True and s.single_model is False and s.batch_config is None
+    assert s.raw_pcm_input is False and s.RATE == 16000
+    with pytest.raises(ValueError, match="not a valid backend"):
+        s.run("127.0.0.1", port=0, backend="bogus")
+    with pytest.raises(ValueError, match="TensorRT model"):
+        s.run("127.0.0.1", port=0, backend="tensorrt", whisper_tensorrt_path=str(tmp_path / "missing"))
+    with pytest.raises(ValueError, match="not a valid path"):
+        s.run("127.0.0.1", port=0, faster_whisper_custom_model_path=str(tmp_path / "missing"))
+    for kw, pat in [(dict(max_clients=0), "max_clients"), (dict(max_clients=-1), "max_clients"),
+                    (dict(max_connection_time=0), "max_connection_time"),
+                    (dict(batch_enabled=True, batch_max_size=0), "batch_max_size"),
+                    (dict(batch_enabled=True, batch_window_ms=-1), "batch_window_ms")]:
+        with pytest.raises(ValueError, match=pat):
+            s.run("127.0.0.1", port=0, **kw)
+    with pytest.raises(NotImplementedError):
+        s.run("127.0.0.1", port=0, enable_rest=True)
+    assert s.configure(batch_enabled=True, batch_max_size=4, batch_window_ms=20) == BackendType.HIP
+    assert s.single_model is True and s.batch_config == {"max_batch_size": 4, "batch_window_ms": 20}
+    s.configure(devices=[2, 3])
+    assert [s._next_device() for _ in range(5)] == [2, 3, 2, 3, 2]
+
+
+# ---- socket bytes -> PCM ------------------------------------------------------------------------------------------
+def test_get_audio_from_websocket_formats():
+    s = TranscriptionServer()
+    w = MagicMock()
+    w.recv.return_value = b"END_OF_AUDIO"
+    assert s.get_audio_from_websocket(w) is False
+    x = np.array([0.25, -0.5, 1.0], np.float32)
+    w.recv.return_value = x.tobytes()
+    out = s.get_audio_from_websocket(w)
+    assert out.dtype == np.float32 and np.array_equal(out, x)
+    i16 = np.array([0, 16384, -32768, 32767], np.int16)
+    s.raw_pcm_input = True
+    w.recv.return_value = i16.tobytes()
+    assert np.array_equal(s.get_audio_from_websocket(w), i16.astype(np.float32) / 32768.0)
+    s.raw_pcm_input = False
+    s.audio_formats[w] = "int16"
+    assert np.array_equal(s.get_audio_from_websocket(w), i16.astype(np.float32) / 32768.0)
+    s.audio_formats[w] = "uint8"
+    w.recv.return_value = bytes([0, 128, 255])
+    assert np.allclose(s.get_audio_from_websocket(w), [-1.0, 0.0, 127 / 128])
+    s.audio_formats[w] = "float32"
+    w.recv.return_value = "text frame"
+    with pytest.raises(ValueError):
+        s.get_audio_from_websocket(w)
+
+
+def test_handle_new_connection_rejections():
+    s = TranscriptionServer()
+    s.configure(max_clients=1)
+    w = MagicMock()
+    w.recv.return_value = "not json {"
+    assert s.handle_new_connection(w, None, None, False) is False
+    w.recv.return_value = json.dumps({"uid": "u", "audio_format": "mp3", "language": "en", "task": "transcribe", "model": "m"})
+    assert s.handle_new_connection(w, None, None, False) is False and w not in s.audio_formats
+    s.client_manager.add_client(MagicMock(), MagicMock())
+    before = metrics.snapshot()["connections"]["rejected"]
+    w.recv.return_value = json.dumps({"uid": "u2"})
+    assert s.handle_new_connection(w, None, None, False) is False
+    assert json.loads(w.send.call_args[0][0])["status"] == "WAIT"
+    w.close.assert_called_once()
+    assert metrics.snapshot()["connections"]["rejected"] == before + 1
+    w.recv.side_effect = ws.ConnectionClosed(1001)
+    assert s.handle_new_connection(w, None, None, False) is False
+
+
+def test_cleanup_removes_client_and_format():
+    s = TranscriptionServer()
+    s.configure()
+    w, c = MagicMock(), MagicMock()
+    s.client_manager.add_client(w, c)
+    s.audio_formats[w] = "int16"
+    s.cleanup(w)
+    c.cleanup.assert_called_once()
+    assert s.client_manager.get_client(w) is False and w not in s.audio_formats
+
+
+def test_websocket_auth_rule():
+    conn = MagicMock()
+    conn.respond.return_value = "401"
+    req = lambda path, hdr: SimpleNamespace(path=path, headers=ws.Headers({k.lower(): v for k, v in hdr.items()}))
+    assert _websocket_auth("k", conn, req("/", {"Authorization": "Bearer k"})) is None
+    assert _websocket_auth("k", conn, req("/", {"Authorization": "Bearer x"})) == "401"
+    assert _websocket_auth("k", conn, req("/", {})) == "401"
+    assert _websocket_auth("k", conn, req("/?token=k", {})) is None
+    assert _websocket_auth("k", conn, req("/?token=x", {})) == "401"
+
+
+# ---- RFC 6455 framing ---------------------------------------------------------------------------------------------
+def test_accept_key_known_answer():
+    # RFC 6455 §1.3 example
+    assert ws.accept_key("dGhlIHNhbXBsZSBub25jZQ==") == "s3pPLMBiTxaQ9kYGzzhZRbK+xOo="
+
+
+@pytest.mark.parametrize("n", [0, 1, 125, 126, 127, 65535, 65536, 200000])
+@pytest.mark.parametrize("mask", [False, True])
+def test_frame_codec_round_trip(n, mask):
+    payload = np.random.default_rng(n).integers(0, 256, n, dtype=np.uint8).tobytes()
+    raw = ws.encode_frame(ws.OP_BINARY, payload, mask=mask)
+    hdr = 2 + (0 if n < 126 else 2 if n < 65536 else 8) + (4 if mask else 0)
+    assert len(raw) == hdr + n
+    a, b = socket.socketpair()
+    try:
+        threading.Thread(target=a.sendall, args=(raw,), daemon=True).start()
+        fin, op, got = ws.read_frame(ws._Reader(b), expect_mask=mask)
+        assert fin and op == ws.OP_BINARY and got == payload
+    finally:
+        a.close(); b.close()
+
+
+def test_rfc_masked_hello_known_answer():
+    # RFC 6455 §5.7: masked "Hello"
+    raw = bytes([0x81, 0x85, 0x37, 0xFA, 0x21, 0x3D, 0x7F, 0x9F, 0x4D, 0x51, 0x58])
+    a, b = socket.socketpair()
+    try:
+        a.sendall(raw)
+        assert ws.read_frame(ws._Reader(b), expect_mask=True) == (True, ws.OP_TEXT, b"Hello")
+    finally:
+        a.close(); b.close()
+
+
+def _pair():
+    a, b = socket.socketpair()
+    return ws.Connection(a, ws._Reader(a), is_client=True), ws.Connection(b, ws._Reader(b), is_client=False)
+
+
+def test_connection_text_binary_fragments_ping_close():
+    c, s = _pair()
+    c.send("héllo")
+    c.send(b"\x00\x01\x02")
+    assert s.recv() == "héllo" and s.recv() == b"\x00\x01\x02"
+    # fragmented text with a ping in the middle: the ping is answered, the message is reassembled
+    c.sock.sendall(ws.encode_frame(ws.OP_TEXT, b"ab", mask=True, fin=False) + ws.encode_frame(ws.OP_PING, b"p", mask=True)
+                   + ws.encode_frame(ws.OP_CONT, b"cd", mask=True, fin=True))
+    assert s.recv() == "abcd"
+    assert ws.read_frame(c._rd, expect_mask=False) == (True, ws.OP_PONG, b"p")
+    # an unmasked client frame is a protocol error
+    c.sock.sendall(ws.encode_frame(ws.OP_TEXT, b"x", mask=False))
+    with pytest.raises(ws.ConnectionClosed):
+        s.recv()
+    c2, s2 = _pair()
+    t = threading.Thread(target=c2.close, kwargs=dict(code=1000, reason="bye"))
+    t.start()
+    with pytest.raises(ws.ConnectionClosed) as ei:
+        s2.recv()
+    t.join()
+    assert ei.value.code == 1000 and ei.value.reason == "bye"
+    with pytest.raises(ws.ConnectionClosed):
+        s2.send("late")
+    s2.close()                                           # idempotent
+
+
+# ---- end to end over loopback ---------------------------------------------------------------------------------------
+class ScriptedTranscriber:
+    """Duck type of the transcriber: one segment per call covering the chunk, text = chunk stats."""
+
+    def __init__(self):
+        self.calls = []
+
+    def transcribe(self, audio, **kw):
+        self.calls.append((audio.copy(), kw))
+        dur = audio.shape[0] / 16000.0
+        seg = [SimpleNamespace(start=0.0, end=min(dur, 2.0), text=f" n{len(self.calls)}", no_speech_prob=0.0, words=None),
+               SimpleNamespace(start=min(dur, 2.0), end=dur, text=" tail", no_speech_prob=0.0, words=None)]
+        return seg, SimpleNamespace(language="en", language_probability=0.99)
+
+
+@pytest.fixture
+def running_server():
+    started = []
+
+    def start(**kw):
+        srv, ready = TranscriptionServer(), threading.Event()
+        kw.setdefault("model_factory", lambda model, dev: ScriptedTranscriber())
+        t = threading.Thread(target=srv.run, args=("127.0.0.1",), kwargs=dict(port=0, ready=ready, **kw), daemon=True)
+        t.start()
+        assert ready.wait(10)
+        started.append((srv, t))
+        return srv
+
+    ServeClientHIP.MODELS.clear()
+    yield start
+    for srv, t in started:
+        srv.shutdown()
+        t.join(5)
+    ServeClientHIP.MODELS.clear()
+
+
+OPTS = dict(uid="u1", language="en", task="transcribe", model="small.en", use_vad=False, send_last_n_segments=10,
+            no_speech_thresh=0.45, clip_audio=False, same_output_threshold=10)
+
+
+def _recv_json(c, timeout=10.0):
+    return json.loads(c.recv(timeout=timeout))
+
+
+def test_e2e_stream_float32_packets_get_segments(running_server):
+    srv = running_server(single_model=True)
+    c = ws.connect(f"ws://127.0.0.1:{srv.port}")
+    c.send(json.dumps(OPTS))
+    ready = _recv_json(c)
+    assert ready == {"uid": "u1", "message": "SERVER_READY", "backend": "faster_whisper"}
+    pcm = (0.1 * np.sin(np.arange(3 * 16000) * 0.05)).astype(np.float32)
+    for i in range(0, pcm.shape[0], 4096):                      # stock client packet size (client.py:433)
+        c.send(pcm[i: i + 4096].tobytes())
+    msg = _recv_json(c)
+    assert msg["uid"] == "u1" and msg["segments"]
+    seg = msg["segments"][0]
+    assert set(seg) >= {"start", "end", "text", "completed"} and seg["start"] == "0.000"
+    tr = ServeClientHIP.MODELS[0]
+    audio, kw = tr.calls[0]
+    assert audio.dtype == np.float32 and np.array_equal(audio, pcm[: audio.shape[0]])
+    assert kw["language"] == "en" and kw["task"] == "transcribe" and kw["vad_filter"] is False
+    c.send(b"END_OF_AUDIO")
+    with pytest.raises(ws.ConnectionClosed):                    # server closes after the terminator
+        for _ in range(200):
+            c.recv(timeout=5.0)
+    deadline = time.time() + 5
+    while srv.client_manager.clients and time.time() < deadline:
+        time.sleep(0.02)
+    assert not srv.client_manager.clients and not srv.audio_formats
+
+
+def test_e2e_int16_format_and_capacity_and_auth(running_server):
+    srv = running_server(single_model=True, max_clients=1, api_key="sekret")
+    with pytest.raises(ws.InvalidStatus) as ei:
+        ws.connect(f"ws://127.0.0.1:{srv.port}")
+    assert ei.value.status == 401
+    c = ws.connect(f"ws://127.0.0.1:{srv.port}/?token=sekret")
+    c.send(json.dumps(dict(OPTS, audio_format="int16")))
+    assert _recv_json(c)["message"] == "SERVER_READY"
+    i16 = (np.sin(np.arange(2 * 16000) * 0.05) * 8000).astype(np.int16)
+    c.send(i16.tobytes())
+    assert _recv_json(c)["segments"]
+    audio, _kw = ServeClientHIP.MODELS[0].calls[0]
+    assert np.array_equal(audio, i16.astype(np.float32)[: audio.shape[0]] / 32768.0)
+    # second client: server full -> WAIT with minutes, then closed
+    c2 = ws.connect(f"ws://127.0.0.1:{srv.port}", additional_headers={"Authorization": "Bearer sekret"})
+    c2.send(json.dumps(dict(OPTS, uid="u2")))
+    wait = _recv_json(c2)
+    assert wait["uid"] == "u2" and wait["status"] == "WAIT" and 0 < wait["message"] <= 10
+    with pytest.raises(ws.ConnectionClosed):
+        c2.recv(timeout=5.0)
+    c.close()
+
+
+def test_e2e_model_load_failure_reports_error(running_server):
+    def boom(model, dev):
+        raise RuntimeError("no such model")
+    srv = running_server(single_model=True, model_factory=boom)
+    c = ws.connect(f"ws://127.0.0.1:{srv.port}")
+    c.send(json.dumps(OPTS))
+    msg = _recv_json(c)
+    assert msg["status"] == "ERROR" and "small.en" in msg["message"]
+    with pytest.raises(ws.ConnectionClosed):
+        c.recv(timeout=5.0)
+
+
+def test_e2e_tensorrt_backend_name_falls_back_with_warning(running_server):
+    srv = running_server(single_model=True, backend="tensorrt")
+    c = ws.connect(f"ws://127.0.0.1:{srv.port}")
+    c.send(json.dumps(OPTS))
+    warn = _recv_json(c)
+    assert warn["status"] == "WARNING" and "faster_whisper" in warn["message"]
+    assert _recv_json(c)["message"] == "SERVER_READY"
+    c.close()
+
+
+def test_e2e_connection_time_limit_sends_disconnect(running_server):
+    srv = running_server(single_model=True, max_connection_time=1)
+    c = ws.connect(f"ws://127.0.0.1:{srv.port}")
+    c.send(json.dumps(OPTS))
+    assert _recv_json(c)["message"] == "SERVER_READY"
+    time.sleep(1.1)
+    c.send(np.zeros(1600, np.float32).tobytes())          # the loop checks the limit between packets
+    c.send(np.zeros(1600, np.float32).tobytes())
+    msgs = []
+    with pytest.raises(ws.ConnectionClosed):
+        for _ in range(50):
+            msgs.append(_recv_json(c, timeout=5.0))
+    assert {"uid": "u1", "message": "DISCONNECT"} in msgs
+
+
+def test_e2e_four_clients_shard_over_devices_and_batch_workers(running_server):
+    made = []
+
+    def factory(model, dev):
+        made.append(dev)
+        return ScriptedTranscriber()
+    srv = running_server(single_model=True, devices=[0, 1], max_clients=4, model_factory=factory)
+    conns = []
+    for i in range(4):
+        c = ws.connect(f"ws://127.0.0.1:{srv.port}")
+        c.send(json.dumps(dict(OPTS, uid=f"u{i}")))
+        assert _recv_json(c)["message"] == "SERVER_READY"
+        conns.append(c)
+    assert sorted(made) == [0, 1]                              # one transcriber (one weights replica) per GPU
+    devs = sorted(cl.device_index for cl in srv.client_manager.clients.values())
+    assert devs == [0, 0, 1, 1]
+    for c in conns:
+        c.send(np.zeros(2 * 16000, np.float32).tobytes())
+    for i, c in enumerate(conns):
+        assert _recv_json(c)["uid"] == f"u{i}"
+        c.close()

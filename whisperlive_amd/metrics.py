@@ -12,6 +12,7 @@ _latencies: List[float] = []
 _audio_seconds: List[float] = []
 _errors = {}
 _segments = {"completed": 0, "partial": 0}
+_connections = {"opened": 0, "closed": 0, "active": 0, "rejected": 0}
 
 try:  # optional, like the reference
     from prometheus_client import Counter, Histogram
@@ -49,15 +50,46 @@ def track_segment_emitted(completed: bool):
         _segments["completed" if completed else "partial"] += 1
 
 
+def track_connection_opened():
+    """whisper_live/metrics.py:45-49 (active-connections gauge + total counter)."""
+    with _lock:
+        _connections["opened"] += 1
+        _connections["active"] += 1
+
+
+def track_connection_closed():
+    with _lock:
+        _connections["closed"] += 1
+        _connections["active"] = max(0, _connections["active"] - 1)
+
+
+def track_connection_rejected(reason: str = "full"):
+    with _lock:
+        _connections["rejected"] += 1
+
+
+def start_metrics_server(port: int = 9091):
+    """Prometheus scrape endpoint (whisper_live/metrics.py:29-42); a no-op when prometheus_client is missing."""
+    try:
+        from prometheus_client import start_http_server
+        start_http_server(port)
+        return True
+    except Exception:  # pragma: no cover
+        return False
+
+
 def snapshot(reset: bool = False) -> dict:
     import statistics
     with _lock:
         lat, aud = list(_latencies), list(_audio_seconds)
         out = dict(chunks=len(lat), audio_s=sum(aud), latency_s=sum(lat), errors=dict(_errors), segments=dict(_segments),
+                   connections=dict(_connections),
                    xrt=(sum(aud) / sum(lat)) if lat and sum(lat) > 0 else None,
                    p50_latency_s=statistics.median(lat) if lat else None,
                    p95_latency_s=(sorted(lat)[int(0.95 * (len(lat) - 1))] if lat else None))
         if reset:
             _latencies.clear(); _audio_seconds.clear(); _errors.clear()
             _segments["completed"] = _segments["partial"] = 0
+            for k in _connections:
+                _connections[k] = 0
     return out

@@ -292,7 +292,8 @@ class ServeClientHIP(ServeClientBase):
     MODELS = {}                     # device index -> WhisperModelHIP (one engine = one copy of the weights per GPU)
     MODELS_LOCK = threading.Lock()
     SINGLE_MODEL_LOCK = threading.Lock()
-    BATCH_WORKER = None             # optional whisperlive_amd.batching.BatchInferenceWorker
+    BATCH_WORKER = None             # optional whisperlive_amd.batching.BatchInferenceWorker (all devices)
+    BATCH_WORKERS = {}              # device index -> BatchInferenceWorker (one per GPU; set by TranscriptionServer)
     BACKEND_NAME = "faster_whisper"  # the stock Python client only keeps completed segments for this string (client.py:182,399)
 
     def __init__(self, websocket, task="transcribe", device=None, language=None, client_uid=None, model="small.en",
@@ -350,7 +351,7 @@ class ServeClientHIP(ServeClientBase):
                                             "language_prob": info.language_probability}))
 
     def transcribe_audio(self, input_sample):
-        worker = ServeClientHIP.BATCH_WORKER
+        worker = ServeClientHIP.BATCH_WORKER or ServeClientHIP.BATCH_WORKERS.get(self.device_index)
         if worker is not None:
             from .batching import BatchRequest
             req = BatchRequest(audio=input_sample, language=self.language, task=self.task,
