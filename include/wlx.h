@@ -169,6 +169,36 @@ int32_t wlx_detect_language(wlx_engine* e, int32_t slot, int32_t batch, int32_t 
 int32_t wlx_timings_get(wlx_engine* e, int32_t slot, wlx_timings* out);
 int32_t wlx_sync(wlx_engine* e, int32_t slot);
 
+/* ---- voice-activity probabilities (Silero VAD, 16 kHz) ------------------------------------------------------------
+ * Replaces the model call inside faster_whisper.vad.get_speech_timestamps (onnxruntime, one CPU thread) that the
+ * reference makes before every transcription when the client asks for VAD:
+ * whisper_live/transcriber/transcriber_faster_whisper.py:830-838 and, per batch item, whisper_live/batch_inference.py:245-248;
+ * I/O contract of the same network: whisper_live/vad.py:50-109 (512-sample windows, 64 samples of left context, zero
+ * initial state, one probability per window). The hysteresis / padding / chunk bookkeeping that turns probabilities
+ * into sample ranges stays on the host (whisperlive_amd/vad.py).
+ * Weights: HOST pointers, float32 row-major, copied and repacked at creation:
+ *   stft_basis [258,256]; enc_w[i] [Cout,Cin,3], enc_b[i] [Cout] with (Cin,Cout) = (129,128) (128,64) (64,64) (64,128);
+ *   lstm_w_ih, lstm_w_hh [512,128] and lstm_b_ih, lstm_b_hh [512] in gate order i,f,g,o; out_w [128]; out_b [1]. */
+typedef struct wlx_vad wlx_vad;
+typedef struct {
+    const float* stft_basis;
+    const float* enc_w[4];
+    const float* enc_b[4];
+    const float* lstm_w_ih;
+    const float* lstm_w_hh;
+    const float* lstm_b_ih;
+    const float* lstm_b_hh;
+    const float* out_w;
+    const float* out_b;
+} wlx_vad_weights;
+int32_t wlx_vad_create(const wlx_vad_weights* w, int32_t device, wlx_vad** out);
+void    wlx_vad_destroy(wlx_vad* v);
+/* `n` float32 samples (host pointer) -> ceil(n/512) probabilities (host buffer of `cap` floats); the last window is
+ * zero-padded. Each call starts from a zero state, like get_speech_timestamps on a fresh chunk. Thread-safe (calls on
+ * one object are serialised; it owns its HIP stream). device_ms_out (nullable): kernel time between HIP events. */
+int32_t wlx_vad_probs(wlx_vad* v, const float* pcm, int64_t n, float* probs_out, int32_t cap,
+                      int32_t* n_windows_out, float* device_ms_out);
+
 /* ---- test hooks (used only by tests/ and bench.py's roofline leg; not part of the drop-in) ---- */
 /* next-token logits [rows, vocab] of the last decoder step executed on the slot */
 int32_t wlx_debug_logits_get(wlx_engine* e, int32_t slot, float* out, int32_t rows, int64_t cap_floats);

@@ -22,8 +22,11 @@ What is restated, and from where (paths relative to the reference checkout /root
 * ``alignment.py`` — ctranslate2.models.Whisper.align as called at transcriber_faster_whisper.py:1657-1663 (word
   timestamps): published openai/whisper timing.py algorithm; median filter and DTW pinned against transformers
   generation_whisper.py (tests/golden/align_golden.npz).
-* ``vad.py``      — faster_whisper.vad (get_speech_timestamps / collect_chunks / SpeechTimestampsMap)
-  as used at transcriber_faster_whisper.py:830-838,1792-1817.
+* ``silero_vad.py`` — the Silero-VAD probability network faster_whisper.vad.get_speech_timestamps evaluates through
+  onnxruntime before every VAD-gated transcription (transcriber_faster_whisper.py:830-838; batch_inference.py:245-248);
+  I/O contract whisper_live/vad.py:50-109; layer stack from the published model description.
+  PARITY UNPINNED (no weights / runtime offline): pinned only against an independent torch build of the same stack.
+  The segmentation bookkeeping around it (hysteresis, padding, time map) is host logic in whisperlive_amd/vad.py.
 
 PARITY PINNING STATUS. The reference's own tests pin NO tensor on this path (every test
 that touches the transcriber mocks it; the only result-level pin is one WER<5% sentence that needs

@@ -55,3 +55,14 @@ def test_no_gpu_means_loud_failure_not_fallback():
     spec = WhisperSpec(80, 128, 2, 1, 1, 512, 2310)
     with pytest.raises(WlxError):
         HipWhisperEngine(spec, random_weights(spec, 0))
+
+
+def test_vad_model_without_gpu_fails_loudly():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from oracle import silero_vad as sv
+    from whisperlive_amd._lib import WlxError
+    from whisperlive_amd.vad import SileroHIPModel
+    with pytest.raises(WlxError):
+        SileroHIPModel(sv.random_weights(0), device=0)

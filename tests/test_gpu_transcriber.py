@@ -143,8 +143,9 @@ def test_batch_worker_on_device_equals_single_requests(pair):
 
 def test_websocket_server_end_to_end_on_the_engine(pair):
     """Stock-protocol clients over loopback sockets -> TranscriptionServer -> ServeClientHIP -> libwlx.so. The first
-    transcript each client receives must carry exactly the text the transcriber returns for that audio when called
-    directly (the server adds transport, not arithmetic)."""
+    transcript a client receives must carry exactly the text the transcriber returns for that audio when called
+    directly (the server adds transport, not arithmetic); then two clients stream concurrently."""
+    import itertools
     import json
     from whisperlive_amd import metrics, ws
     from whisperlive_amd.serve_client import ServeClientHIP
@@ -157,31 +158,45 @@ def test_websocket_server_end_to_end_on_the_engine(pair):
                          kwargs=dict(port=0, ready=ready, single_model=True, max_clients=2, model_factory=lambda m, d: hip))
     t.start()
     assert ready.wait(10)
+
+    def open_client(uid):
+        c = ws.connect(f"ws://127.0.0.1:{srv.port}")
+        c.send(json.dumps(dict(uid=uid, language="en", task="transcribe", model="x.en", use_vad=False, no_speech_thresh=1.0)))
+        assert json.loads(c.recv(timeout=20))["message"] == "SERVER_READY"
+        return c
+
     try:
-        pcms = [olm.speech_like_pcm(6.0, seed=s) for s in (31, 32)]
-        want = []
-        for pcm in pcms:
+        # (1) one client at a time, sampling seed pinned (temperature fallbacks draw from a per-model seed counter)
+        for i, seed in enumerate((31, 32)):
+            pcm = olm.speech_like_pcm(6.0, seed=seed)
+            hip._seed = itertools.count(0x5EED)
             segs, _info = hip.transcribe(pcm, language="en", task="transcribe", vad_filter=False)
             assert segs
             kept = [s for s in segs[:-1] if s.start < min(6.0, s.end)] + [segs[-1]]   # update_segments' commit rule
-            want.append("".join(s.text for s in kept))
-        conns = []
-        for i, pcm in enumerate(pcms):
-            c = ws.connect(f"ws://127.0.0.1:{srv.port}")
-            c.send(json.dumps(dict(uid=f"c{i}", language="en", task="transcribe", model="x.en", use_vad=False,
-                                   no_speech_thresh=1.0)))
-            assert json.loads(c.recv(timeout=20))["message"] == "SERVER_READY"
-            conns.append(c)
-        for c, pcm in zip(conns, pcms):
+            want = "".join(s.text for s in kept)
+            hip._seed = itertools.count(0x5EED)
+            c = open_client(f"c{i}")
+            session = next(iter(srv.client_manager.clients.values()))
             c.send(pcm.tobytes())                          # one 6 s packet: the first chunk is exactly this audio
-        for i, c in enumerate(conns):
             msg = json.loads(c.recv(timeout=30))
             assert msg["uid"] == f"c{i}" and msg["segments"]
             got = "".join(s["text"] for s in msg["segments"])
-            assert got == want[i], (got, want[i])
+            assert got == want, (got, want)
+            c.send(b"END_OF_AUDIO")
+            session.trans_thread.join(30)
+            assert not session.trans_thread.is_alive()
+        # (2) two clients at once on their own slots / HIP streams
+        conns = [open_client(f"p{i}") for i in range(2)]
+        for i, c in enumerate(conns):
+            pcm = olm.speech_like_pcm(5.0, seed=40 + i)
+            for k in range(0, pcm.size, 4096):
+                c.send(pcm[k: k + 4096].tobytes())
+        for i, c in enumerate(conns):
+            msg = json.loads(c.recv(timeout=30))
+            assert msg["uid"] == f"p{i}" and msg["segments"]
             c.send(b"END_OF_AUDIO")
         snap = metrics.snapshot()
-        assert snap["errors"] == {} and snap["chunks"] >= 2 and snap["connections"]["opened"] == 2, snap
+        assert snap["errors"] == {} and snap["chunks"] >= 4 and snap["connections"]["opened"] == 4, snap
     finally:
         srv.shutdown()
         t.join(5)

@@ -13,11 +13,12 @@ CSRC = PKG_DIR / "csrc"
 # WLX_LIB selects another build of the same sources (scripts/trace_step.py: libwlx_trace.so, compiled with -DWLX_TRACE)
 DEFAULT_LIB = PKG_DIR / "libwlx.so"
 LIB_PATH = Path(os.environ["WLX_LIB"]).resolve() if os.environ.get("WLX_LIB") else DEFAULT_LIB
-SOURCES = ["pack.hip", "logmel.hip", "gemm.hip", "attention.hip", "decoder.hip", "search.hip", "engine.hip"]
+SOURCES = ["pack.hip", "logmel.hip", "gemm.hip", "attention.hip", "decoder.hip", "search.hip", "engine.hip", "vad.hip"]
 EXPORTS = [
     "wlx_abi_version", "wlx_last_error", "wlx_engine_create", "wlx_engine_destroy", "wlx_engine_spec",
     "wlx_slot_create", "wlx_slot_destroy", "wlx_logmel", "wlx_pcm_put", "wlx_logmel_resident", "wlx_features_get", "wlx_features_set", "wlx_encode",
     "wlx_encoder_output_get", "wlx_generate", "wlx_generate_ex", "wlx_detect_language", "wlx_align", "wlx_timings_get", "wlx_sync",
+    "wlx_vad_create", "wlx_vad_destroy", "wlx_vad_probs",
     "wlx_debug_logits_get", "wlx_debug_decode_logits", "wlx_debug_search", "wlx_debug_time_decode_step", "wlx_debug_profile_step", "wlx_debug_trace_step",
 ]
 
@@ -57,6 +58,12 @@ class wlx_timings(C.Structure):
 class wlx_kernel_stat(C.Structure):
     _fields_ = [("name", C.c_char * 64), ("launches_per_step", C.c_float), ("avg_us", C.c_float),
                 ("total_us_per_step", C.c_float), ("bytes_per_launch", C.c_double)]
+
+
+class wlx_vad_weights(C.Structure):
+    _fields_ = [("stft_basis", C.POINTER(C.c_float)), ("enc_w", C.POINTER(C.c_float) * 4), ("enc_b", C.POINTER(C.c_float) * 4),
+                ("lstm_w_ih", C.POINTER(C.c_float)), ("lstm_w_hh", C.POINTER(C.c_float)), ("lstm_b_ih", C.POINTER(C.c_float)),
+                ("lstm_b_hh", C.POINTER(C.c_float)), ("out_w", C.POINTER(C.c_float)), ("out_b", C.POINTER(C.c_float))]
 
 
 def build_trace() -> Path:
@@ -134,6 +141,10 @@ def load() -> C.CDLL:
     lib.wlx_align.argtypes = [vp, i32, i32, i32p, i32, i32, i32, i32, i32p, i32, i32, i32p, i32p, i32, i32p, f32p]
     lib.wlx_timings_get.argtypes = [vp, i32, C.POINTER(wlx_timings)]
     lib.wlx_sync.argtypes = [vp, i32]
+    lib.wlx_vad_create.argtypes = [C.POINTER(wlx_vad_weights), i32, C.POINTER(vp)]
+    lib.wlx_vad_destroy.argtypes = [vp]
+    lib.wlx_vad_destroy.restype = None
+    lib.wlx_vad_probs.argtypes = [vp, f32p, i64, f32p, i32, i32p, f32p]
     lib.wlx_debug_logits_get.argtypes = [vp, i32, f32p, i32, i64]
     lib.wlx_debug_decode_logits.argtypes = [vp, i32, i32p, i32, f32p]
     lib.wlx_debug_search.argtypes = [vp, i32, f32p, i32, i32p, i32, C.POINTER(wlx_gen_opts), i32p, i32, i32p, f32p]
@@ -142,7 +153,7 @@ def load() -> C.CDLL:
     lib.wlx_debug_trace_step.argtypes = [vp, i32, i32, i32, i32, C.POINTER(C.c_uint64), i64, C.c_char_p, i32p]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("wlx_last_error", "wlx_engine_destroy"):
+        if name not in ("wlx_last_error", "wlx_engine_destroy", "wlx_vad_destroy"):
             fn.restype = i32
     if lib.wlx_abi_version() != 1:
         raise WlxError("libwlx.so ABI version mismatch")

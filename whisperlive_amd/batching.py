@@ -136,7 +136,7 @@ class BatchInferenceWorker:
                 if req.use_vad:
                     params = req.vad_parameters or {}
                     opts = _vad.VadOptions(**params) if isinstance(params, dict) else params
-                    chunks = _vad.get_speech_timestamps(audio, opts)
+                    chunks = _vad.get_speech_timestamps(audio, opts, model=getattr(tr, "vad_model", None))
                     if chunks:
                         pieces, _ = _vad.collect_chunks(audio, chunks)
                         audio = np.concatenate(pieces, axis=0) if pieces else audio

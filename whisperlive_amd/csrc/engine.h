@@ -10,6 +10,9 @@
 
 namespace wlx {
 
+// writes the thread-local message wlx_last_error() returns; shared by every translation unit of the library
+int set_error(int code, const char* fmt, ...);
+
 struct EncLayerW {
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     half_t *Wqkv, *Wo, *W1, *W2;

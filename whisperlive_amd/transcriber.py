@@ -250,7 +250,7 @@ class WhisperModelHIP:
     def __init__(self, model_size_or_path: str = "small.en", device: str = "cuda", device_index: int = 0,
                  compute_type: str = "float16", *, weights: Optional[Dict[str, np.ndarray]] = None,
                  spec: Optional[WhisperSpec] = None, hf_tokenizer=None, engine: Optional[HipWhisperEngine] = None,
-                 max_batch: int = 1, multilingual: Optional[bool] = None, **_ignored):
+                 max_batch: int = 1, multilingual: Optional[bool] = None, vad_model=None, **_ignored):
         if device not in ("cuda", "auto"):
             raise ValueError("WhisperModelHIP runs on the MI355X only (device='cuda'); there is no CPU path")
         if compute_type not in ("float16", "default", "auto"):
@@ -318,6 +318,7 @@ class WhisperModelHIP:
         self.time_precision = 0.02
         self.max_length = 448
         self.max_batch = max_batch
+        self.vad_model = vad_model          # padded audio -> per-window speech probability; None = vad.get_default_model()
         self._tls = threading.local()
         self._slots: List[Slot] = []
         self._slots_lock = threading.Lock()
@@ -417,7 +418,7 @@ class WhisperModelHIP:
                 vad_parameters = VadOptions()
             elif isinstance(vad_parameters, dict):
                 vad_parameters = VadOptions(**vad_parameters)
-            speech_chunks = _vad.get_speech_timestamps(audio, vad_parameters)
+            speech_chunks = _vad.get_speech_timestamps(audio, vad_parameters, model=self.vad_model)
             chunks, _meta = _vad.collect_chunks(audio, speech_chunks)
             audio = np.concatenate(chunks, axis=0)
             duration_after_vad = audio.shape[0] / sr
@@ -719,7 +720,7 @@ class WhisperModelHIP:
             if vad_filter:
                 if isinstance(vad_parameters, dict):
                     vad_parameters = VadOptions(**vad_parameters)
-                chunks, _ = _vad.collect_chunks(audio, _vad.get_speech_timestamps(audio, vad_parameters))
+                chunks, _ = _vad.collect_chunks(audio, _vad.get_speech_timestamps(audio, vad_parameters, model=self.vad_model))
                 audio = np.concatenate(chunks, axis=0)
             audio = audio[: language_detection_segments * fe.n_samples]
             slot = self._slot()

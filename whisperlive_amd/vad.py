@@ -9,9 +9,10 @@ Two parts:
   reference's dependency follows (SURVEY.md Appendix A.3; ⚠ verify against the wheel the first time one is available);
 * the PROBABILITY model (Silero VAD v5: 512-sample windows with 64 samples of left context, LSTM state [2,1,128];
   I/O contract documented in-tree at whisper_live/vad.py:50-109). Its weights are not available offline, so the model is
-  pluggable: ``SileroOnnxModel`` loads an ONNX file through onnxruntime when both exist; ``EnergyGateModel`` is a
-  clearly-labelled stand-in (spectral-energy sigmoid) that keeps the gate on the path for plumbing and benchmarks.
-  No parity claim is made for the stand-in.
+  pluggable: ``SileroHIPModel`` runs the network on the MI355X through libwlx.so (``wlx_vad_*``, csrc/vad.hip) from
+  a weight archive (``load_silero_npz``; names/shapes in include/wlx.h); ``SileroOnnxModel`` loads an ONNX file
+  through onnxruntime when both exist; ``EnergyGateModel`` is a clearly-labelled stand-in (spectral-energy sigmoid)
+  that keeps the gate on the path for plumbing and benchmarks. No parity claim is made for the stand-in.
 """
 from __future__ import annotations
 
@@ -72,6 +73,82 @@ class SileroOnnxModel:
         return np.asarray(probs, dtype=np.float32)
 
 
+SILERO_SHAPES = {
+    "stft_basis": (258, 256),
+    "enc0_w": (128, 129, 3), "enc0_b": (128,), "enc1_w": (64, 128, 3), "enc1_b": (64,),
+    "enc2_w": (64, 64, 3), "enc2_b": (64,), "enc3_w": (128, 64, 3), "enc3_b": (128,),
+    "lstm_w_ih": (512, 128), "lstm_w_hh": (512, 128), "lstm_b_ih": (512,), "lstm_b_hh": (512,),
+    "out_w": (128,), "out_b": (1,),
+}
+
+
+def check_silero_weights(weights: Dict[str, np.ndarray]) -> Dict[str, np.ndarray]:
+    """Validate names / shapes and return C-contiguous float32 copies. Conv weights exported as [Cout, Cin, 3] or, for
+    the STFT filter bank and the output layer, with the singleton conv axes torch keeps ([258,1,256], [1,128,1])."""
+    out = {}
+    for name, shape in SILERO_SHAPES.items():
+        if name not in weights:
+            raise ValueError(f"Silero VAD weights: '{name}' is missing")
+        a = np.asarray(weights[name], dtype=np.float32)
+        if a.size != int(np.prod(shape)):
+            raise ValueError(f"Silero VAD weights: '{name}' has shape {a.shape}, expected {shape}")
+        out[name] = np.ascontiguousarray(a.reshape(shape))
+    return out
+
+
+def load_silero_npz(path: str) -> Dict[str, np.ndarray]:
+    with np.load(path) as z:
+        return check_silero_weights({k: z[k] for k in z.files})
+
+
+class SileroHIPModel:
+    """Silero VAD on the GPU: padded audio (a multiple of 512 samples) -> one probability per window, through
+    ``wlx_vad_probs``. No CPU fallback: construction raises if libwlx.so is missing."""
+
+    def __init__(self, weights: Dict[str, np.ndarray], device: int = 0):
+        import ctypes as C
+        from . import _lib
+        self._lib = _lib
+        self.lib = _lib.load()
+        self._w = check_silero_weights(weights)              # keeps the host arrays alive during creation
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        cw = _lib.wlx_vad_weights()
+        cw.stft_basis = fp(self._w["stft_basis"])
+        for i in range(4):
+            cw.enc_w[i] = fp(self._w[f"enc{i}_w"])
+            cw.enc_b[i] = fp(self._w[f"enc{i}_b"])
+        for k in ("lstm_w_ih", "lstm_w_hh", "lstm_b_ih", "lstm_b_hh", "out_w", "out_b"):
+            setattr(cw, k, fp(self._w[k]))
+        h = C.c_void_p()
+        _lib.check(self.lib.wlx_vad_create(C.byref(cw), int(device), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+        self.last_device_ms = 0.0
+
+    def __call__(self, padded_audio: np.ndarray) -> np.ndarray:
+        import ctypes as C
+        x = np.ascontiguousarray(padded_audio, dtype=np.float32).reshape(-1)
+        cap = x.shape[0] // WINDOW + 1
+        probs = np.empty(cap, np.float32)
+        n_out, ms = C.c_int32(0), C.c_float(0.0)
+        f32p = C.POINTER(C.c_float)
+        self._lib.check(self.lib.wlx_vad_probs(self.handle, x.ctypes.data_as(f32p), x.shape[0], probs.ctypes.data_as(f32p),
+                                               cap, C.byref(n_out), C.byref(ms)))
+        self.last_device_ms = float(ms.value)
+        return probs[: n_out.value].copy()
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.wlx_vad_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
 _default_model: Optional[Callable[[np.ndarray], np.ndarray]] = None
 
 
@@ -84,8 +161,11 @@ def get_default_model() -> Callable[[np.ndarray], np.ndarray]:
     global _default_model
     if _default_model is None:
         import os
+        npz = os.environ.get("WLX_SILERO_VAD_NPZ")
         path = os.environ.get("WLX_SILERO_VAD_ONNX")
-        if path and os.path.isfile(path):
+        if npz and os.path.isfile(npz):
+            _default_model = SileroHIPModel(load_silero_npz(npz), int(os.environ.get("WLX_VAD_DEVICE", "0")))
+        elif path and os.path.isfile(path):
             _default_model = SileroOnnxModel(path)
         else:
             _default_model = EnergyGateModel()

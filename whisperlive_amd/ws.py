@@ -18,6 +18,7 @@ import base64
 import hashlib
 import http
 import os
+import select
 import socket
 import struct
 import threading
@@ -183,9 +184,19 @@ class Connection:
     def recv(self, timeout: Optional[float] = None) -> Union[str, bytes]:
         if self._closed:
             raise ConnectionClosed(self.close_code or 1006, self.close_reason)
-        self.sock.settimeout(timeout)
+        if timeout is not None and not self._rd.buf:
+            # wait for the START of a message only; once bytes are flowing the frame is read to its end, so a
+            # timeout can never strand a half-consumed frame
+            try:
+                ready, _, _ = select.select([self.sock], [], [], timeout)
+            except (OSError, ValueError) as e:
+                self._closed = True
+                raise ConnectionClosed(1006, str(e)) from None
+            if not ready:
+                raise TimeoutError("recv timed out")
         parts, kind = [], None
         try:
+            self.sock.settimeout(None)
             while True:
                 fin, opcode, payload = read_frame(self._rd, expect_mask=not self.is_client)
                 if opcode == OP_PING:
@@ -219,8 +230,6 @@ class Connection:
                 if fin:
                     data = b"".join(parts)
                     return data.decode("utf-8") if kind == OP_TEXT else data
-        except socket.timeout:
-            raise TimeoutError("recv timed out") from None
         except ConnectionClosed:
             if not self._closed:
                 self._closed = True
