@@ -103,6 +103,111 @@ def cpu_baseline(spec, weights, pcm, ids, decode_steps: int, full_steps: int, th
                        f"cannot be installed offline, so this is the repo's own fp32 port")
 
 
+def stream_through_server(make_transcriber, seconds: float = 40.0, paced_seconds: float = 4.0, settle_s: float = 3.0,
+                          pcm_fn=None):
+    """BASELINE configs[1] in its literal form: ONE WebSocket stream against the TranscriptionServer shell
+    (whisperlive_amd/server.py), VAD on, float32 16 kHz PCM in 4096-sample packets (the stock client's packet,
+    whisper_live/client.py:433,547), first unpaced (throughput: xRT as the reference's own counters define it,
+    sum(audio s)/sum(latency) over the chunks the session thread transcribed, whisper_live/backend/base.py:123-131) and
+    then paced at 256 ms per packet (interactive p50 chunk latency). The transcriber is the product one
+    (WhisperModelHIP: VAD gate -> log-mel -> encoder -> beam search -> segments) with the decode length pinned."""
+    import threading
+    from whisperlive_amd import metrics, ws
+    from whisperlive_amd.serve_client import ServeClientHIP
+    from whisperlive_amd.server import TranscriptionServer
+
+    tr = make_transcriber()
+    ServeClientHIP.MODELS.clear()
+    srv, ready = TranscriptionServer(), threading.Event()
+    th = threading.Thread(target=srv.run, args=("127.0.0.1",), daemon=True,
+                          kwargs=dict(port=0, ready=ready, single_model=True, max_clients=1, model_factory=lambda m, d: tr))
+    th.start()
+    if not ready.wait(10):
+        raise RuntimeError("server did not start")
+    opts = dict(uid="bench", language="en", task="transcribe", model="small.en", use_vad=True, no_speech_thresh=1.0,
+                same_output_threshold=10)
+    out = {}
+
+    def run(tag, pcm, pace_s):
+        metrics.snapshot(reset=True)
+        c = ws.connect(f"ws://127.0.0.1:{srv.port}")
+        c.send(json.dumps(opts))
+        if json.loads(c.recv(timeout=30)).get("message") != "SERVER_READY":
+            raise RuntimeError("no SERVER_READY")
+        got = [0]
+
+        def drain():
+            try:
+                while True:
+                    if "segments" in json.loads(c.recv()):
+                        got[0] += 1
+            except Exception:  # noqa: BLE001 — closed
+                return
+        rd = threading.Thread(target=drain, daemon=True)
+        rd.start()
+        t0 = time.perf_counter()
+        for i in range(0, pcm.shape[0], 4096):
+            c.send(pcm[i: i + 4096].tobytes())
+            if pace_s:
+                time.sleep(max(0.0, t0 + (i // 4096 + 1) * pace_s - time.perf_counter()))
+        sent_s = time.perf_counter() - t0
+        time.sleep(settle_s)
+        snap = metrics.snapshot()
+        c.send(b"END_OF_AUDIO")
+        rd.join(5)
+        out[tag] = dict(audio_sent_s=pcm.shape[0] / 16000.0, send_wall_s=sent_s, chunks=snap["chunks"], audio_processed_s=snap["audio_s"],
+                        xrt=snap["xrt"], p50_chunk_latency_ms=None if snap["p50_latency_s"] is None else 1e3 * snap["p50_latency_s"],
+                        p95_chunk_latency_ms=None if snap["p95_latency_s"] is None else 1e3 * snap["p95_latency_s"],
+                        segment_messages=got[0], errors=snap["errors"])
+
+    try:
+        run("unpaced", pcm_fn(seconds, 4321), 0.0)
+        run("paced_256ms", pcm_fn(paced_seconds, 4322), 0.256)
+    finally:
+        srv.shutdown()
+        th.join(5)
+        ServeClientHIP.MODELS.clear()
+    return out
+
+
+def stream_leg(eng, spec, ids, decode_steps, pcm_fn):
+    """The product transcriber on the already-built engine, decode length pinned like the window benchmark: EOT suppressed,
+    max_length = prompt + decode_steps, quality fallbacks off (they never trigger on real speech; random weights would
+    trigger all five re-decodes). VAD: the Silero network on the GPU with seeded weights and a +6 output bias, so the gate
+    passes the audio while costing what the real network costs."""
+    from oracle import silero_vad as sv          # seeded weight generator only; the network runs in libwlx.so
+    from whisperlive_amd import vad
+    from whisperlive_amd.tokenizer import synthetic_tokenizer
+    from whisperlive_amd.transcriber import WhisperModelHIP, _EngineModel
+
+    class FixedLengthModel(_EngineModel):
+        def generate(self, encoder_output, prompts, **kw):
+            kw["max_length"] = max(len(p) for p in prompts) + decode_steps
+            kw["suppress_tokens"] = list(kw.get("suppress_tokens") or (-1,)) + [ids["eot"]]
+            return super().generate(encoder_output, prompts, **kw)
+
+    class BenchTranscriber(WhisperModelHIP):
+        def transcribe(self, audio, **kw):
+            kw.update(temperature=0.0, compression_ratio_threshold=None, log_prob_threshold=None, no_speech_threshold=None)
+            return super().transcribe(audio, **kw)
+
+    w = sv.random_weights(3)
+    w["out_b"] = np.asarray([6.0], np.float32)
+    vm = vad.SileroHIPModel(w, device=eng.device)
+
+    def make():
+        tr = BenchTranscriber("bench", engine=eng, hf_tokenizer=synthetic_tokenizer(spec.vocab), vad_model=vm)
+        tr.model = FixedLengthModel(tr)
+        return tr
+    try:
+        res = stream_through_server(make, pcm_fn=pcm_fn)
+    finally:
+        vm.close()
+    res["config"] = ("configs[1]: one WebSocket stream -> TranscriptionServer -> ServeClientHIP -> WhisperModelHIP.transcribe, "
+                     f"VAD on (Silero on GPU), beam 5, {decode_steps} tokens per window")
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -112,6 +217,7 @@ def main():
     ap.add_argument("--decode-steps", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-decode-steps", type=int, default=32)
+    ap.add_argument("--no-stream", action="store_true", help="skip the WebSocket-server stream leg (configs[1] literal form)")
     ap.add_argument("--batch", type=int, default=1,
                     help="windows per step batched into ONE decode (batch_inference.py's batched mode on one GPU): "
                          "one slot, B items, encoder and every decode step shared by the B x 5 beam rows")
@@ -244,6 +350,11 @@ def main():
                             "kernels": prof},
             "roofline": roof,
         }
+        if world == 1 and S == 1 and B == 1 and not args.no_stream:
+            try:
+                out["stream"] = stream_leg(eng, spec, ids, args.decode_steps, olm.speech_like_pcm)
+            except Exception as e:  # noqa: BLE001 — the headline line must survive a failure of this leg
+                out["stream"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(spec, weights, pcm, ids, args.cpu_decode_steps, n_tok,
                                                threads=min(16, os.cpu_count() or 1))
