@@ -104,13 +104,15 @@ def cpu_baseline(spec, weights, pcm, ids, decode_steps: int, full_steps: int, th
 
 
 def stream_through_server(make_transcriber, seconds: float = 40.0, paced_seconds: float = 4.0, settle_s: float = 3.0,
-                          pcm_fn=None):
-    """BASELINE configs[1] in its literal form: ONE WebSocket stream against the TranscriptionServer shell
-    (whisperlive_amd/server.py), VAD on, float32 16 kHz PCM in 4096-sample packets (the stock client's packet,
-    whisper_live/client.py:433,547), first unpaced (throughput: xRT as the reference's own counters define it,
-    sum(audio s)/sum(latency) over the chunks the session thread transcribed, whisper_live/backend/base.py:123-131) and
-    then paced at 256 ms per packet (interactive p50 chunk latency). The transcriber is the product one
-    (WhisperModelHIP: VAD gate -> log-mel -> encoder -> beam search -> segments) with the decode length pinned."""
+                          pcm_fn=None, clients: int = 1, batch: bool = False, model_name: str = "small.en", language="en"):
+    """BASELINE configs[1] (and, with clients=4, configs[2]) in their literal form: WebSocket streams against the
+    TranscriptionServer shell (whisperlive_amd/server.py), VAD on, float32 16 kHz PCM in 4096-sample packets (the stock
+    client's packet, whisper_live/client.py:433,547), first unpaced (throughput) and then paced at 256 ms per packet
+    (interactive latency). Numbers are the reference's own counters (whisper_live/backend/base.py:123-131,
+    whisper_live/metrics.py:100-107): xrt = sum(audio s) / sum(latency) over every chunk any session thread transcribed
+    (a per-stream rate: with N clients the aggregate is up to N x that), p50 = median chunk latency. The transcriber is
+    the product one (WhisperModelHIP: VAD gate -> log-mel -> encoder -> beam search -> segments), decode length pinned.
+    batch=True starts the per-GPU BatchInferenceWorker (the reference's --batch_inference mode)."""
     import threading
     from whisperlive_amd import metrics, ws
     from whisperlive_amd.serve_client import ServeClientHIP
@@ -120,49 +122,59 @@ def stream_through_server(make_transcriber, seconds: float = 40.0, paced_seconds
     ServeClientHIP.MODELS.clear()
     srv, ready = TranscriptionServer(), threading.Event()
     th = threading.Thread(target=srv.run, args=("127.0.0.1",), daemon=True,
-                          kwargs=dict(port=0, ready=ready, single_model=True, max_clients=1, model_factory=lambda m, d: tr))
+                          kwargs=dict(port=0, ready=ready, single_model=True, max_clients=clients, batch_enabled=batch,
+                                      batch_max_size=max(clients, 1), batch_window_ms=5, model_factory=lambda m, d: tr))
     th.start()
     if not ready.wait(10):
         raise RuntimeError("server did not start")
-    opts = dict(uid="bench", language="en", task="transcribe", model="small.en", use_vad=True, no_speech_thresh=1.0,
-                same_output_threshold=10)
     out = {}
 
-    def run(tag, pcm, pace_s):
-        metrics.snapshot(reset=True)
-        c = ws.connect(f"ws://127.0.0.1:{srv.port}")
-        c.send(json.dumps(opts))
-        if json.loads(c.recv(timeout=30)).get("message") != "SERVER_READY":
-            raise RuntimeError("no SERVER_READY")
-        got = [0]
+    def client(k, pcm, pace_s, got, errs):
+        try:
+            c = ws.connect(f"ws://127.0.0.1:{srv.port}")
+            c.send(json.dumps(dict(uid=f"bench{k}", language=language, task="transcribe", model=model_name, use_vad=True,
+                                   no_speech_thresh=1.0, same_output_threshold=10)))
+            if json.loads(c.recv(timeout=30)).get("message") != "SERVER_READY":
+                raise RuntimeError("no SERVER_READY")
 
-        def drain():
-            try:
-                while True:
-                    if "segments" in json.loads(c.recv()):
-                        got[0] += 1
-            except Exception:  # noqa: BLE001 — closed
-                return
-        rd = threading.Thread(target=drain, daemon=True)
-        rd.start()
+            def drain():
+                try:
+                    while True:
+                        if "segments" in json.loads(c.recv()):
+                            got[k] += 1
+                except Exception:  # noqa: BLE001 — closed
+                    return
+            rd = threading.Thread(target=drain, daemon=True)
+            rd.start()
+            t0 = time.perf_counter()
+            for i in range(0, pcm.shape[0], 4096):
+                c.send(pcm[i: i + 4096].tobytes())
+                if pace_s:
+                    time.sleep(max(0.0, t0 + (i // 4096 + 1) * pace_s - time.perf_counter()))
+            time.sleep(settle_s)
+            c.send(b"END_OF_AUDIO")
+            rd.join(5)
+        except Exception as e:  # noqa: BLE001
+            errs.append(f"{type(e).__name__}: {e}")
+
+    def run(tag, secs, seed, pace_s):
+        metrics.snapshot(reset=True)
+        got, errs = [0] * clients, []
+        ts = [threading.Thread(target=client, args=(k, pcm_fn(secs, seed + k), pace_s, got, errs)) for k in range(clients)]
         t0 = time.perf_counter()
-        for i in range(0, pcm.shape[0], 4096):
-            c.send(pcm[i: i + 4096].tobytes())
-            if pace_s:
-                time.sleep(max(0.0, t0 + (i // 4096 + 1) * pace_s - time.perf_counter()))
-        sent_s = time.perf_counter() - t0
-        time.sleep(settle_s)
+        [t.start() for t in ts]
+        time.sleep(secs * (pace_s / 0.256 if pace_s else 0.0) + settle_s * 0.9)        # snapshot while every client is still connected
         snap = metrics.snapshot()
-        c.send(b"END_OF_AUDIO")
-        rd.join(5)
-        out[tag] = dict(audio_sent_s=pcm.shape[0] / 16000.0, send_wall_s=sent_s, chunks=snap["chunks"], audio_processed_s=snap["audio_s"],
-                        xrt=snap["xrt"], p50_chunk_latency_ms=None if snap["p50_latency_s"] is None else 1e3 * snap["p50_latency_s"],
+        [t.join(60) for t in ts]
+        out[tag] = dict(clients=clients, audio_sent_s_per_client=secs, wall_s=time.perf_counter() - t0, chunks=snap["chunks"],
+                        audio_processed_s=snap["audio_s"], xrt=snap["xrt"],
+                        p50_chunk_latency_ms=None if snap["p50_latency_s"] is None else 1e3 * snap["p50_latency_s"],
                         p95_chunk_latency_ms=None if snap["p95_latency_s"] is None else 1e3 * snap["p95_latency_s"],
-                        segment_messages=got[0], errors=snap["errors"])
+                        segment_messages=sum(got), errors=snap["errors"], client_errors=errs)
 
     try:
-        run("unpaced", pcm_fn(seconds, 4321), 0.0)
-        run("paced_256ms", pcm_fn(paced_seconds, 4322), 0.256)
+        run("unpaced", seconds, 4321, 0.0)
+        run("paced_256ms", paced_seconds, 4400, 0.256)
     finally:
         srv.shutdown()
         th.join(5)
@@ -170,7 +182,7 @@ def stream_through_server(make_transcriber, seconds: float = 40.0, paced_seconds
     return out
 
 
-def stream_leg(eng, spec, ids, decode_steps, pcm_fn):
+def stream_leg(eng, spec, ids, decode_steps, pcm_fn, clients=1, batch=False, model_name="small.en"):
     """The product transcriber on the already-built engine, decode length pinned like the window benchmark: EOT suppressed,
     max_length = prompt + decode_steps, quality fallbacks off (they never trigger on real speech; random weights would
     trigger all five re-decodes). VAD: the Silero network on the GPU with seeded weights and a +6 output bias, so the gate
@@ -189,22 +201,34 @@ def stream_leg(eng, spec, ids, decode_steps, pcm_fn):
     class BenchTranscriber(WhisperModelHIP):
         def transcribe(self, audio, **kw):
             kw.update(temperature=0.0, compression_ratio_threshold=None, log_prob_threshold=None, no_speech_threshold=None)
-            return super().transcribe(audio, **kw)
+            segs, info = super().transcribe(audio, **kw)
+            if info is not None:      # random weights give a flat language distribution; real speech locks the language (> 0.5)
+                info.language_probability = max(info.language_probability, 0.99)
+            return segs, info
 
     w = sv.random_weights(3)
     w["out_b"] = np.asarray([6.0], np.float32)
     vm = vad.SileroHIPModel(w, device=eng.device)
 
     def make():
-        tr = BenchTranscriber("bench", engine=eng, hf_tokenizer=synthetic_tokenizer(spec.vocab), vad_model=vm)
+        tr = BenchTranscriber("bench", engine=eng, hf_tokenizer=synthetic_tokenizer(spec.vocab), vad_model=vm,
+                              max_batch=max(1, clients if batch else 1))
         tr.model = FixedLengthModel(tr)
         return tr
+    english_only = model_name.endswith("en")
+    from whisperlive_amd.batching import BatchInferenceWorker
+    saved_t = BatchInferenceWorker.TEMPERATURES
+    BatchInferenceWorker.TEMPERATURES = (0.0,)        # the batch worker's own fallback ladder, off like the transcriber's
     try:
-        res = stream_through_server(make, pcm_fn=pcm_fn)
+        res = stream_through_server(make, pcm_fn=pcm_fn, clients=clients, batch=batch, model_name=model_name,
+                                    language="en" if english_only else None)
     finally:
+        BatchInferenceWorker.TEMPERATURES = saved_t
         vm.close()
-    res["config"] = ("configs[1]: one WebSocket stream -> TranscriptionServer -> ServeClientHIP -> WhisperModelHIP.transcribe, "
-                     f"VAD on (Silero on GPU), beam 5, {decode_steps} tokens per window")
+    res["config"] = (f"configs[{1 if clients == 1 else 2}]: {clients} WebSocket stream{'s' if clients > 1 else ''} -> TranscriptionServer -> "
+                     f"ServeClientHIP{' -> BatchInferenceWorker' if batch else ''} -> WhisperModelHIP.transcribe, Whisper-{model_name}, "
+                     f"VAD on (Silero on GPU), beam 5, {decode_steps} tokens per window"
+                     + ("" if english_only else ", language detected on the first chunk"))
     return res
 
 
@@ -218,6 +242,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-decode-steps", type=int, default=32)
     ap.add_argument("--no-stream", action="store_true", help="skip the WebSocket-server stream leg (configs[1] literal form)")
+    ap.add_argument("--stream-clients", type=int, default=1, help="WebSocket clients of the stream leg (configs[2]: 4, with --model small)")
+    ap.add_argument("--stream-batch", action="store_true", help="stream leg through the per-GPU BatchInferenceWorker")
     ap.add_argument("--batch", type=int, default=1,
                     help="windows per step batched into ONE decode (batch_inference.py's batched mode on one GPU): "
                          "one slot, B items, encoder and every decode step shared by the B x 5 beam rows")
@@ -352,7 +378,8 @@ def main():
         }
         if world == 1 and S == 1 and B == 1 and not args.no_stream:
             try:
-                out["stream"] = stream_leg(eng, spec, ids, args.decode_steps, olm.speech_like_pcm)
+                out["stream"] = stream_leg(eng, spec, ids, args.decode_steps, olm.speech_like_pcm, clients=max(1, args.stream_clients),
+                                           batch=args.stream_batch, model_name=args.model)
             except Exception as e:  # noqa: BLE001 — the headline line must survive a failure of this leg
                 out["stream"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
