@@ -25,6 +25,7 @@ import numpy as np
 
 from . import vad as _vad
 from .tokenizer import Tokenizer
+from .transcriber import get_compression_ratio, get_suppressed_tokens, pad_or_trim
 from .types import Segment, TranscriptionInfo
 
 
@@ -120,9 +121,8 @@ class BatchInferenceWorker:
         """Device path when the transcriber is a WhisperModelHIP (per-item log-mel kernels + one batched encoder
         launch, nothing returns to the host); generic duck-typed path otherwise (what the reference does)."""
         tr = self.transcriber
-        if hasattr(tr, "encode_audio_batch"):
+        if getattr(type(tr), "encode_audio_batch", None) is not None:     # class-level: a MagicMock transcriber has "every" attribute
             return tr.encode_audio_batch(audios)
-        from .transcriber import pad_or_trim
         feats = np.stack([pad_or_trim(tr.feature_extractor(a)) for a in audios])
         return tr.encode(feats)
 
@@ -136,7 +136,7 @@ class BatchInferenceWorker:
                 if req.use_vad:
                     params = req.vad_parameters or {}
                     opts = _vad.VadOptions(**params) if isinstance(params, dict) else params
-                    chunks = _vad.get_speech_timestamps(audio, opts, model=getattr(tr, "vad_model", None))
+                    chunks = _vad.get_speech_timestamps(audio, opts, model=tr.__dict__.get("vad_model") if hasattr(tr, "__dict__") else None)
                     if chunks:
                         pieces, _ = _vad.collect_chunks(audio, chunks)
                         audio = np.concatenate(pieces, axis=0) if pieces else audio
@@ -173,7 +173,6 @@ class BatchInferenceWorker:
                 prev = tk.encode(" " + req.initial_prompt.strip()) if req.initial_prompt else []
                 toks.append(tk)
                 prompts.append(tr.get_prompt(tk, previous_tokens=prev, without_timestamps=False))
-            from .transcriber import get_compression_ratio, get_suppressed_tokens
             suppress = get_suppressed_tokens(toks[0], [-1])
             final: List[Optional[tuple]] = [None] * n
             pending = list(range(n))
