@@ -191,13 +191,53 @@ def test_websocket_server_end_to_end_on_the_engine(pair):
             pcm = olm.speech_like_pcm(5.0, seed=40 + i)
             for k in range(0, pcm.size, 4096):
                 c.send(pcm[k: k + 4096].tobytes())
+        sessions = list(srv.client_manager.clients.values())
         for i, c in enumerate(conns):
             msg = json.loads(c.recv(timeout=30))
             assert msg["uid"] == f"p{i}" and msg["segments"]
             c.send(b"END_OF_AUDIO")
+        for sess in sessions:                              # sessions end with their chunk in flight completed
+            sess.trans_thread.join(30)
+            assert not sess.trans_thread.is_alive()
         snap = metrics.snapshot()
         assert snap["errors"] == {} and snap["chunks"] >= 4 and snap["connections"]["opened"] == 4, snap
     finally:
         srv.shutdown()
         t.join(5)
         ServeClientHIP.MODELS.clear()
+
+
+def test_slot_creation_does_not_break_another_slots_graph_capture(pair):
+    """A client connecting (slot allocation, first-step graph capture) while other clients are decoding must not disturb
+    them: every set-up operation stays off the legacy stream. Four threads create a fresh slot each round — so every
+    round captures its decode graphs anew — transcribe, and must all get the result of the undisturbed run."""
+    hip, _ = pair
+    eng = hip.engine
+    pcm = olm.speech_like_pcm(3.0, seed=77)
+    ids = H.engine_ids(H.token_ids_for(eng.spec.vocab))
+    kw = dict(beam_size=5, patience=1.0, max_length=12, suppress_tokens=[])
+
+    def once():
+        s = eng.create_slot(1, 5)
+        try:
+            T = s.logmel(pcm)
+            s.encode(1, seek=[0], seg=[T - 1])
+            return s.generate([[ids.sot]], ids, **kw)[0].sequences_ids[0]
+        finally:
+            s.close()
+
+    want = once()
+    errs, outs = [], []
+
+    def worker():
+        try:
+            for _ in range(4):
+                outs.append(once())
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=worker) for _ in range(4)]
+    [t.start() for t in ts]
+    [t.join(120) for t in ts]
+    assert not errs, errs[:2]
+    assert len(outs) == 16 and all(o == want for o in outs)

@@ -254,3 +254,47 @@ def test_hip_backend_goes_through_the_batch_worker():
     finally:
         ServeClientHIP.BATCH_WORKER = None
         w.stop()
+
+
+def test_engine_slots_are_pooled_across_client_threads():
+    """One slot per CONCURRENT client thread, not per connection ever made: a slot whose owner thread has ended (or that
+    was released) is taken over by the next thread that needs one."""
+    eng = FakeEngine()
+    m = _model(eng)
+    seen = []
+
+    def session(hold=None, release=False):
+        s = m._slot()
+        seen.append(s)
+        assert m._slot() is s                       # stable within a thread
+        if hold is not None:
+            hold.wait(5)
+        if release:
+            m.release_slot()
+
+    for _ in range(3):                              # three consecutive connections: one slot, reused
+        t = threading.Thread(target=session)
+        t.start(); t.join()
+    assert len(eng.slots) == 1 and seen[0] is seen[1] is seen[2]
+    gate = threading.Event()                        # two concurrent connections: a second slot, no more
+    ts = [threading.Thread(target=session, args=(gate,)) for _ in range(2)]
+    [t.start() for t in ts]
+    deadline = time.time() + 5
+    while len(seen) < 5 and time.time() < deadline:
+        time.sleep(0.01)
+    assert len(eng.slots) == 2 and seen[3] is not seen[4]
+    gate.set(); [t.join() for t in ts]
+    # an explicit release makes the slot available while its thread lives on
+    done, keep = threading.Event(), threading.Event()
+
+    def releasing():
+        session(release=True); done.set(); keep.wait(5)
+    t1 = threading.Thread(target=releasing); t1.start(); done.wait(5)
+    t2 = threading.Thread(target=session); t2.start(); t2.join()
+    keep.set(); t1.join()
+    assert len(eng.slots) == 2
+    # a closed slot is never handed out again
+    for s in eng.slots:
+        s.close()
+    t = threading.Thread(target=session); t.start(); t.join()
+    assert len(eng.slots) == 3 and seen[-1].sid >= 0

@@ -12,6 +12,8 @@ namespace wlx {
 
 // writes the thread-local message wlx_last_error() returns; shared by every translation unit of the library
 int set_error(int code, const char* fmt, ...);
+// per-device non-blocking stream for set-up work (see engine.hip: the legacy stream is never used)
+hipStream_t util_stream();
 
 struct EncLayerW {
     float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
@@ -39,6 +41,7 @@ struct ProfRec { std::string name; double bytes; };
 struct Prof { std::vector<ProfRec> recs; bool list_only = true; std::string only; int t = 0; };
 
 struct Slot {
+    std::mutex call_mu;      // held by the entry point currently using the slot (engine.hip: slot_acquire)
     int B = 0, R = 0, rows_cap = 0, cache_rows = 0, groups_cap = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_poll0 = nullptr, ev_poll1 = nullptr;

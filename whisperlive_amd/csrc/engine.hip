@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <thread>
 
 using namespace wlx;
 
@@ -46,6 +48,33 @@ extern "C" int32_t wlx_abi_version(void) { return WLX_ABI_VERSION; }
 extern "C" const char* wlx_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------------------------------------
+// Nothing in this library may touch the legacy (null) stream once slots exist: while ANY stream is capturing a decode
+// graph, a legacy-stream operation from another thread (hipMemset, synchronous hipMemcpy, hipDeviceSynchronize) fails with
+// "would make the legacy stream depend on a capturing ... stream" AND invalidates that capture — i.e. a second client
+// connecting (slot creation) used to be able to break the first client's transcription. Set-up work that is not tied to a
+// slot therefore runs on a per-device non-blocking utility stream and waits for it explicitly.
+hipStream_t wlx::util_stream() {
+    static std::mutex mu;
+    static std::map<int, hipStream_t> streams;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> g(mu);
+    auto it = streams.find(dev);
+    if (it != streams.end()) return it->second;
+    hipStream_t st = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    streams[dev] = st;
+    return st;
+}
+static int upload_sync(void* dst, const void* src, size_t bytes) {      // host -> device, complete on return
+    hipStream_t us = wlx::util_stream();
+    if (!us) return fail(WLX_ERR_HIP, "utility stream creation failed");
+    CK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, us));
+    CK(hipStreamSynchronize(us));
+    return WLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // allocation helpers
 template <typename T>
 static int dalloc(std::vector<void*>& pool, T** out, size_t count, bool zero = true) {
@@ -54,8 +83,11 @@ static int dalloc(std::vector<void*>& pool, T** out, size_t count, bool zero = t
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) return fail(WLX_ERR_NOMEM, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     if (zero) {
-        e = hipMemset(p, 0, bytes);
-        if (e != hipSuccess) return fail(WLX_ERR_HIP, "hipMemset failed: %s", hipGetErrorString(e));
+        hipStream_t us = wlx::util_stream();
+        if (!us) return fail(WLX_ERR_HIP, "utility stream creation failed");
+        e = hipMemsetAsync(p, 0, bytes, us);
+        if (e == hipSuccess) e = hipStreamSynchronize(us);
+        if (e != hipSuccess) return fail(WLX_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
     }
     pool.push_back(p);
     *out = reinterpret_cast<T*>(p);
@@ -90,7 +122,7 @@ struct WeightSource {
             staging_cap = n;
         }
         CK(hipStreamSynchronize(stream));  // previous consumer of the staging buffer
-        CK(hipMemcpy(staging, t->data, n * sizeof(float), hipMemcpyHostToDevice));
+        CKR(upload_sync(staging, t->data, n * sizeof(float)));
         *out = staging;
         return WLX_OK;
     }
@@ -117,7 +149,7 @@ static int load_vec(WeightSource& ws, const std::string& name, int64_t n, float*
     const wlx_tensor* t;
     CKR(need(ws, name, {n}, &t));
     if (t->on_device) CK(hipMemcpyAsync(dst, t->data, n * sizeof(float), hipMemcpyDeviceToDevice, ws.stream));
-    else CK(hipMemcpy(dst, t->data, n * sizeof(float), hipMemcpyHostToDevice));
+    else CKR(upload_sync(dst, t->data, n * sizeof(float)));
     return WLX_OK;
 }
 static int alloc_vec(Engine* e, WeightSource& ws, const std::string& name, int64_t n, float** out) {
@@ -187,10 +219,10 @@ static int build_logmel_consts(Engine* e) {
     float *dwin, *dtw, *dfilt; int* drange;
     CKR(dalloc(e->allocs, &dwin, 400)); CKR(dalloc(e->allocs, &dtw, 800));
     CKR(dalloc(e->allocs, &dfilt, filt.size())); CKR(dalloc(e->allocs, &drange, range.size()));
-    CK(hipMemcpy(dwin, win.data(), 400 * 4, hipMemcpyHostToDevice));
-    CK(hipMemcpy(dtw, tw.data(), 800 * 4, hipMemcpyHostToDevice));
-    CK(hipMemcpy(dfilt, filt.data(), filt.size() * 4, hipMemcpyHostToDevice));
-    CK(hipMemcpy(drange, range.data(), range.size() * 4, hipMemcpyHostToDevice));
+    CKR(upload_sync(dwin, win.data(), 400 * 4));
+    CKR(upload_sync(dtw, tw.data(), 800 * 4));
+    CKR(upload_sync(dfilt, filt.data(), filt.size() * 4));
+    CKR(upload_sync(drange, range.data(), range.size() * 4));
     e->lm.window = dwin; e->lm.twiddle = dtw; e->lm.filters = dfilt; e->lm.frange = drange;
     return WLX_OK;
 }
@@ -219,7 +251,7 @@ static int engine_load(Engine* e, const wlx_tensor* weights, int n_weights) {
     const int d = sp.d_model, F = sp.ffn, V = sp.vocab;
     WeightSource ws;
     for (int i = 0; i < n_weights; ++i) ws.by_name[weights[i].name] = &weights[i];
-    CK(hipStreamCreate(&ws.stream));
+    CK(hipStreamCreateWithFlags(&ws.stream, hipStreamNonBlocking));
     int rc = WLX_OK;
     auto body = [&]() -> int {
         CKR(build_logmel_consts(e));
@@ -373,11 +405,21 @@ extern "C" int32_t wlx_engine_spec(const wlx_engine* e, wlx_spec* out) {
 
 // ------------------------------------------------------------------------------------------------
 // slots
-static int slot_get(wlx_engine* e, int slot, Slot** out) {
+// Every entry point holds the slot's call mutex for its duration: a slot is one unit of concurrency (one stream, one set
+// of scratch buffers), so a second call on it is refused rather than corrupting the first, and wlx_slot_destroy waits for
+// a call in flight instead of freeing buffers under it.
+struct SlotGuard {
+    Slot* s = nullptr;
+    ~SlotGuard() { if (s) s->call_mu.unlock(); }
+};
+static int slot_acquire(wlx_engine* e, int slot, SlotGuard& g) {
     if (!e) return fail(WLX_ERR_ARG, "null engine");
-    std::lock_guard<std::mutex> g(e->mu);
+    std::lock_guard<std::mutex> lk(e->mu);
     if (slot < 0 || slot >= (int)e->slots.size() || !e->slots[slot]) return fail(WLX_ERR_ARG, "bad slot %d", slot);
-    *out = e->slots[slot];
+    Slot* s = e->slots[slot];
+    if (!s->call_mu.try_lock())
+        return fail(WLX_ERR_STATE, "slot %d is busy in another call (a slot serves one call at a time)", slot);
+    g.s = s;
     return WLX_OK;
 }
 
@@ -479,43 +521,53 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         CK(hipHostMalloc(reinterpret_cast<void**>(&s->h_stage), s->h_stage_ints * sizeof(int), hipHostMallocDefault));
         // the search kernels raise this pinned word themselves when every item is finished (no per-step D2H copy)
         s->st.done_host = s->h_stage + (s->h_stage_ints - 4);
-        CK(hipDeviceSynchronize());
+        CK(hipStreamSynchronize(s->stream));      // (allocations were zeroed on the utility stream and waited for in dalloc)
         return WLX_OK;
     }();
     if (rc != WLX_OK) { slot_free(s); return rc; }
     std::lock_guard<std::mutex> g(e->mu);
-    int id = -1;
-    for (size_t i = 0; i < e->slots.size(); ++i) if (!e->slots[i]) { id = (int)i; break; }
-    if (id < 0) { e->slots.push_back(nullptr); id = (int)e->slots.size() - 1; }
-    e->slots[id] = s;
+    // ids are never reused: a stale handle of a destroyed slot must fail ("bad slot"), not reach its successor
+    e->slots.push_back(s);
+    const int id = (int)e->slots.size() - 1;
     *slot_out = id;
     return WLX_OK;
 }
 
 extern "C" int32_t wlx_slot_destroy(wlx_engine* e, int32_t slot) {
-    Slot* s;
-    CKR(slot_get(e, slot, &s));
-    CK(hipSetDevice(e->device));
-    CK(hipStreamSynchronize(s->stream));
-    {
-        std::lock_guard<std::mutex> g(e->mu);
-        e->slots[slot] = nullptr;
+    if (!e) return fail(WLX_ERR_ARG, "null engine");
+    Slot* s = nullptr;
+    for (;;) {      // wait for a call still running on the slot in another thread (a session being torn down mid-chunk)
+        {
+            std::lock_guard<std::mutex> g(e->mu);
+            if (slot < 0 || slot >= (int)e->slots.size() || !e->slots[slot]) return fail(WLX_ERR_ARG, "bad slot %d", slot);
+            if (e->slots[slot]->call_mu.try_lock()) {
+                s = e->slots[slot];
+                e->slots[slot] = nullptr;        // no other thread can reach it any more
+                break;
+            }
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
     }
+    s->call_mu.unlock();
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(s->stream);
     slot_free(s);
     return WLX_OK;
 }
 
 extern "C" int32_t wlx_sync(wlx_engine* e, int32_t slot) {
-    Slot* s;
-    CKR(slot_get(e, slot, &s));
+    SlotGuard sg_;
+    CKR(slot_acquire(e, slot, sg_));
+    Slot* s = sg_.s;
     CK(hipSetDevice(e->device));
     CK(hipStreamSynchronize(s->stream));
     return WLX_OK;
 }
 
 extern "C" int32_t wlx_timings_get(wlx_engine* e, int32_t slot, wlx_timings* out) {
-    Slot* s;
-    CKR(slot_get(e, slot, &s));
+    SlotGuard sg_;
+    CKR(slot_acquire(e, slot, sg_));
+    Slot* s = sg_.s;
     if (!out) return fail(WLX_ERR_ARG, "null out");
     *out = s->tm;
     return WLX_OK;
@@ -524,8 +576,9 @@ extern "C" int32_t wlx_timings_get(wlx_engine* e, int32_t slot, wlx_timings* out
 // ------------------------------------------------------------------------------------------------
 // log-mel
 extern "C" int32_t wlx_pcm_put(wlx_engine* e, int32_t slot, int32_t item, const float* pcm, int64_t n) {
-    Slot* s;
-    CKR(slot_get(e, slot, &s));
+    SlotGuard sg_;
+    CKR(slot_acquire(e, slot, sg_));
+    Slot* s = sg_.s;
     if (!pcm || n <= 0) return fail(WLX_ERR_ARG, "empty audio");
     if (item < 0 || item >= s->B) return fail(WLX_ERR_ARG, "bad item %d", item);
     if (n > 16000LL * 3600) return fail(WLX_ERR_ARG, "audio chunk too long");
@@ -539,8 +592,9 @@ extern "C" int32_t wlx_pcm_put(wlx_engine* e, int32_t slot, int32_t item, const 
 }
 
 extern "C" int32_t wlx_logmel_resident(wlx_engine* e, int32_t slot, int32_t item, int32_t* n_frames_out) {
-    Slot* s;
-    CKR(slot_get(e, slot, &s));
+    SlotGuard sg_;
+    CKR(slot_acquire(e, slot, sg_));
+    Slot* s = sg_.s;
     if (item < 0 || item >= s->B) return fail(WLX_ERR_ARG, "bad item %d", item);
     const int64_t n = s->npcm[item];
     if (n <= 0) return fail(WLX_ERR_STATE, "item %d: no PCM resident (call wlx_pcm_put first)", item);
@@ -567,8 +621,9 @@ extern "C" int32_t wlx_logmel(wlx_engine* e, int32_t slot, int32_t item, const f
 
 extern "C" int32_t wlx_features_get(wlx_engine* e, int32_t slot, int32_t item, float* out, int64_t cap_floats,
                                     int32_t* n_frames_out) {
-    Slot* s;
-    CKR(slot_get(e, slot, &s));
+    SlotGuard sg_;
+    CKR(slot_acquire(e, slot, sg_));
+    Slot* s = sg_.s;
     if (item < 0 || item >= s->B) return fail(WLX_ERR_ARG, "bad item");
     const int T = s->nframes[item], nm = e->spec.n_mels;
     if (n_frames_out) *n_frames_out = T;
@@ -583,8 +638,9 @@ extern "C" int32_t wlx_features_get(wlx_engine* e, int32_t slot, int32_t item, f
 
 extern "C" int32_t wlx_features_set(wlx_engine* e, int32_t slot, int32_t item, const float* feats,
                                     int32_t n_mels, int32_t n_frames) {
-    Slot* s;
-    CKR(slot_get(e, slot, &s));
+    SlotGuard sg_;
+    CKR(slot_acquire(e, slot, sg_));
+    Slot* s = sg_.s;
     if (item < 0 || item >= s->B || !feats) return fail(WLX_ERR_ARG, "bad item / null");
     if (n_mels != e->spec.n_mels || n_frames < 1) return fail(WLX_ERR_ARG, "features must be [%d, T>=1]", e->spec.n_mels);
     CK(hipSetDevice(e->device));
@@ -600,8 +656,9 @@ extern "C" int32_t wlx_features_set(wlx_engine* e, int32_t slot, int32_t item, c
 // ------------------------------------------------------------------------------------------------
 // encoder
 extern "C" int32_t wlx_encode(wlx_engine* e, int32_t slot, int32_t batch, const int32_t* seek, const int32_t* seg) {
-    Slot* s;
-    CKR(slot_get(e, slot, &s));
+    SlotGuard sg_;
+    CKR(slot_acquire(e, slot, sg_));
+    Slot* s = sg_.s;
     if (batch < 1 || batch > s->B) return fail(WLX_ERR_ARG, "batch %d out of range (slot max %d)", batch, s->B);
     const wlx_spec& sp = e->spec;
     const int d = sp.d_model, F = sp.ffn, nm = sp.n_mels, H = e->H, T = WLX_T_AUDIO;
@@ -671,8 +728,9 @@ extern "C" int32_t wlx_encode(wlx_engine* e, int32_t slot, int32_t batch, const 
 }
 
 extern "C" int32_t wlx_encoder_output_get(wlx_engine* e, int32_t slot, int32_t item, float* out, int64_t cap_floats) {
-    Slot* s;
-    CKR(slot_get(e, slot, &s));
+    SlotGuard sg_;
+    CKR(slot_acquire(e, slot, sg_));
+    Slot* s = sg_.s;
     if (item < 0 || item >= s->enc_batch) return fail(WLX_ERR_STATE, "item %d not encoded", item);
     const size_t n = (size_t)WLX_T_AUDIO * e->spec.d_model;
     if (!out || (int64_t)n > cap_floats) return fail(WLX_ERR_ARG, "output buffer too small");
@@ -853,7 +911,19 @@ static int get_step_graph(Engine* e, Slot* s, int rows, int R, int groups, bool 
     CK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
     decoder_pass(e, s, rows, R, groups, true, true);
     launch_search(e, s, rows, groups, sampling);
-    CK(hipStreamEndCapture(s->stream, &graph));
+    const hipError_t ce = hipStreamEndCapture(s->stream, &graph);
+    if (ce != hipSuccess) {
+        // An invalidated capture leaves the stream refusing every later operation ("previous error during capture"), so
+        // one bad capture would end the client's session for good. Replace the stream: this call fails (the session logs
+        // it and moves on to the next chunk, whisper_live/backend/base.py:134-137), the next one captures afresh.
+        (void)hipGetLastError();
+        hipStream_t ns = nullptr;
+        if (hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) == hipSuccess) {
+            (void)hipStreamDestroy(s->stream);
+            s->stream = ns;
+        }
+        return fail(WLX_ERR_HIP, "decode-step graph capture failed: %s (slot stream replaced)", hipGetErrorString(ce));
+    }
     hipGraphExec_t exec;
     CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     CK(hipGraphDestroy(graph));
@@ -1087,8 +1157,9 @@ extern "C" int32_t wlx_generate_ex(wlx_engine* e, int32_t slot, int32_t batch, c
                                    const int32_t* prompts, const int32_t* prompt_lens, int32_t prompt_stride,
                                    const wlx_gen_opts* opts, int32_t* tokens_out, int32_t tokens_stride,
                                    int32_t* n_tokens_out, float* scores_out, float* no_speech_prob_out) {
-    Slot* s;
-    CKR(slot_get(e, slot, &s));
+    SlotGuard sg_;
+    CKR(slot_acquire(e, slot, sg_));
+    Slot* s = sg_.s;
     if (!prompts || !prompt_lens || !tokens_out || !n_tokens_out || !scores_out) return fail(WLX_ERR_ARG, "null argument");
     if (batch < 1 || batch > s->B) return fail(WLX_ERR_ARG, "batch %d out of range (slot max %d)", batch, s->B);
     if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "generate before encode");
@@ -1113,8 +1184,9 @@ extern "C" int32_t wlx_generate(wlx_engine* e, int32_t slot, int32_t batch, cons
 extern "C" int32_t wlx_debug_search(wlx_engine* e, int32_t slot, const float* logits, int32_t steps,
                                     const int32_t* prompt, int32_t prompt_len, const wlx_gen_opts* opts,
                                     int32_t* tokens_out, int32_t tokens_stride, int32_t* n_tokens_out, float* scores_out) {
-    Slot* s;
-    CKR(slot_get(e, slot, &s));
+    SlotGuard sg_;
+    CKR(slot_acquire(e, slot, sg_));
+    Slot* s = sg_.s;
     if (!logits || !prompt || !opts) return fail(WLX_ERR_ARG, "null argument");
     CK(hipSetDevice(e->device));
     float nsp;
@@ -1124,8 +1196,9 @@ extern "C" int32_t wlx_debug_search(wlx_engine* e, int32_t slot, const float* lo
 
 extern "C" int32_t wlx_detect_language(wlx_engine* e, int32_t slot, int32_t batch, int32_t sot, const int32_t* lang_ids,
                                        int32_t n_lang, float* probs_out) {
-    Slot* s;
-    CKR(slot_get(e, slot, &s));
+    SlotGuard sg_;
+    CKR(slot_acquire(e, slot, sg_));
+    Slot* s = sg_.s;
     if (batch < 1 || batch > s->enc_batch) return fail(WLX_ERR_STATE, "detect_language before encode");
     if (!lang_ids || n_lang < 1 || n_lang > 256 || !probs_out) return fail(WLX_ERR_ARG, "bad language id list");
     if (sot < 0 || sot >= e->spec.vocab) return fail(WLX_ERR_ARG, "bad sot id");
@@ -1243,8 +1316,9 @@ extern "C" int32_t wlx_align(wlx_engine* e, int32_t slot, int32_t item, const in
                              int32_t num_frames, int32_t median_filter_width, const int32_t* heads, int32_t n_heads, int32_t eot,
                              int32_t* text_indices, int32_t* time_indices, int32_t path_cap, int32_t* n_path_out,
                              float* text_token_probs) {
-    Slot* s;
-    CKR(slot_get(e, slot, &s));
+    SlotGuard sg_;
+    CKR(slot_acquire(e, slot, sg_));
+    Slot* s = sg_.s;
     if (!tokens || !heads || !text_indices || !time_indices || !n_path_out || !text_token_probs) return fail(WLX_ERR_ARG, "null argument");
     if (item < 0 || item >= s->enc_batch) return fail(WLX_ERR_STATE, "align: item %d not encoded", item);
     if (n_sot < 1 || n_tokens < n_sot + 3 || n_tokens > WLX_T_TEXT) return fail(WLX_ERR_ARG, "align: %d tokens with a start sequence of %d", n_tokens, n_sot);
@@ -1312,8 +1386,9 @@ extern "C" int32_t wlx_align(wlx_engine* e, int32_t slot, int32_t item, const in
 // ------------------------------------------------------------------------------------------------
 // test hooks
 extern "C" int32_t wlx_debug_logits_get(wlx_engine* e, int32_t slot, float* out, int32_t rows, int64_t cap_floats) {
-    Slot* s;
-    CKR(slot_get(e, slot, &s));
+    SlotGuard sg_;
+    CKR(slot_acquire(e, slot, sg_));
+    Slot* s = sg_.s;
     const int V = e->spec.vocab;
     if (!out || rows < 1 || rows > s->rows_cap || (int64_t)rows * V > cap_floats) return fail(WLX_ERR_ARG, "bad rows/cap");
     CK(hipSetDevice(e->device));
@@ -1323,8 +1398,9 @@ extern "C" int32_t wlx_debug_logits_get(wlx_engine* e, int32_t slot, float* out,
 }
 
 extern "C" int32_t wlx_debug_decode_logits(wlx_engine* e, int32_t slot, const int32_t* tokens, int32_t n, float* out) {
-    Slot* s;
-    CKR(slot_get(e, slot, &s));
+    SlotGuard sg_;
+    CKR(slot_acquire(e, slot, sg_));
+    Slot* s = sg_.s;
     if (!tokens || !out || n < 1 || n > WLX_T_TEXT) return fail(WLX_ERR_ARG, "bad tokens");
     if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "decode before encode");
     for (int i = 0; i < n; ++i) if (tokens[i] < 0 || tokens[i] >= e->spec.vocab) return fail(WLX_ERR_ARG, "token out of vocabulary");
@@ -1338,8 +1414,9 @@ extern "C" int32_t wlx_debug_decode_logits(wlx_engine* e, int32_t slot, const in
 
 extern "C" int32_t wlx_debug_time_decode_step(wlx_engine* e, int32_t slot, int32_t rows, int32_t t, int32_t iters,
                                               float* avg_ms_out) {
-    Slot* s;
-    CKR(slot_get(e, slot, &s));
+    SlotGuard sg_;
+    CKR(slot_acquire(e, slot, sg_));
+    Slot* s = sg_.s;
     if (rows < 1 || rows > s->cache_rows || rows > 16 || t < 0 || t >= WLX_T_TEXT || iters < 1 || !avg_ms_out)
         return fail(WLX_ERR_ARG, "bad arguments");
     if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "decode before encode");
@@ -1378,8 +1455,9 @@ extern "C" int32_t wlx_debug_trace_step(wlx_engine* e, int32_t slot, int32_t row
     (void)e; (void)slot; (void)rows; (void)t; (void)with_search; (void)out; (void)cap_u64; (void)names; (void)n_launches_out;
     return fail(WLX_ERR_STATE, "libwlx.so was built without -DWLX_TRACE (use libwlx_trace.so, scripts/trace_step.py)");
 #else
-    Slot* s;
-    CKR(slot_get(e, slot, &s));
+    SlotGuard sg_;
+    CKR(slot_acquire(e, slot, sg_));
+    Slot* s = sg_.s;
     if (rows < 1 || rows > s->cache_rows || rows > 16 || t < 0 || t >= WLX_T_TEXT || !out || !names || !n_launches_out)
         return fail(WLX_ERR_ARG, "bad arguments");
     if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "decode before encode");
@@ -1421,7 +1499,8 @@ extern "C" int32_t wlx_debug_trace_step(wlx_engine* e, int32_t slot, int32_t row
     CK(hipStreamSynchronize(st));
     CK(hipGraphExecDestroy(exec));
     if ((int64_t)n * WLX_TR_STRIDE > cap_u64) { (void)hipFree(buf); return fail(WLX_ERR_ARG, "trace buffer too small"); }
-    CK(hipMemcpy(out, buf, (size_t)n * WLX_TR_STRIDE * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpyAsync(out, buf, (size_t)n * WLX_TR_STRIDE * 8, hipMemcpyDeviceToHost, st));
+    CK(hipStreamSynchronize(st));
     CK(hipFree(buf));
     for (int i = 0; i < n; ++i) { strncpy(names + (size_t)i * 48, g_trace_names[i] ? g_trace_names[i] : "?", 47); names[(size_t)i * 48 + 47] = 0; }
     *n_launches_out = n;
@@ -1431,8 +1510,9 @@ extern "C" int32_t wlx_debug_trace_step(wlx_engine* e, int32_t slot, int32_t row
 
 extern "C" int32_t wlx_debug_profile_step(wlx_engine* e, int32_t slot, int32_t rows, int32_t t, int32_t iters,
                                           wlx_kernel_stat* out, int32_t cap, int32_t* n_out) {
-    Slot* s;
-    CKR(slot_get(e, slot, &s));
+    SlotGuard sg_;
+    CKR(slot_acquire(e, slot, sg_));
+    Slot* s = sg_.s;
     if (rows < 1 || rows > s->cache_rows || rows > 16 || t < 0 || t >= WLX_T_TEXT || iters < 1 || !out || !n_out || cap < 1)
         return fail(WLX_ERR_ARG, "bad arguments");
     if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "decode before encode");

@@ -334,7 +334,8 @@ static int vad_upload(wlx_vad* v, const std::vector<float>& host, const float** 
     void* p = nullptr;
     VCK(hipMalloc(&p, host.size() * sizeof(float)));
     v->pool.push_back(p);
-    VCK(hipMemcpy(p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice));
+    VCK(hipMemcpyAsync(p, host.data(), host.size() * sizeof(float), hipMemcpyHostToDevice, v->stream));   // never the legacy stream
+    VCK(hipStreamSynchronize(v->stream));
     *out = reinterpret_cast<const float*>(p);
     return WLX_OK;
 }
@@ -443,6 +444,7 @@ extern "C" int32_t wlx_vad_probs(wlx_vad* v, const float* pcm, int64_t n, float*
     if (T > cap) return set_error(WLX_ERR_ARG, "wlx_vad_probs: %lld windows do not fit the output buffer (%d)", T, cap);
     std::lock_guard<std::mutex> lk(v->mu);
     VCK(hipSetDevice(v->device));
+    (void)hipGetLastError();                  // a stale error of this thread must not be blamed on the launches below
     int rc = vad_reserve(v, n);
     if (rc) return rc;
     memcpy(v->h_pin, pcm, (size_t)n * sizeof(float));

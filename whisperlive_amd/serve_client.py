@@ -122,7 +122,11 @@ class ServeClientBase:
                 logging.error(f"[ERROR]: Failed to transcribe audio chunk: {e}")
                 wl_metrics.track_error("transcription")
                 time.sleep(0.01)
+        self.on_transcription_thread_exit()
         logging.info("Exiting speech to text thread")
+
+    def on_transcription_thread_exit(self):
+        """Hook run by the transcription thread as it ends (backends release per-thread resources here)."""
 
     def transcribe_audio(self, input_sample):
         raise NotImplementedError
@@ -376,6 +380,11 @@ class ServeClientHIP(ServeClientBase):
         if self.language is None and info is not None:
             self.set_language(info)
         return result
+
+    def on_transcription_thread_exit(self):
+        release = getattr(type(self.transcriber), "release_slot", None) if hasattr(self, "transcriber") else None
+        if release is not None:
+            self.transcriber.release_slot()            # the engine slot goes back to the per-GPU pool
 
     def handle_transcription_output(self, result, duration):
         segments = []

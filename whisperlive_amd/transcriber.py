@@ -326,14 +326,35 @@ class WhisperModelHIP:
 
     # ---- slots: one per calling thread (the reference runs one transcription thread per client)
     def _slot(self) -> Slot:
+        """The calling thread's slot. A slot is a few hundred MB of HBM (encoder activations, cross K/V, KV cache), so
+        slots are POOLED: a thread that needs one first takes over a slot whose owner thread has ended (a client that
+        disconnected) or that was handed back with release_slot(); a new one is created only when every slot is in use.
+        The pool therefore holds max-concurrent-clients slots, not one per connection ever made, and reconnecting
+        clients reuse the captured decode graphs of their predecessor."""
         s = getattr(self._tls, "slot", None)
         if s is None or s.sid < 0:
-            s = self.engine.create_slot(self.max_batch, 5 if self.max_batch <= 12 else max(1, 64 // self.max_batch))
-            s._enc_generation = 0
-            self._tls.slot = s
+            me = threading.current_thread()
             with self._slots_lock:
-                self._slots.append(s)
+                self._slots = [x for x in self._slots if x.sid >= 0]
+                s = next((x for x in self._slots if x._owner is None or not x._owner.is_alive()), None)
+                if s is not None:
+                    s._owner = me
+            if s is None:
+                s = self.engine.create_slot(self.max_batch, 5 if self.max_batch <= 12 else max(1, 64 // self.max_batch))
+                s._enc_generation = 0
+                s._owner = me
+                with self._slots_lock:
+                    self._slots.append(s)
+            self._tls.slot = s
         return s
+
+    def release_slot(self):
+        """Hand the calling thread's slot back to the pool (a session thread calls this when it exits)."""
+        s = getattr(self._tls, "slot", None)
+        if s is not None:
+            self._tls.slot = None
+            with self._slots_lock:
+                s._owner = None
 
     def _next_seed(self) -> int:
         return next(self._seed)
