@@ -403,3 +403,51 @@ def test_e2e_four_clients_shard_over_devices_and_batch_workers(running_server):
     for i, c in enumerate(conns):
         assert _recv_json(c)["uid"] == f"u{i}"
         c.close()
+
+
+def test_soak_connections_leave_no_threads_and_bounded_slot_pool(running_server):
+    """A long-running server: many short connections (sequential, then bursts of four) against the real host stack
+    (ServeClientHIP -> WhisperModelHIP on a scripted engine). Afterwards no session / handler threads remain and the
+    engine slot pool is bounded by the number of clients connected AT ONCE, not by the number of connections made."""
+    from tests.fakes import FakeEngine
+    from whisperlive_amd.tokenizer import synthetic_tokenizer
+    from whisperlive_amd.transcriber import WhisperModelHIP
+    eng = FakeEngine()
+    tb = eng.spec.vocab - 1501
+    eng.default_tokens = [tb, 300, 301, tb + 50, tb + 50, 302, tb + 90]
+    model = WhisperModelHIP("fake", engine=eng, hf_tokenizer=synthetic_tokenizer(eng.spec.vocab), max_batch=1)
+    srv = running_server(single_model=True, max_clients=4, model_factory=lambda m, d: model)
+    base_threads = threading.active_count()
+    pcm = (0.1 * np.sin(np.arange(24000) * 0.07)).astype(np.float32)
+
+    def one(uid, errs):
+        try:
+            c = ws.connect(f"ws://127.0.0.1:{srv.port}")
+            c.send(json.dumps(dict(OPTS, uid=uid)))
+            assert _recv_json(c)["message"] == "SERVER_READY"
+            c.send(pcm.tobytes())
+            assert _recv_json(c)["uid"] == uid
+            c.send(b"END_OF_AUDIO")
+            with pytest.raises(ws.ConnectionClosed):
+                for _ in range(100):
+                    c.recv(timeout=5.0)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    errs = []
+    for i in range(12):
+        one(f"s{i}", errs)
+    for r in range(3):
+        ts = [threading.Thread(target=one, args=(f"b{r}_{k}", errs)) for k in range(4)]
+        [t.start() for t in ts]
+        [t.join(30) for t in ts]
+    assert not errs, errs[:3]
+    deadline = time.time() + 10
+    while time.time() < deadline and (threading.active_count() > base_threads or srv.client_manager.clients):
+        time.sleep(0.05)
+    assert threading.active_count() <= base_threads, [t.name for t in threading.enumerate()]
+    assert not srv.client_manager.clients and not srv.audio_formats
+    # 24 connections were made; at most 4 were open at once, and a closing session may still be finishing its last
+    # chunk when its successor connects -> the pool is bounded by 2 x max_clients, independent of the connection count
+    assert 1 <= len(eng.slots) <= 8, len(eng.slots)
+    assert metrics.snapshot()["connections"]["active"] == 0

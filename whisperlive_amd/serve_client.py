@@ -65,6 +65,7 @@ class ServeClientBase:
         self.language = None
         self.lock = threading.Lock()
         self.frames_ready = threading.Event()
+        self._wake = threading.Event()    # set by cleanup(): the loop's pauses (the reference's time.sleep calls) end at once
 
     # ---- audio buffer ------------------------------------------------------------------------------------------
     def add_frames(self, frame_np: np.ndarray):
@@ -105,7 +106,7 @@ class ServeClientBase:
                 self.clip_audio_if_no_valid_segment()
             chunk, duration = self.get_audio_chunk_for_processing()
             if duration < 1.0:
-                time.sleep(0.1)
+                self._pause(0.1)
                 continue
             try:
                 sample = chunk.copy()
@@ -113,7 +114,7 @@ class ServeClientBase:
                 result = self.transcribe_audio(sample)
                 if result is None or self.language is None:
                     self.timestamp_offset += duration          # no voice activity in this chunk
-                    time.sleep(0.25)
+                    self._pause(0.25)
                     continue
                 wl_metrics.track_transcription_latency(time.time() - t0)
                 wl_metrics.track_audio_processed(duration)
@@ -175,6 +176,12 @@ class ServeClientBase:
         logging.info("Cleaning up.")
         self.exit = True
         self.frames_ready.set()
+        self._wake.set()
+
+    def _pause(self, seconds: float):
+        """The reference sleeps here (base.py:117,128,445); same duration, but a session being torn down does not linger
+        in it holding its engine slot."""
+        self._wake.wait(seconds)
 
     # ---- segment accessors (backends name these fields differently) ------------------------------------------
     def get_segment_no_speech_prob(self, segment):
@@ -254,7 +261,7 @@ class ServeClientBase:
             self.same_output_count += 1
             if self.end_time_for_same_output is None:          # remember when the repetition started
                 self.end_time_for_same_output = self.get_segment_end(tail)
-            time.sleep(0.1)                                    # base.py:445 — wait briefly for new voice activity
+            self._pause(0.1)                                   # base.py:445 — wait briefly for new voice activity
         else:
             self.same_output_count = 0
             self.end_time_for_same_output = None
