@@ -12,7 +12,9 @@
 // per wave (first form; 128 B/clk/CU demanded of a 64 B/clk L1) 39 us; THIS form 32 us; a 4-deep LDS ring filled by
 // LDS-direct loads (global_load_lds_dwordx4) 34-38 us (LDS-direct fills are issue-limited per wave); two register sets
 // (two stages of loads in flight) 36-48 us (188 VGPRs: occupancy). At M = 1500 and N = 768..3072 the launches are
-// short (12-96 stages per workgroup) and still latency-dominated.
+// short (12-96 stages per workgroup) and still latency-dominated. Forcing one tile shape for every GEMM of the encoder
+// (128x128 / 128x64 / 64x64 workgroup tiles) moves the encoder by 2 % at most (2.21 ms chosen per shape as below, 2.19 / 2.17 ms
+// all-128x64 / all-64x64, 2.62 ms all-128x128): the stage loop's latency, not the tiling or the 1.1-wave grids, bounds it.
 // Wave tile = WNT x WMT 16x16 tiles; a 4-wave workgroup covers (2*WNT*16) x (2*WMT*16) outputs. Epilogues are fused
 // (bias, exact GELU,
 // positional add, residual accumulate in fp32, q-scaling, K/V scatter with V stored transposed
