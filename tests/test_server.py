@@ -451,3 +451,19 @@ def test_soak_connections_leave_no_threads_and_bounded_slot_pool(running_server)
     # chunk when its successor connects -> the pool is bounded by 2 x max_clients, independent of the connection count
     assert 1 <= len(eng.slots) <= 8, len(eng.slots)
     assert metrics.snapshot()["connections"]["active"] == 0
+
+
+def test_cli_maps_flags_onto_run(monkeypatch):
+    """`python -m whisperlive_amd.server`: the reference's run_server.py flags that apply here reach run() unchanged."""
+    from whisperlive_amd import server as srv_mod
+    seen = {}
+    monkeypatch.setattr(srv_mod.TranscriptionServer, "run", lambda self, host, **kw: seen.update(host=host, **kw))
+    srv_mod.main(["--port", "9191", "--backend", "faster_whisper", "-fw", "/models/x", "--max_clients", "7", "--max_connection_time", "99",
+                  "--batch_inference", "--batch_max_size", "6", "--batch_window_ms", "12", "--raw_pcm_input", "--devices", "0,2,3",
+                  "--api_key", "k", "--metrics_port", "9100"])
+    assert seen == dict(host="0.0.0.0", port=9191, backend="faster_whisper", faster_whisper_custom_model_path="/models/x",
+                        single_model=True, max_clients=7, max_connection_time=99, batch_enabled=True, batch_max_size=6,
+                        batch_window_ms=12, raw_pcm_input=True, metrics_port=9100, api_key="k", devices=[0, 2, 3])
+    seen.clear()
+    srv_mod.main(["--no_single_model"])
+    assert seen["single_model"] is False and seen["backend"] == "hip" and seen["devices"] == [0] and seen["port"] == 9090
