@@ -23,9 +23,12 @@
  * 0 on success and a non-zero wlx_status otherwise (no exceptions cross the boundary, no
  * callbacks into the host language); wlx_last_error() returns a thread-local message.
  * Threading: concurrent calls are safe on DISTINCT slots (each slot owns a HIP stream and all
- * of its scratch); calls on the same slot must be serialised by the caller, which is what the
+ * of its scratch); calls on the same slot are to be serialised by the caller, which is what the
  * reference does (one transcription thread per client, faster_whisper_backend.py:121; or the
- * single batch-worker thread, batch_inference.py:155-187).
+ * single batch-worker thread, batch_inference.py:155-187). The library enforces it: a second call
+ * on a busy slot returns WLX_ERR_STATE instead of running, wlx_slot_destroy waits for the call in
+ * flight, slot ids are never reused. No entry point uses the legacy (null) HIP stream, so slot
+ * creation and destruction are safe while other slots are decoding.
  */
 #ifndef WLX_H
 #define WLX_H
