@@ -81,6 +81,9 @@ class HipWhisperEngine:
             self._h = None
 
     def __del__(self):
+        import sys
+        if sys.is_finalizing():      # interpreter shutdown: daemon session threads may still be inside a call; the
+            return                   # process is about to return the device memory anyway
         try:
             self.close()
         except Exception:

@@ -142,11 +142,8 @@ class SileroHIPModel:
             self.lib.wlx_vad_destroy(self.handle)
             self.handle = None
 
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:  # noqa: BLE001
-            pass
+    # no __del__: at interpreter shutdown the HIP runtime may already be gone; close() is explicit, and a process that
+    # exits without it simply returns the device memory with its context
 
 
 _default_model: Optional[Callable[[np.ndarray], np.ndarray]] = None
