@@ -96,23 +96,52 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     __syncthreads();
     for (int st = 0; st < S; ++st) {
         const bool more = st + 1 < S;
+#ifndef WLX_PROBE_NO_GLOAD   // (WLX_PROBE_*: scripts/ubench/gemm_probe.hip removes one pipeline phase at a time; never defined in libwlx)
         if (more) gload((st + 1) * KS);                                   // next stage in flight under this stage's MFMAs
+#endif
         const f16x8* src = stage_lds + (long)(st & 1) * (FA + FB) * 64 + lane;
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
             f16x8 wf[WNT], af[WMT];
 #pragma unroll
+#ifndef WLX_PROBE_NO_LREAD
             for (int ni = 0; ni < WNT; ++ni) wf[ni] = src[((wn * WNT + ni) * KS + kk) * 64];
 #pragma unroll
             for (int mi = 0; mi < WMT; ++mi) af[mi] = src[(FA + (wm * WMT + mi) * KS + kk) * 64];
+#else
+            for (int ni = 0; ni < WNT; ++ni) wf[ni] = ra[ni % CA];
+#pragma unroll
+            for (int mi = 0; mi < WMT; ++mi) af[mi] = rb[mi % CB];
+#endif
 #pragma unroll
             for (int ni = 0; ni < WNT; ++ni)
 #pragma unroll
-                for (int mi = 0; mi < WMT; ++mi) acc[ni][mi] = mfma16(wf[ni], af[mi], acc[ni][mi]);
+                for (int mi = 0; mi < WMT; ++mi) {
+#ifndef WLX_PROBE_NO_MFMA
+                    acc[ni][mi] = mfma16(wf[ni], af[mi], acc[ni][mi]);
+#else
+                    asm volatile("" :: "v"(wf[ni]), "v"(af[mi]));
+#endif
+                }
         }
+#ifndef WLX_PROBE_NO_LSTORE
         if (more) lstore((st + 1) & 1);                                   // the other buffer: last read one barrier ago
+#endif
+#ifndef WLX_PROBE_NO_BARRIER
         __syncthreads();
+#endif
     }
+#ifdef WLX_PROBE_NO_EPILOGUE
+    {
+        float t = 0.f;
+#pragma unroll
+        for (int ni = 0; ni < WNT; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < WMT; ++mi) t += acc[ni][mi][0] + acc[ni][mi][1] + acc[ni][mi][2] + acc[ni][mi][3];
+        if (t == 1.2345e30f) p.X[0] = t;
+        return;
+    }
+#endif
 
     // ---------------- epilogue: lane owns columns n..n+3 of row m
 #pragma unroll
