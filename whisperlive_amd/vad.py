@@ -165,6 +165,9 @@ def get_default_model() -> Callable[[np.ndarray], np.ndarray]:
         elif path and os.path.isfile(path):
             _default_model = SileroOnnxModel(path)
         else:
+            import logging
+            logging.warning("VAD: no Silero weights configured (WLX_SILERO_VAD_NPZ / WLX_SILERO_VAD_ONNX); using the energy-gate "
+                            "stand-in, which is NOT the reference's speech detector")
             _default_model = EnergyGateModel()
     return _default_model
 
