@@ -599,13 +599,13 @@ class WhisperModelHIP:
                 def align_fn(text_tokens, num_frames, _window):
                     r = self.model.align(enc_now, tokenizer.sot_sequence, [text_tokens], num_frames)[0]
                     pairs = np.asarray(r.alignments, dtype=np.int64).reshape(-1, 2)
-                    return pairs[:, 0], pairs[:, 1], np.asarray(r.text_token_probs, dtype=np.float32)
+                    return pairs[:, 0], pairs[:, 1], np.asarray(r.text_token_probs, dtype=np.float64)   # fp32 values, means in double like np.mean over CT2's Python floats
 
-                upd = _wt.add_word_timestamps([current], tokenizer, align_fn, segment_size, self.tokens_per_second,
-                                              self.frames_per_second, options.prepend_punctuations,
-                                              options.append_punctuations, last_speech_timestamp)
-                if upd is not None:
-                    last_speech_timestamp = upd
+                # the reference discards add_word_timestamps' return value here (:1227-1235): the last-speech time only
+                # moves at the end of this block, so the hallucination rules below still see the PREVIOUS window's
+                _wt.add_word_timestamps([current], tokenizer, align_fn, segment_size, self.tokens_per_second,
+                                        self.frames_per_second, options.prepend_punctuations,
+                                        options.append_punctuations, last_speech_timestamp)
                 if not single_ts_ending:
                     lwe = _wt.last_word_end(current)
                     if lwe is not None and lwe > time_offset:

@@ -5,12 +5,14 @@ that only exist with word timings (:1186-1291). Pure bookkeeping over (text inde
 scores, token probabilities and the DTW come from libwlx."""
 from __future__ import annotations
 
-import string
+
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import numpy as np
 
 SENTENCE_END = ".。!！?？"
+# the reference's own list for the anomaly score (:1078; a SUBSTRING test against this string, not a set of characters)
+ANOMALY_PUNCTUATION = "\"'“¿([{-\"'.。,，!！?？:：”)]}、"
 
 
 def last_word_end(segments: List[dict]) -> Optional[float]:
@@ -154,7 +156,7 @@ def word_anomaly_score(word: dict) -> float:
 def is_segment_anomaly(segment: Optional[dict]) -> bool:
     if segment is None or not segment["words"]:
         return False
-    words = [w for w in segment["words"] if w["word"] not in string.punctuation][:8]
+    words = [w for w in segment["words"] if w["word"] not in ANOMALY_PUNCTUATION][:8]
     score = sum(word_anomaly_score(w) for w in words)
     return score >= 3 or score + 0.01 >= len(words)
 
