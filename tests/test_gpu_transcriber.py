@@ -26,12 +26,15 @@ def pair(gpu):
     from whisperlive_amd.specs import WhisperSpec
     from whisperlive_amd.tokenizer import synthetic_tokenizer
     from whisperlive_amd.transcriber import WhisperModelHIP
+    from whisperlive_amd.vad import EnergyGateModel
     from whisperlive_amd.weights import random_weights
     spec = WhisperSpec(n_mels=80, d_model=256, n_heads=4, enc_layers=2, dec_layers=2, ffn=1024, vocab=4310)
     w = random_weights(spec, seed=21)
     tok = synthetic_tokenizer(spec.vocab)
-    hip = WhisperModelHIP("rand", weights=w, spec=spec, hf_tokenizer=tok, max_batch=4, multilingual=True)
-    ora = WhisperModelHIP("rand", engine=OracleEngine(spec, H.f16_weights(w)), hf_tokenizer=tok, max_batch=4, multilingual=True)
+    gate = EnergyGateModel()        # explicit, labelled stand-in (the Silero network itself: tests/test_vad_model.py)
+    hip = WhisperModelHIP("rand", weights=w, spec=spec, hf_tokenizer=tok, max_batch=4, multilingual=True, vad_model=gate)
+    ora = WhisperModelHIP("rand", engine=OracleEngine(spec, H.f16_weights(w)), hf_tokenizer=tok, max_batch=4, multilingual=True,
+                          vad_model=gate)
     yield hip, ora
     hip.close()
     hip.engine.close()

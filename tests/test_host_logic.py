@@ -18,7 +18,7 @@ V = 2310
 @pytest.fixture()
 def model():
     eng = FakeEngine()
-    return WhisperModelHIP("fake", engine=eng, hf_tokenizer=synthetic_tokenizer(V)), eng
+    return WhisperModelHIP("fake", engine=eng, hf_tokenizer=synthetic_tokenizer(V), vad_model=vad.EnergyGateModel()), eng
 
 
 @pytest.fixture()
@@ -268,3 +268,41 @@ def test_model_construction_errors():
         WhisperModelHIP("fake", engine=FakeEngine(), hf_tokenizer=synthetic_tokenizer(V + 16))
     with pytest.raises(FileNotFoundError):
         WhisperModelHIP("/nonexistent/model/dir")
+
+
+def test_tokenizer_json_without_timestamp_entries_is_accepted():
+    """Older converted checkpoints (Systran faster-whisper-tiny … large-v2) ship a tokenizer.json that ends at
+    <|notimestamps|>: ~50364 ids against a 51865-row model. faster-whisper derives timestamp ids as no_timestamps + 1 and
+    never looks them up, so such a tokenizer must load and transcribe."""
+    tok = synthetic_tokenizer(V, timestamps=False)
+    assert tok.get_vocab_size() == V - 1501 and tok.token_to_id("<|0.00|>") is None
+    eng = FakeEngine()
+    m = WhisperModelHIP("fake", engine=eng, hf_tokenizer=tok)
+    tb = m.token_ids.timestamp_begin
+    assert tb == V - 1501 == Tokenizer(tok, False).no_timestamps + 1
+    words = Tokenizer(tok, False).encode(" hello there")
+    eng.default_tokens = [tb] + words + [tb + 100]
+    segs, _info = m.transcribe(np.zeros(3 * 16000, np.float32) + 0.01, language="en")
+    assert [s.text for s in segs] == [" hello there"] and (segs[0].start, segs[0].end) == (0.0, 2.0)
+    res = m.model.generate(m.encode(np.zeros((80, 3000), np.float32)), [[m.token_ids.sot]])
+    assert res[0].sequences[0][0] == "<|0.00|>" and res[0].sequences[0][-1] == "<|2.00|>"
+    # specials that do not fit the model's vocabulary are still refused
+    small = FakeEngine()
+    small.spec = type(small.spec)(80, 128, 2, 1, 1, 512, V - 1501 + 10)
+    with pytest.raises(ValueError, match="do not fit"):
+        WhisperModelHIP("fake", engine=small, hf_tokenizer=tok)
+
+
+def test_metrics_record_is_bounded_and_xrt_stays_exact():
+    from whisperlive_amd import metrics
+    metrics.snapshot(reset=True)
+    n = metrics.WINDOW + 1000
+    for i in range(n):
+        metrics.track_transcription_latency(0.01 if i < n - 100 else 1.0)
+        metrics.track_audio_processed(0.5)
+    assert len(metrics._latencies) == metrics.WINDOW                       # a long-running server does not grow
+    snap = metrics.snapshot(reset=True)
+    assert snap["chunks"] == n and abs(snap["audio_s"] - 0.5 * n) < 1e-6
+    assert abs(snap["xrt"] - (0.5 * n) / (0.01 * (n - 100) + 100.0)) < 1e-9   # sums cover every chunk, not the window
+    assert snap["p50_latency_s"] == 0.01 and snap["p95_latency_s"] == 0.01
+    assert metrics.snapshot()["chunks"] == 0

@@ -463,7 +463,95 @@ def test_cli_maps_flags_onto_run(monkeypatch):
                   "--api_key", "k", "--metrics_port", "9100"])
     assert seen == dict(host="0.0.0.0", port=9191, backend="faster_whisper", faster_whisper_custom_model_path="/models/x",
                         single_model=True, max_clients=7, max_connection_time=99, batch_enabled=True, batch_max_size=6,
-                        batch_window_ms=12, raw_pcm_input=True, metrics_port=9100, api_key="k", devices=[0, 2, 3])
+                        batch_window_ms=12, raw_pcm_input=True, metrics_port=9100, api_key="k", devices=[0, 2, 3], vad_weights=None)
+    seen.clear()
+    srv_mod.main(["--vad_weights", "/models/silero_vad.onnx"])
+    assert seen["vad_weights"] == "/models/silero_vad.onnx"
     seen.clear()
     srv_mod.main(["--no_single_model"])
     assert seen["single_model"] is False and seen["backend"] == "hip" and seen["devices"] == [0] and seen["port"] == 9090
+
+
+def test_batch_inference_with_concurrent_clients_uses_slots_as_wide_as_the_batches(running_server, monkeypatch):
+    """--batch_inference with several clients submitting inside one batch window: the shared
+    transcriber the server creates must own slots as wide as the worker's batches, or every batch of >= 2 fails with
+    'batch N exceeds the slot's max_batch 1' and the sessions retry forever."""
+    from tests.fakes import FakeEngine
+    from whisperlive_amd.tokenizer import synthetic_tokenizer
+    from whisperlive_amd.transcriber import WhisperModelHIP
+    eng = FakeEngine()
+    tb = eng.spec.vocab - 1501
+    eng.default_tokens = [tb, 300, 301, tb + 50]
+    made = []
+
+    def create_model(model, device_index, max_batch=1):
+        made.append(max_batch)
+        return WhisperModelHIP("fake", engine=eng, hf_tokenizer=synthetic_tokenizer(eng.spec.vocab), max_batch=max_batch)
+
+    monkeypatch.setattr(ServeClientHIP, "create_model", staticmethod(create_model))
+    srv = running_server(batch_enabled=True, batch_max_size=4, batch_window_ms=400, max_clients=4, model_factory=None)
+    conns = []
+    for i in range(3):
+        c = ws.connect(f"ws://127.0.0.1:{srv.port}")
+        c.send(json.dumps(dict(OPTS, uid=f"b{i}")))
+        assert _recv_json(c)["message"] == "SERVER_READY"
+        conns.append(c)
+    assert made == [4]                                           # one shared transcriber, slots 4 items wide
+    worker = ServeClientHIP.BATCH_WORKERS[0]
+    assert worker.max_batch_size == 4
+    pcm = (0.1 * np.sin(np.arange(2 * 16000) * 0.05)).astype(np.float32)
+    for c in conns:                                              # all three land inside one 400 ms batch window
+        c.send(pcm.tobytes())
+    for i, c in enumerate(conns):
+        msg = _recv_json(c)
+        assert msg["uid"] == f"b{i}" and msg["segments"], msg
+        c.close()
+    batched = [c for s in eng.slots for c in s.calls if c[0] == "encode" and c[1] >= 2]
+    assert batched, [c for s in eng.slots for c in s.calls if c[0] == "encode"]   # at least one true multi-item encode
+    assert metrics.snapshot()["errors"].get("transcription", 0) == 0
+
+
+def test_batch_worker_clamps_to_the_transcribers_slot_width():
+    from unittest.mock import MagicMock
+    from types import SimpleNamespace
+    from whisperlive_amd.batching import BatchInferenceWorker
+    assert BatchInferenceWorker(SimpleNamespace(max_batch=2), max_batch_size=8).max_batch_size == 2
+    assert BatchInferenceWorker(SimpleNamespace(max_batch=16), max_batch_size=8).max_batch_size == 8
+    assert BatchInferenceWorker(MagicMock(), max_batch_size=8).max_batch_size == 8       # mocked / duck-typed: unchanged
+
+
+def test_use_vad_without_silero_weights_is_refused_with_a_warning(running_server, monkeypatch):
+    from whisperlive_amd import vad
+    for k in ("WLX_SILERO_VAD_NPZ", "WLX_SILERO_VAD_ONNX", "WLX_ALLOW_VAD_STANDIN"):
+        monkeypatch.delenv(k, raising=False)
+    vad.set_default_model(None)
+    seen = {}
+
+    def create_model(model, device_index, max_batch=1):
+        return ScriptedTranscriber()
+
+    monkeypatch.setattr(ServeClientHIP, "create_model", staticmethod(create_model))
+    srv = running_server(single_model=True, model_factory=None)
+    c = ws.connect(f"ws://127.0.0.1:{srv.port}")
+    c.send(json.dumps(dict(OPTS, use_vad=True)))
+    warn = _recv_json(c)
+    assert warn["status"] == "WARNING" and "use_vad" in warn["message"]
+    assert _recv_json(c)["message"] == "SERVER_READY"
+    c.send(np.zeros(2 * 16000, np.float32).tobytes())
+    assert _recv_json(c)["uid"] == "u1"
+    tr = ServeClientHIP.MODELS[0]
+    assert tr.calls[0][1]["vad_filter"] is False                  # the session runs ungated rather than mis-gated
+    c.close()
+    # with a configured model the request is honoured
+    vad.set_default_model(vad.EnergyGateModel())
+    try:
+        c = ws.connect(f"ws://127.0.0.1:{srv.port}")
+        c.send(json.dumps(dict(OPTS, uid="u2", use_vad=True)))
+        assert _recv_json(c)["message"] == "SERVER_READY"
+        c.send(np.zeros(2 * 16000, np.float32).tobytes())
+        assert _recv_json(c)["uid"] == "u2"
+        assert tr.calls[-1][1]["vad_filter"] is True
+        c.close()
+    finally:
+        vad.set_default_model(None)
+    del seen

@@ -18,6 +18,7 @@ from whisperlive_amd.engine import GenerationResult
 from whisperlive_amd.serve_client import ServeClientBase, ServeClientHIP
 from whisperlive_amd.tokenizer import Tokenizer, synthetic_tokenizer
 from whisperlive_amd.transcriber import WhisperModelHIP
+from whisperlive_amd.vad import EnergyGateModel
 
 V = 2310
 
@@ -114,7 +115,8 @@ def test_speech_to_text_loop_measures_latency_and_handles_errors(monkeypatch):
 
 
 def _model(engine=None):
-    return WhisperModelHIP("fake", engine=engine or FakeEngine(), hf_tokenizer=synthetic_tokenizer(V), max_batch=8)
+    return WhisperModelHIP("fake", engine=engine or FakeEngine(), hf_tokenizer=synthetic_tokenizer(V), max_batch=8,
+                           vad_model=EnergyGateModel())      # explicit, labelled stand-in: the host logic is what is tested
 
 
 def test_serve_client_hip_protocol_and_model_failure():

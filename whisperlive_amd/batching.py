@@ -53,6 +53,12 @@ class BatchInferenceWorker:
 
     def __init__(self, transcriber, max_batch_size: int = 8, batch_window_ms: int = 50):
         self.transcriber = transcriber
+        # never collect more requests than one engine slot can hold (WhisperModelHIP.max_batch); a duck-typed or mocked
+        # transcriber without that integer keeps the configured size
+        cap = getattr(transcriber, "max_batch", None)
+        if isinstance(cap, int) and not isinstance(cap, bool) and 1 <= cap < max_batch_size:
+            logging.warning(f"[BatchInference] max_batch_size {max_batch_size} clamped to the transcriber's slot width {cap}")
+            max_batch_size = cap
         self.max_batch_size = max_batch_size
         self.batch_window_ms = batch_window_ms
         self._queue: "queue.Queue[BatchRequest]" = queue.Queue()

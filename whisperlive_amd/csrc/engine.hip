@@ -433,9 +433,16 @@ static int slot_grow_audio(Engine* e, Slot* s, size_t n_samples) {
     CKR(dalloc(s->allocs, &npcm, (size_t)s->B * cap, false));
     CKR(dalloc(s->allocs, &nfe, (size_t)s->B * e->spec.n_mels * ld));
     // (old buffers stay in the pool until slot destruction; growth is rare: 1-2 times per stream)
+    if (s->pcm_cap) {
+        // keep what the other items of a batch already hold: a batched encode runs log-mel item by item, and a later,
+        // longer item must not wipe the earlier items' PCM / features / frame counts
+        CK(hipMemcpy2DAsync(npcm, cap * sizeof(float), s->pcm, s->pcm_cap * sizeof(float), s->pcm_cap * sizeof(float),
+                            (size_t)s->B, hipMemcpyDeviceToDevice, s->stream));
+        CK(hipMemcpy2DAsync(nfe, (size_t)ld * sizeof(float), s->feats, (size_t)s->feat_ld * sizeof(float),
+                            (size_t)s->feat_ld * sizeof(float), (size_t)s->B * e->spec.n_mels, hipMemcpyDeviceToDevice, s->stream));
+        CK(hipStreamSynchronize(s->stream));
+    }
     s->pcm = npcm; s->pcm_cap = cap; s->feats = nfe; s->feat_ld = ld;
-    std::fill(s->nframes.begin(), s->nframes.end(), 0);
-    std::fill(s->npcm.begin(), s->npcm.end(), 0);
     return WLX_OK;
 }
 

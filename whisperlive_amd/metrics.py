@@ -9,7 +9,7 @@ from __future__ import annotations
 
 import logging
 import threading
-from typing import List
+from collections import deque
 
 LATENCY_BUCKETS_S = (0.05, 0.1, 0.25, 0.5, 1.0, 2.5, 5.0, 10.0)
 # (python name, kind, exported name, label names) — the exported names and labels are the reference's, so a dashboard or
@@ -40,8 +40,11 @@ except ImportError:  # pragma: no cover
 
 # ---- in-process record (always on) -------------------------------------------------------------------------------------
 _lock = threading.Lock()
-_latencies: List[float] = []
-_audio_seconds: List[float] = []
+# running sums for xRT (exact over the whole run) + a bounded window of recent latencies for p50 / p95: a server that
+# stays up for weeks must not grow by one float per chunk
+WINDOW = 65536
+_latencies: "deque[float]" = deque(maxlen=WINDOW)
+_totals = {"chunks": 0, "latency_s": 0.0, "audio_s": 0.0}
 _errors = {}
 _segments = {"completed": 0, "partial": 0}
 _connections = {"opened": 0, "closed": 0, "active": 0, "rejected": 0}
@@ -93,13 +96,15 @@ def track_connection_rejected(reason: str = "full"):
 def track_transcription_latency(seconds: float):
     with _lock:
         _latencies.append(float(seconds))
+        _totals["chunks"] += 1
+        _totals["latency_s"] += float(seconds)
     if _AVAILABLE:
         TRANSCRIPTION_LATENCY.observe(seconds)
 
 
 def track_audio_processed(seconds: float):
     with _lock:
-        _audio_seconds.append(float(seconds))
+        _totals["audio_s"] += float(seconds)
     if _AVAILABLE:
         AUDIO_PROCESSED.inc(seconds)
 
@@ -124,17 +129,21 @@ def track_error(error_type: str = "transcription"):
 
 
 def snapshot(reset: bool = False) -> dict:
+    """xRT over everything recorded since the last reset; p50 / p95 over the most recent WINDOW chunks."""
     import statistics
     with _lock:
-        lat, aud = list(_latencies), list(_audio_seconds)
-        out = dict(chunks=len(lat), audio_s=sum(aud), latency_s=sum(lat), errors=dict(_errors), segments=dict(_segments),
-                   connections=dict(_connections),
-                   xrt=(sum(aud) / sum(lat)) if lat and sum(lat) > 0 else None,
-                   p50_latency_s=statistics.median(lat) if lat else None,
-                   p95_latency_s=(sorted(lat)[int(0.95 * (len(lat) - 1))] if lat else None))
+        lat = list(_latencies)
+        tot = dict(_totals)
+        out = dict(chunks=tot["chunks"], audio_s=tot["audio_s"], latency_s=tot["latency_s"], errors=dict(_errors),
+                   segments=dict(_segments), connections=dict(_connections))
         if reset:
-            _latencies.clear(); _audio_seconds.clear(); _errors.clear()
+            _latencies.clear(); _errors.clear()
+            _totals.update(chunks=0, latency_s=0.0, audio_s=0.0)
             _segments["completed"] = _segments["partial"] = 0
             for k in _connections:
                 _connections[k] = 0
+    lat.sort()                                                       # outside the lock
+    out["xrt"] = (tot["audio_s"] / tot["latency_s"]) if tot["chunks"] and tot["latency_s"] > 0 else None
+    out["p50_latency_s"] = statistics.median(lat) if lat else None
+    out["p95_latency_s"] = lat[int(0.95 * (len(lat) - 1))] if lat else None
     return out

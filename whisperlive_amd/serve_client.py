@@ -312,7 +312,7 @@ class ServeClientHIP(ServeClientBase):
                  no_speech_thresh=0.45, clip_audio=False, same_output_threshold=7, cache_path="~/.cache/whisper-live/",
                  translation_queue=None, hotwords=None, diarization=None, word_timestamps=False, *,
                  device_index: int = 0, transcriber=None, model_factory=None, serialize_single_model: bool = False,
-                 start_thread: bool = True):
+                 start_thread: bool = True, max_batch: int = 1):
         super().__init__(client_uid, websocket, send_last_n_segments, no_speech_thresh, clip_audio, same_output_threshold,
                          translation_queue, diarization, word_timestamps)
         self.cache_path = cache_path
@@ -334,7 +334,11 @@ class ServeClientHIP(ServeClientBase):
                 with ServeClientHIP.MODELS_LOCK:
                     key = (device_index, model) if not single_model else device_index
                     if key not in ServeClientHIP.MODELS:
-                        ServeClientHIP.MODELS[key] = (model_factory or self.create_model)(model, device_index)
+                        if model_factory is not None:
+                            ServeClientHIP.MODELS[key] = model_factory(model, device_index)
+                        else:
+                            # a transcriber that a batch worker will drive needs slots as wide as the worker's batches
+                            ServeClientHIP.MODELS[key] = self.create_model(model, device_index, max_batch=max_batch)
                     self.transcriber = ServeClientHIP.MODELS[key]
         except Exception as e:  # noqa: BLE001 — same client-visible behaviour as faster_whisper_backend.py:108-116
             logging.error(f"Failed to load model: {e}")
@@ -350,9 +354,10 @@ class ServeClientHIP(ServeClientBase):
                                         "backend": self.BACKEND_NAME}))
 
     @staticmethod
-    def create_model(model: str, device_index: int):
+    def create_model(model: str, device_index: int, max_batch: int = 1):
         from .transcriber import WhisperModelHIP
-        return WhisperModelHIP(model, device="cuda", device_index=device_index, compute_type="float16")
+        return WhisperModelHIP(model, device="cuda", device_index=device_index, compute_type="float16",
+                               max_batch=max(1, min(int(max_batch), 12)))
 
     def set_language(self, info):
         if info.language_probability > 0.5:

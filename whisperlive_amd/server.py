@@ -39,6 +39,7 @@ from urllib.parse import parse_qs, urlparse
 import numpy as np
 
 from . import metrics as wl_metrics
+from . import vad as _vad
 from . import ws
 from .serve_client import ServeClientBase, ServeClientHIP
 from .sharding import assign_gpu
@@ -191,6 +192,17 @@ class TranscriptionServer:
                 logging.info(f"Using custom model {faster_whisper_custom_model_path}")
                 options["model"] = faster_whisper_custom_model_path
             device_index = self._next_device()
+            use_vad = bool(options.get("use_vad"))
+            if use_vad and self.model_factory is None:
+                # the gate must be the reference's detector or nothing: without Silero weights the client is told and
+                # the session runs ungated (WLX_ALLOW_VAD_STANDIN=1 opts into the labelled energy gate instead)
+                try:
+                    _vad.get_default_model()
+                except _vad.VadUnavailable as e:
+                    logging.warning(f"use_vad requested by {options['uid']} but unavailable: {e}")
+                    websocket.send(json.dumps({"uid": options["uid"], "status": "WARNING",
+                                               "message": "use_vad ignored: no Silero VAD weights are configured on this server"}))
+                    use_vad = False
             client = ServeClientHIP(
                 websocket,
                 language=options["language"],
@@ -199,7 +211,7 @@ class TranscriptionServer:
                 model=options["model"],
                 initial_prompt=options.get("initial_prompt"),
                 vad_parameters=options.get("vad_parameters"),
-                use_vad=bool(options.get("use_vad")),
+                use_vad=use_vad,
                 single_model=self.single_model,
                 send_last_n_segments=options.get("send_last_n_segments", 10),
                 no_speech_thresh=options.get("no_speech_thresh", 0.45),
@@ -210,6 +222,7 @@ class TranscriptionServer:
                 word_timestamps=options.get("word_timestamps", False),
                 device_index=device_index,
                 model_factory=self.model_factory,
+                max_batch=self.batch_config["max_batch_size"] if self.batch_config is not None else 1,
             )
             if not hasattr(client, "transcriber"):          # model load failed: ERROR already sent, socket closed
                 return
@@ -315,7 +328,8 @@ class TranscriptionServer:
     def configure(self, backend="hip", faster_whisper_custom_model_path=None, whisper_tensorrt_path=None,
                   single_model=False, max_clients=4, max_connection_time=600, cache_path="~/.cache/whisper-live/",
                   enable_rest=False, batch_enabled=False, batch_max_size=8, batch_window_ms=50, raw_pcm_input=False,
-                  segment_post_processor=None, devices: Optional[Sequence[int]] = None, model_factory=None):
+                  segment_post_processor=None, devices: Optional[Sequence[int]] = None, model_factory=None,
+                  vad_weights: Optional[str] = None):
         """Argument validation and server state of ``run`` (server.py:644-690), split out so it can be used without
         opening a socket."""
         self.cache_path = cache_path
@@ -352,6 +366,8 @@ class TranscriptionServer:
         if any(d < 0 for d in self.devices):
             raise ValueError("device indices must be >= 0")
         self.model_factory = model_factory
+        if vad_weights:
+            _vad.configure(vad_weights, self.devices[0])         # silero_vad.onnx or .npz -> Silero on the GPU
         return BackendType(backend)
 
     def run(self, host, port=9090, backend="hip", faster_whisper_custom_model_path=None, whisper_tensorrt_path=None,
@@ -359,14 +375,15 @@ class TranscriptionServer:
             cache_path="~/.cache/whisper-live/", rest_port=8000, enable_rest=False, cors_origins: Optional[str] = None,
             batch_enabled=False, batch_max_size=8, batch_window_ms=50, raw_pcm_input=False, metrics_port: int = 0,
             api_key: Optional[str] = None, rate_limit_rpm: int = 0, segment_post_processor=None,
-            devices: Optional[Sequence[int]] = None, model_factory=None, ready: Optional[threading.Event] = None):
+            devices: Optional[Sequence[int]] = None, model_factory=None, ready: Optional[threading.Event] = None,
+            vad_weights: Optional[str] = None):
         """Serve until ``shutdown()``. Same arguments as the reference (server.py:600-622) plus ``devices`` (GPU
         indices to shard connections over), ``model_factory`` and ``ready`` (set once the socket is listening;
         ``self.port`` then holds the bound port — pass ``port=0`` for an ephemeral one)."""
         backend_type = self.configure(backend, faster_whisper_custom_model_path, whisper_tensorrt_path, single_model,
                                       max_clients, max_connection_time, cache_path, enable_rest, batch_enabled,
                                       batch_max_size, batch_window_ms, raw_pcm_input, segment_post_processor, devices,
-                                      model_factory)
+                                      model_factory, vad_weights)
         if metrics_port > 0:
             wl_metrics.start_metrics_server(metrics_port)
         extra = {}
@@ -409,13 +426,16 @@ def main(argv=None):
     ap.add_argument("--metrics_port", type=int, default=0)
     ap.add_argument("--api_key", default=os.environ.get("WHISPERLIVE_API_KEY"))
     ap.add_argument("--devices", default="0", help="comma-separated GPU indices to shard connections over")
+    ap.add_argument("--vad_weights", default=os.environ.get("WLX_SILERO_VAD_ONNX") or os.environ.get("WLX_SILERO_VAD_NPZ"),
+                    help="Silero VAD weights: the silero_vad.onnx the reference downloads, or an .npz export of it "
+                         "(python -m whisperlive_amd.silero_export); without it use_vad is refused with a WARNING")
     a = ap.parse_args(argv)
     TranscriptionServer().run(
         a.host, port=a.port, backend=a.backend, faster_whisper_custom_model_path=a.model_path,
         single_model=not a.no_single_model, max_clients=a.max_clients, max_connection_time=a.max_connection_time,
         batch_enabled=a.batch_inference, batch_max_size=a.batch_max_size, batch_window_ms=a.batch_window_ms,
         raw_pcm_input=a.raw_pcm_input, metrics_port=a.metrics_port, api_key=a.api_key,
-        devices=[int(x) for x in a.devices.split(",") if x != ""])
+        devices=[int(x) for x in a.devices.split(",") if x != ""], vad_weights=a.vad_weights)
 
 
 if __name__ == "__main__":

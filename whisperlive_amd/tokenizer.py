@@ -188,7 +188,7 @@ class Tokenizer:
         return sorted(out, key=lambda x: x[1])
 
 
-def synthetic_tokenizer(vocab_size: int, n_languages: Optional[int] = None):
+def synthetic_tokenizer(vocab_size: int, n_languages: Optional[int] = None, timestamps: bool = True):
     """A `tokenizers.Tokenizer` with Whisper's special-token layout for a vocabulary of `vocab_size` ids:
     [0, eot): byte-level pieces (256 byte tokens + filler words), then <|endoftext|>, <|startoftranscript|>,
     99 (100 for large-v3) language tokens — English-only vocabularies carry them too —, <|translate|>, <|transcribe|>,
@@ -214,7 +214,9 @@ def synthetic_tokenizer(vocab_size: int, n_languages: Optional[int] = None):
     specials = ["<|endoftext|>", "<|startoftranscript|>"]
     specials += [f"<|{c}|>" for c in LANGUAGE_CODES[:n_lang]]
     specials += ["<|translate|>", "<|transcribe|>", "<|startoflm|>", "<|startofprev|>", "<|nospeech|>", "<|notimestamps|>"]
-    specials += [f"<|{k * 0.02:.2f}|>" for k in range(1501)]
+    if timestamps:
+        specials += [f"<|{k * 0.02:.2f}|>" for k in range(1501)]
+    # timestamps=False: the tokenizer.json of older converted checkpoints, which ends at <|notimestamps|>
     tok.add_special_tokens(specials)
-    assert tok.get_vocab_size() == vocab_size, (tok.get_vocab_size(), vocab_size)
+    assert tok.get_vocab_size() == vocab_size - (0 if timestamps else 1501), (tok.get_vocab_size(), vocab_size)
     return tok

@@ -202,7 +202,8 @@ class _EngineModel:
                             enc_items=encoder_output.items)
         hf = o.hf_tokenizer
         for r in res:
-            r.sequences = [[hf.id_to_token(t) for t in seq] for seq in r.sequences_ids]
+            tb = o.token_ids.timestamp_begin       # ids past the tokenizer's own table are timestamps (see __init__)
+            r.sequences = [[hf.id_to_token(t) or f"<|{(t - tb) * 0.02:.2f}|>" for t in seq] for seq in r.sequences_ids]
         return res
 
     def align(self, encoder_output: EncoderOutput, start_sequence: Sequence[int], text_tokens: Sequence[Sequence[int]],
@@ -286,11 +287,20 @@ class WhisperModelHIP:
                     self.logger.warning("Could not load preprocessor config: %s", e)
         self.hf_tokenizer = hf_tokenizer
         self._multilingual = self.spec.multilingual if multilingual is None else bool(multilingual)
-        if hf_tokenizer.get_vocab_size() != self.spec.vocab:
-            raise ValueError(f"tokenizer has {hf_tokenizer.get_vocab_size()} ids, the model {self.spec.vocab}")
+        # Older converted checkpoints ship a tokenizer.json WITHOUT the <|0.00|>..<|30.00|> entries (≈50364 ids for a
+        # 51865-row model); faster-whisper derives timestamp ids as no_timestamps + 1 and never looks them up, so the
+        # only hard requirements are: no id beyond the model's vocabulary, and every named special (and the 1501
+        # timestamp ids derived from no_timestamps) inside it.
+        if hf_tokenizer.get_vocab_size() > self.spec.vocab:
+            raise ValueError(f"tokenizer has {hf_tokenizer.get_vocab_size()} ids, the model only {self.spec.vocab}")
         self._base_tokenizer = Tokenizer(hf_tokenizer, False)
         bt = self._base_tokenizer
         self.token_ids = TokenIds(bt.sot, bt.eot, bt.no_timestamps, bt.timestamp_begin, bt.no_speech, bt.blank)
+        specials = dict(sot=bt.sot, eot=bt.eot, no_timestamps=bt.no_timestamps, no_speech=bt.no_speech,
+                        transcribe=bt.transcribe, translate=bt.translate, sot_prev=bt.sot_prev, sot_lm=bt.sot_lm)
+        bad = {k: v for k, v in specials.items() if not 0 <= v < self.spec.vocab}
+        if bad or bt.timestamp_begin + 1500 > self.spec.vocab - 1:
+            raise ValueError(f"tokenizer specials do not fit the model's {self.spec.vocab}-row vocabulary: {bad or 'timestamps'}")
         feat_kwargs.setdefault("feature_size", self.spec.n_mels)
         if feat_kwargs["feature_size"] != self.spec.n_mels:
             raise ValueError("preprocessor feature_size does not match the model's n_mels")

@@ -17,6 +17,9 @@ Two parts:
 from __future__ import annotations
 
 import bisect
+import logging
+import os
+import threading
 from dataclasses import dataclass
 from typing import Callable, Dict, List, Optional, Sequence, Tuple
 
@@ -147,29 +150,64 @@ class SileroHIPModel:
 
 
 _default_model: Optional[Callable[[np.ndarray], np.ndarray]] = None
+_default_lock = threading.Lock()
+
+
+class VadUnavailable(RuntimeError):
+    """use_vad was requested but no Silero weights are configured (and the stand-in was not opted into)."""
 
 
 def set_default_model(model: Optional[Callable[[np.ndarray], np.ndarray]]):
     global _default_model
-    _default_model = model
+    with _default_lock:
+        _default_model = model
+
+
+def configure(weights_path: Optional[str] = None, device: int = 0) -> Callable[[np.ndarray], np.ndarray]:
+    """Install the process-wide VAD model from a weight file: ``.npz`` (names / shapes of SILERO_SHAPES) or the
+    ``silero_vad.onnx`` the reference downloads (whisper_live/vad.py:112-128) — the latter is converted on the fly by
+    ``whisperlive_amd.silero_export`` (stdlib protobuf walk, no onnx / onnxruntime needed) and runs on the GPU."""
+    if weights_path is None:
+        return get_default_model()
+    if weights_path.endswith(".npz"):
+        w = load_silero_npz(weights_path)
+    else:
+        from .silero_export import silero_weights_from_onnx
+        w = check_silero_weights(silero_weights_from_onnx(weights_path))
+    model = SileroHIPModel(w, device)
+    set_default_model(model)
+    logging.info("VAD: Silero weights from %s on GPU %d", weights_path, device)
+    return model
 
 
 def get_default_model() -> Callable[[np.ndarray], np.ndarray]:
+    """WLX_SILERO_VAD_NPZ / WLX_SILERO_VAD_ONNX name the weights (the ONNX file is the one the reference downloads).
+    Without them ``use_vad`` FAILS (VadUnavailable) unless WLX_ALLOW_VAD_STANDIN=1 opts into the labelled energy gate —
+    a default deployment must not silently gate audio with something that is not the reference's detector."""
     global _default_model
-    if _default_model is None:
-        import os
+    with _default_lock:
+        if _default_model is not None:
+            return _default_model
         npz = os.environ.get("WLX_SILERO_VAD_NPZ")
         path = os.environ.get("WLX_SILERO_VAD_ONNX")
+        dev = int(os.environ.get("WLX_VAD_DEVICE", "0"))
         if npz and os.path.isfile(npz):
-            _default_model = SileroHIPModel(load_silero_npz(npz), int(os.environ.get("WLX_VAD_DEVICE", "0")))
+            _default_model = SileroHIPModel(load_silero_npz(npz), dev)
+            logging.info("VAD: Silero (HIP) from %s", npz)
         elif path and os.path.isfile(path):
-            _default_model = SileroOnnxModel(path)
-        else:
-            import logging
-            logging.warning("VAD: no Silero weights configured (WLX_SILERO_VAD_NPZ / WLX_SILERO_VAD_ONNX); using the energy-gate "
-                            "stand-in, which is NOT the reference's speech detector")
+            from .silero_export import silero_weights_from_onnx
+            _default_model = SileroHIPModel(check_silero_weights(silero_weights_from_onnx(path)), dev)
+            logging.info("VAD: Silero (HIP) from %s", path)
+        elif os.environ.get("WLX_ALLOW_VAD_STANDIN") == "1":
+            logging.warning("VAD: WLX_ALLOW_VAD_STANDIN=1 — using the energy-gate stand-in, which is NOT the reference's "
+                            "speech detector (set WLX_SILERO_VAD_ONNX / WLX_SILERO_VAD_NPZ or pass --vad_weights)")
             _default_model = EnergyGateModel()
-    return _default_model
+        else:
+            raise VadUnavailable(
+                "use_vad needs Silero VAD weights: set WLX_SILERO_VAD_ONNX (the silero_vad.onnx the reference downloads) or "
+                "WLX_SILERO_VAD_NPZ, pass --vad_weights to the server, or opt into the energy-gate stand-in with "
+                "WLX_ALLOW_VAD_STANDIN=1")
+        return _default_model
 
 
 def speech_segments_from_probs(probs: Sequence[float], n_samples: int, opt: VadOptions, sampling_rate: int = 16000
