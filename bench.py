@@ -74,7 +74,9 @@ def pmc_traffic(kernel_name: str):
 def cpu_baseline(spec, weights, pcm, ids, decode_steps: int, full_steps: int, threads: int):
     """The CPU oracle (numpy log-mel + torch-fp32 network + numpy beam search) on a BOUNDED sample of the same
     workload: the whole front-end and encoder of one 30 s window, but only `decode_steps` of the `full_steps`
-    beam-5 decode steps; the decode time is scaled to `full_steps` (per-step cost is flat in t at this length)."""
+    beam-5 decode steps; the decode time is scaled to `full_steps` (per-step cost is flat in t at this length).
+    Evaluated on the engine's fp16-rounded weights, so its tokens are also the parity reference of the timed path
+    (`parity_prefix`). Returns (baseline dict, generated tokens of the bounded decode)."""
     import torch
 
     from oracle import decoding as odec
@@ -99,8 +101,66 @@ def cpu_baseline(spec, weights, pcm, ids, decode_steps: int, full_steps: int, th
     return dict(value=WINDOW_S / est, unit="xRT (audio s / wall s)", cores=threads, kind="port",
                 sample=f"one 30 s window: numpy log-mel {t1 - t0:.2f} s + torch-fp32 encoder {t2 - t1:.2f} s measured in full; "
                        f"beam-5 decode measured for {res.steps} steps ({per_step * 1e3:.0f} ms/step) and scaled to {full_steps} steps; "
-                       f"{t3 - t0:.1f} s of CPU work on {threads} threads. CTranslate2-int8 (the reference's CPU backend) "
-                       f"cannot be installed offline, so this is the repo's own fp32 port")
+                       f"{t3 - t0:.1f} s of CPU work on {threads} thread{'s' if threads != 1 else ''}. CTranslate2-int8 (the reference's "
+                       f"CPU backend) cannot be installed offline, so this is the repo's own fp32 port"), res.sequences_ids[0]
+
+
+def f16_rounded(weights):
+    """the engine stores projection matrices in fp16: the CPU leg evaluates the same rounded values"""
+    return {k: (v.astype(np.float16).astype(np.float32) if v.ndim >= 2 and "embed_positions" not in k else v)
+            for k, v in weights.items()}
+
+
+def measured_traffic(kernel_name: str, model: str, timeout_s: int = 240):
+    """HBM bytes per launch of `kernel_name`, measured BY THIS RUN: a child process of this script (a few decode steps of
+    the same workload) under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` — counters in their own pass, as the MI355X guide
+    prescribes — and its counter_collection.csv reduced here. FETCH_SIZE is in KiB and on gfx950 counts half the bytes
+    of wide coalesced reads: x 1024 x 2. (None, reason) when rocprofv3 is missing or the pass fails."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return None, "rocprofv3 not found"
+    d = tempfile.mkdtemp(prefix="wlx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [rp, "--pmc", "FETCH_SIZE", "--kernel-trace", "-d", d, "-o", "wlx", "--output-format", "csv", "--",
+           sys.executable, os.path.abspath(__file__), "--pmc-child", "--model", model]
+    try:
+        proc = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+        tot = n = 0.0
+        for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+            with open(f, newline="") as fh:
+                for r in csv.DictReader(fh):
+                    if r["Counter_Name"] == "FETCH_SIZE" and kernel_name in r["Kernel_Name"]:
+                        tot += float(r["Counter_Value"])
+                        n += 1
+        if not n:
+            return None, f"no FETCH_SIZE rows for {kernel_name} (rocprofv3 rc {proc.returncode}: {proc.stderr[-200:]})"
+        return tot / n * 1024.0 * 2.0, f"rocprofv3 --pmc FETCH_SIZE pass of this run ({int(n)} launches)"
+    except Exception as e:  # noqa: BLE001 — the headline line must survive a failed counter pass
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def respawn_ranks(n: int, argv) -> int:
+    """`python bench.py --gpus N` started by hand (no RANK/WORLD_SIZE in the environment): launch the N ranks ourselves,
+    exactly the way the driver does — one process per GPU under torch.distributed.run, rendezvous on 127.0.0.1."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def stream_through_server(make_transcriber, seconds: float = 40.0, paced_seconds: float = 4.0, settle_s: float = 3.0,
@@ -182,13 +242,10 @@ def stream_through_server(make_transcriber, seconds: float = 40.0, paced_seconds
     return out
 
 
-def stream_leg(eng, spec, ids, decode_steps, pcm_fn, clients=1, batch=False, model_name="small.en"):
-    """The product transcriber on the already-built engine, decode length pinned like the window benchmark: EOT suppressed,
-    max_length = prompt + decode_steps, quality fallbacks off (they never trigger on real speech; random weights would
-    trigger all five re-decodes). VAD: the Silero network on the GPU with seeded weights and a +6 output bias, so the gate
-    passes the audio while costing what the real network costs."""
-    from oracle import silero_vad as sv          # seeded weight generator only; the network runs in libwlx.so
-    from whisperlive_amd import vad
+def make_bench_transcriber(eng, spec, ids, decode_steps, vad_model=None, max_batch=1):
+    """The product transcriber on an already-built engine with the decode length pinned like the window benchmark: EOT
+    suppressed, max_length = prompt + decode_steps, quality fallbacks off (they never trigger on real speech; random
+    weights would trigger all five re-decodes)."""
     from whisperlive_amd.tokenizer import synthetic_tokenizer
     from whisperlive_amd.transcriber import WhisperModelHIP, _EngineModel
 
@@ -206,15 +263,24 @@ def stream_leg(eng, spec, ids, decode_steps, pcm_fn, clients=1, batch=False, mod
                 info.language_probability = max(info.language_probability, 0.99)
             return segs, info
 
+    tr = BenchTranscriber("bench", engine=eng, hf_tokenizer=synthetic_tokenizer(spec.vocab), vad_model=vad_model, max_batch=max_batch)
+    tr.model = FixedLengthModel(tr)
+    return tr
+
+
+def stream_leg(eng, spec, ids, decode_steps, pcm_fn, clients=1, batch=False, model_name="small.en"):
+    """configs[1] / configs[2] through the server shell on the already-built engine (make_bench_transcriber). VAD: the
+    Silero network on the GPU with seeded weights and a +6 output bias, so the gate passes the audio while costing what
+    the real network costs."""
+    from oracle import silero_vad as sv          # seeded weight generator only; the network runs in libwlx.so
+    from whisperlive_amd import vad
+
     w = sv.random_weights(3)
     w["out_b"] = np.asarray([6.0], np.float32)
     vm = vad.SileroHIPModel(w, device=eng.device)
 
     def make():
-        tr = BenchTranscriber("bench", engine=eng, hf_tokenizer=synthetic_tokenizer(spec.vocab), vad_model=vm,
-                              max_batch=max(1, clients if batch else 1))
-        tr.model = FixedLengthModel(tr)
-        return tr
+        return make_bench_transcriber(eng, spec, ids, decode_steps, vad_model=vm, max_batch=max(1, clients if batch else 1))
     english_only = model_name.endswith("en")
     from whisperlive_amd.batching import BatchInferenceWorker
     saved_t = BatchInferenceWorker.TEMPERATURES
@@ -230,6 +296,96 @@ def stream_leg(eng, spec, ids, decode_steps, pcm_fn, clients=1, batch=False, mod
                      f"VAD on (Silero on GPU), beam 5, {decode_steps} tokens per window"
                      + ("" if english_only else ", language detected on the first chunk"))
     return res
+
+
+def config5(args, rank, world, local, dist, torch):
+    """BASELINE configs[4] ("config 5"): batch_inference.py's batched mode — `--clips` pre-recorded 30 s clips,
+    Whisper-large-v3 shapes, sharded in contiguous blocks over the ranks (whisperlive_amd/sharding.py); every rank drives
+    its block through its own BatchInferenceWorker(max_batch_size=8) exactly as the reference's server would for N
+    clients (whisper_live/server.py:665-673, batch_inference.py:155-438: per-item log-mel, ONE batched encode, ONE
+    batched beam-5 decode per batch), then ONE fixed-size all_gather of 2 KiB result records over RCCL. A "step" = one
+    pass over all clips; value = clips x 30 s x steps / max-over-ranks wall."""
+    from oracle import logmel as olm   # synthetic-input generator only
+    from whisperlive_amd import sharding as sh
+    from whisperlive_amd.batching import BatchInferenceWorker, BatchRequest
+    from whisperlive_amd.engine import HipWhisperEngine
+    from whisperlive_amd.specs import get_spec
+    from whisperlive_amd.weights import random_weights
+
+    spec = get_spec(args.model)
+    eng = HipWhisperEngine(spec, random_weights(spec, seed=0), device=local)
+    ids = token_ids(spec.vocab)
+    MB = 8
+    tr = make_bench_transcriber(eng, spec, ids, args.decode_steps, vad_model=None, max_batch=MB)
+    BatchInferenceWorker.TEMPERATURES = (0.0,)
+    worker = BatchInferenceWorker(tr, max_batch_size=MB, batch_window_ms=50)
+    worker.start()
+    n = args.clips
+    lo, hi = sh.shard_range(n, rank, world)
+    clips = [olm.speech_like_pcm(WINDOW_S, seed=2000 + i) if lo <= i < hi else None for i in range(n)]
+    lang = "en"
+    process = sh.worker_block_processor(worker, lambda c: BatchRequest(audio=c, language=lang, use_vad=False))
+    device = f"cuda:{local}"
+
+    def step():
+        t0 = time.perf_counter()
+        res = sh.transcribe_clips_sharded(clips, process, rank=rank, world=world, dist=dist, device=device)
+        return time.perf_counter() - t0, res
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    lat, res = [], None
+    for _ in range(args.steps):
+        dt, res = step()
+        lat.append(dt)
+    barrier()
+    wall = time.perf_counter() - t0
+    if dist is not None:
+        tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+        wall = float(tw.item())
+    out = None
+    if rank == 0:
+        n_tok = [len(r[0]) for r in res]
+        slot = tr._slots[0] if tr._slots else None
+        rows = MB * 5
+        step_ms = slot.debug_time_decode_step(rows=rows, t=1 + args.decode_steps // 2, iters=20) if slot is not None else None
+        sb = decode_step_bytes(spec, rows, 1 + args.decode_steps // 2) + 2 * spec.dec_layers * 2 * spec.n_audio_ctx * spec.d_model * (MB - 1)
+        out = {
+            "metric": "real-time factor (xRT), batched mode: pre-recorded 30 s clips through batch_inference's worker",
+            "value": n * WINDOW_S * args.steps / wall, "unit": "xRT (audio s / wall s)", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1000.0 * wall / args.steps, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "f16 (MFMA operands; f32 accumulate, f32 residual stream, f32 log-mel)", "data": "synthetic",
+            "config": {"workload": f"configs[4]: batch_inference.py batched mode, Whisper-{args.model} shapes, {n} clips x 30 s "
+                                   f"(seeds 2000..{2000 + n - 1}), contiguous blocks over {world} GPU(s), per-GPU "
+                                   f"BatchInferenceWorker(max_batch_size={MB}) -> per-item log-mel + one batched encode + one batched "
+                                   f"beam-5 decode of {args.decode_steps} tokens per batch -> one all_gather of 2 KiB records; "
+                                   f"seeded random weights",
+                       "clips": n, "clips_per_gpu": hi - lo, "max_batch_size": MB, "beam_size": 5, "decode_steps": args.decode_steps,
+                       "window_s": WINDOW_S},
+            "tokens_per_clip": {"min": min(n_tok), "max": max(n_tok)},
+            "p50_step_ms": 1000.0 * float(np.median(lat)),
+        }
+        if step_ms is not None:
+            out["decode_step"] = {"rows": rows, "graph_replay_ms": step_ms, "algorithmic_bytes": sb,
+                                  "hbm_frac_of_peak": sb / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            out["roofline"] = dict(bound="hbm", kernel="decode step (all launches, 40 rows)", achieved=sb / (step_ms * 1e-3) / 1e9,
+                                   peak=HBM_PEAK_GBS, unit="GB/s", frac=sb / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None)
+    worker.stop()
+    tr.close()
+    eng.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
 
 
 def main():
@@ -250,15 +406,32 @@ def main():
     ap.add_argument("--streams", type=int, default=1,
                     help="concurrent streams on this GPU (BASELINE configs[2] = 4): one engine, one slot + HIP stream + "
                          "host thread per stream, the same step each; value = aggregate over streams")
+    ap.add_argument("--config", type=int, default=1, choices=[1, 5],
+                    help="BASELINE.json configs index: 1 = the headline single-stream window benchmark (default; with "
+                         "--model/--streams/--batch also configs 2-4), 5 = batch_inference.py's batched mode: 64 pre-recorded "
+                         "30 s clips, Whisper-large-v3 shapes, one BatchInferenceWorker(max_batch_size=8) per GPU, clips "
+                         "sharded in contiguous blocks, ONE all_gather of 2 KiB result records over RCCL")
+    ap.add_argument("--clips", type=int, default=64, help="--config 5: number of 30 s clips per step")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 FETCH_SIZE pass that fills roofline.traffic")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started by hand: launch the ranks ourselves (the driver does the same thing around this script)
+        raise SystemExit(respawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch as `python bench.py --gpus N` or under "
+                         f"torch.distributed.run with --nproc-per-node equal to --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"rank {rank} needs GPU {local} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local)
     dist = None
     if world > 1:
@@ -272,9 +445,25 @@ def main():
     from whisperlive_amd.specs import get_spec
     from whisperlive_amd.weights import random_weights
 
+    if args.config == 5:
+        if args.model == "small.en":
+            args.model = "large-v3"
+        return config5(args, rank, world, local, dist, torch)
     spec = get_spec(args.model)
     weights = random_weights(spec, seed=0)
     eng = HipWhisperEngine(spec, weights, device=local)
+    if args.pmc_child:
+        # the counter pass of measured_traffic(): a few decode steps of the same workload, nothing else
+        sl = eng.create_slot(1, 5)
+        ids_ = token_ids(spec.vocab)
+        sl.pcm_put(olm.speech_like_pcm(WINDOW_S, seed=1234), 0)
+        T = sl.logmel_resident(0)
+        sl.encode(1, seek=[0], seg=[min(T - 1, 3000)])
+        sl.generate([[ids_["sot"]]], TokenIds(**ids_), beam_size=5, patience=1.0, max_length=1 + 12,
+                    suppress_tokens=suppress_list(ids_, True))
+        sl.close()
+        eng.close()
+        return
     S = max(1, args.streams)
     B = max(1, args.batch)
     slots = [eng.create_slot(B, 5) for _ in range(S)]
@@ -351,7 +540,13 @@ def main():
                     launches_per_decode_step=dom["launches"], avg_us=dom["avg_us"],
                     algorithmic_bytes_per_launch=dom["bytes_per_launch"])
         roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["traffic"], roof["traffic_source"] = pmc_traffic(dom["name"])
+        if world == 1 and not args.no_pmc:
+            roof["traffic"], roof["traffic_source"] = measured_traffic(dom["name"], args.model)
+        if roof["traffic"] is None:
+            why = roof.get("traffic_source")
+            roof["traffic"], roof["traffic_source"] = pmc_traffic(dom["name"])
+            if roof["traffic"] is not None:
+                roof["traffic_source"] = f"committed pass {roof['traffic_source']} (live pass unavailable: {why})"
         # the one launch of the step that is bandwidth- rather than latency-sized: the vocabulary projection (80 MB)
         big = max(prof, key=lambda k: k["bytes_per_launch"])
         roof["largest_launch"] = dict(kernel=big["name"], algorithmic_bytes=big["bytes_per_launch"], avg_us=big["avg_us"],
@@ -383,8 +578,27 @@ def main():
             except Exception as e:  # noqa: BLE001 — the headline line must survive a failure of this leg
                 out["stream"] = {"error": f"{type(e).__name__}: {e}"}
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(spec, weights, pcm, ids, args.cpu_decode_steps, n_tok,
-                                               threads=min(16, os.cpu_count() or 1))
+            # self-check first: the SAME bounded decode on the GPU (untimed), then on the CPU port; the common prefix of
+            # the two token sequences travels with the line
+            kw32 = dict(gen_kw, max_length=1 + args.cpu_decode_steps)
+            T0 = slot.logmel_resident(0)
+            slot.encode(B, seek=[0] * B, seg=[min(T0 - 1, 3000)] * B)
+            gpu_toks = slot.generate([[ids["sot"]]] * B, eids, **kw32)[0].sequences_ids[0]
+            w16 = f16_rounded(weights)
+            nproc = os.cpu_count() or 1
+            base, cpu_toks = cpu_baseline(spec, w16, pcm, ids, args.cpu_decode_steps, n_tok, threads=nproc)
+            one, _ = cpu_baseline(spec, w16, pcm, ids, max(4, args.cpu_decode_steps // 4), n_tok, threads=1)
+            base["single_thread"] = {k: one[k] for k in ("value", "unit", "cores", "sample")}
+            base["single_thread"]["note"] = "OMP_NUM_THREADS=1 is the reference server's default (run_server.py:36-39,118-119)"
+            out["cpu_baseline"] = base
+            n = 0
+            while n < min(len(gpu_toks), len(cpu_toks)) and gpu_toks[n] == cpu_toks[n]:
+                n += 1
+            out["parity_prefix"] = n
+            out["parity"] = dict(compared_tokens=min(len(gpu_toks), len(cpu_toks)), common_prefix=n,
+                                 note="beam-5 decode of the benchmarked window, GPU (fp16 MFMA) vs CPU port (fp32) on the same "
+                                      "fp16-rounded seeded weights; random weights give flat distributions, so the first "
+                                      "fp16-vs-fp32 near-tie ends the common prefix")
     for sl in slots:
         sl.close()
     eng.close()

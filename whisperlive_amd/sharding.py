@@ -79,3 +79,29 @@ def transcribe_clips_sharded(clips: Sequence[np.ndarray], process_block: Callabl
         raise RuntimeError("process_block must return one record per clip")
     gathered = all_gather_records(local, len(clips), rank, world, dist, device)
     return [unpack_record(r) for r in gathered]
+
+
+def worker_block_processor(worker, make_request: Callable[[np.ndarray], "object"], timeout_s: float = 600.0
+                           ) -> Callable[[Sequence[np.ndarray]], List[np.ndarray]]:
+    """`process_block` for transcribe_clips_sharded on top of a rank's BatchInferenceWorker — what the reference's
+    server does with N pre-recorded clips in batched mode (whisper_live/server.py:665-673 starts the worker,
+    whisper_live/batch_inference.py:155-187 collects up to max_batch_size requests per batch): EVERY clip of the block is
+    submitted before the first result is awaited, so the worker forms full batches; each result becomes one 2 KiB record
+    (all generated tokens of the clip, avg_logprob in both score fields, no_speech_prob)."""
+    def process(clips: Sequence[np.ndarray]) -> List[np.ndarray]:
+        reqs = [make_request(c) for c in clips]
+        for r in reqs:
+            worker.submit(r)
+        recs = []
+        for i, r in enumerate(reqs):
+            if not r.future.wait(timeout_s):
+                raise TimeoutError(f"clip {i} of the block was not transcribed within {timeout_s} s")
+            if r.error is not None:
+                raise r.error
+            segs = list(r.result or [])
+            toks = [int(t) for sg in segs for t in sg.tokens]
+            alp = float(segs[0].avg_logprob) if segs else 0.0
+            nsp = float(segs[0].no_speech_prob) if segs else 1.0
+            recs.append(pack_record(toks, alp, nsp, alp))
+        return recs
+    return process
