@@ -105,6 +105,29 @@ def cpu_baseline(spec, weights, pcm, ids, decode_steps: int, full_steps: int, th
                        f"CPU backend) cannot be installed offline, so this is the repo's own fp32 port"), res.sequences_ids[0]
 
 
+def usable_cpus(cap: int = 16) -> int:
+    """Host threads this process may really use: the affinity mask and the cgroup CPU quota, not os.cpu_count() (a
+    container on a 256-thread host reports 256 and is scheduled on far fewer — torch with 256 threads then crawls)."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            quota, period = f.read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, cap))
+
+
+def note(msg: str):
+    """progress on stderr (the JSON line owns stdout)"""
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def f16_rounded(weights):
     """the engine stores projection matrices in fp16: the CPU leg evaluates the same rounded values"""
     return {k: (v.astype(np.float16).astype(np.float32) if v.ndim >= 2 and "embed_positions" not in k else v)
@@ -356,7 +379,12 @@ def config5(args, rank, world, local, dist, torch):
         n_tok = [len(r[0]) for r in res]
         slot = tr._slots[0] if tr._slots else None
         rows = MB * 5
-        step_ms = slot.debug_time_decode_step(rows=rows, t=1 + args.decode_steps // 2, iters=20) if slot is not None else None
+        step_ms = None
+        try:
+            if slot is not None:
+                step_ms = slot.debug_time_decode_step(rows=rows, t=1 + args.decode_steps // 2, iters=20)
+        except Exception as e:  # noqa: BLE001 — the step probe is an extra; the measured line must survive it
+            note(f"decode-step probe at {rows} rows unavailable: {e}")
         sb = decode_step_bytes(spec, rows, 1 + args.decode_steps // 2) + 2 * spec.dec_layers * 2 * spec.n_audio_ctx * spec.d_model * (MB - 1)
         out = {
             "metric": "real-time factor (xRT), batched mode: pre-recorded 30 s clips through batch_inference's worker",
@@ -506,6 +534,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    note("timed region")
     barrier()
     t0 = time.perf_counter()
     lat = []
@@ -541,7 +570,9 @@ def main():
                     algorithmic_bytes_per_launch=dom["bytes_per_launch"])
         roof["frac"] = roof["achieved"] / roof["peak"]
         if world == 1 and not args.no_pmc:
+            note("rocprofv3 FETCH_SIZE pass")
             roof["traffic"], roof["traffic_source"] = measured_traffic(dom["name"], args.model)
+            note(f"traffic: {roof['traffic']} ({roof['traffic_source']})")
         if roof["traffic"] is None:
             why = roof.get("traffic_source")
             roof["traffic"], roof["traffic_source"] = pmc_traffic(dom["name"])
@@ -572,6 +603,7 @@ def main():
             "roofline": roof,
         }
         if world == 1 and S == 1 and B == 1 and not args.no_stream:
+            note("stream leg")
             try:
                 out["stream"] = stream_leg(eng, spec, ids, args.decode_steps, olm.speech_like_pcm, clients=max(1, args.stream_clients),
                                            batch=args.stream_batch, model_name=args.model)
@@ -585,8 +617,10 @@ def main():
             slot.encode(B, seek=[0] * B, seg=[min(T0 - 1, 3000)] * B)
             gpu_toks = slot.generate([[ids["sot"]]] * B, eids, **kw32)[0].sequences_ids[0]
             w16 = f16_rounded(weights)
-            nproc = os.cpu_count() or 1
+            nproc = usable_cpus()
+            note(f"cpu baseline on {nproc} threads")
             base, cpu_toks = cpu_baseline(spec, w16, pcm, ids, args.cpu_decode_steps, n_tok, threads=nproc)
+            note("cpu baseline on 1 thread")
             one, _ = cpu_baseline(spec, w16, pcm, ids, max(4, args.cpu_decode_steps // 4), n_tok, threads=1)
             base["single_thread"] = {k: one[k] for k in ("value", "unit", "cores", "sample")}
             base["single_thread"]["note"] = "OMP_NUM_THREADS=1 is the reference server's default (run_server.py:36-39,118-119)"

@@ -81,6 +81,22 @@ def build_trace() -> Path:
     return out
 
 
+def build_variant(name: str, defines) -> Path:
+    """A/B builds of the same sources with extra -D flags (e.g. libwlx_wfirst.so: -DWLX_X_FIRST=0, the decode GEMVs with
+    their weight stream requested BEFORE the activations, the round-1 order); selected at run time with WLX_LIB=<path>."""
+    out = PKG_DIR / name
+    srcs = [CSRC / s for s in SOURCES]
+    deps = srcs + list(CSRC.glob("*.h"))
+    if out.exists() and all(out.stat().st_mtime >= d.stat().st_mtime for d in deps):
+        return out
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + [f"-D{d}" for d in defines] + ["-o", str(out)] + [str(s) for s in srcs]
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise WlxError(f"hipcc failed ({proc.returncode}):\n{proc.stderr[-4000:]}")
+    return out
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile every HIP source for gfx950 into whisperlive_amd/libwlx.so (hipcc cross-compiles without a GPU)."""
     srcs = [CSRC / s for s in SOURCES]

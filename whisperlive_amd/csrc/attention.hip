@@ -138,13 +138,171 @@ __global__ __launch_bounds__(64) void attn_encoder_kernel(const half_t* __restri
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Second form (round 2): the same arithmetic in the same order — results are bit-identical to attn_encoder_kernel —
+// with the two things the ISA of the first form showed it was waiting on removed:
+//  * hipcc collapsed the one-tile "prefetch" above (the kn/vn -> kf/vf copies were coalesced, so the loads of tile i+1
+//    land in the registers the MFMAs of tile i+1 read and every tile still waits a full L2 round trip, then drains
+//    vmcnt(0) at the loop end): here three NAMED tile register sets rotate through a loop unrolled by three, two tiles
+//    are always in flight behind the one being multiplied, and nothing is copied;
+//  * the softmax row maximum crossed the four 16-lane rows of a wave with two ds_bpermute round trips per query tile
+//    (~250 cycles of LDS latency on the wave's critical path, 94 times per launch): v_permlane16_swap / v_permlane32_swap
+//    exchange rows inside the VALU.
+__device__ __forceinline__ float rows4_max(float v) {
+    // rows (16-lane groups) r0..r3 of a wave: after the first swap a = {r0,r0,r2,r2}, b = {r1,r1,r3,r3}; after the second
+    // a = {lo,lo}, b = {hi,hi}. Written as asm with BOTH operands read-write: the builtin with two identical operands is
+    // folded by hipcc (ROCm 7.2) as if it returned its input twice, which silently drops the max.
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a = fmaxf(a, b);
+    b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+
+struct AttnTile { f16x8 k[2][2]; f16x8 v[4]; };
+
+template <int QT>
+__global__ __launch_bounds__(64) void attn_encoder_pf_kernel(const half_t* __restrict__ Q, long ldq,
+                                                             const half_t* __restrict__ K, long ldk,
+                                                             const half_t* __restrict__ Vt, long ldvt,
+                                                             half_t* __restrict__ O, long ldo, int T,
+                                                             long isq, long isk, long isv, long iso) {
+    const int lane = threadIdx.x;
+    const int c = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, item = blockIdx.z;
+    const int q0 = blockIdx.x * (QT * 16);
+    Q += (long)item * isq + h * WLX_HEAD_DIM;
+    K += (long)item * isk + h * WLX_HEAD_DIM;
+    Vt += (long)item * isv + (long)h * WLX_HEAD_DIM * ldvt;
+    O += (long)item * iso + h * WLX_HEAD_DIM;
+
+    f16x8 qf[QT][2];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        int row = q0 + qt * 16 + c;
+        if (row >= T) row = T - 1;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) qf[qt][kt] = ld_f16x8(Q + (long)row * ldq + kt * 32 + g * 8);
+    }
+    f32x4 acc[QT][4];
+    float mrun[QT], lrun[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        mrun[qt] = WLX_NEG_INF;
+        lrun[qt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const half_t* kbase = K + (long)c * ldk + g * 8;
+    const half_t* vbase = Vt + (long)c * ldvt + g * 4;
+    const int NT = (T + 31) >> 5;
+    auto load_tile = [&](int ti, AttnTile& t) {
+        const int key0 = ((ti < NT) ? ti : NT - 1) << 5;              // past the end: re-read the last tile (never multiplied)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) t.k[s][kt] = ld_f16x8(kbase + (long)(key0 + s * 16) * ldk + kt * 32);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const half_t* vp = vbase + (long)dt * 16 * ldvt + key0;
+            const f16x4 lo = ld_f16x4(vp), hi = ld_f16x4(vp + 16);
+            t.v[dt] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        }
+    };
+    auto multiply = [&](int ti, const AttnTile& t) {
+        const int key0 = ti << 5;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            f32x4 st[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                st[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) st[s] = mfma16(t.k[s][kt], qf[qt][kt], st[s]);
+            }
+            float p[8];
+            float tmax = WLX_NEG_INF;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = key0 + s * 16 + g * 4 + r;
+                    const float v = (key < T) ? st[s][r] : WLX_NEG_INF;
+                    p[s * 4 + r] = v;
+                    tmax = fmaxf(tmax, v);
+                }
+            tmax = rows4_max(tmax);
+            const float mnew = fmaxf(mrun[qt], tmax);
+            const float alpha = __expf(mrun[qt] - mnew);
+            float psum = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { p[i] = __expf(p[i] - mnew); psum += p[i]; }
+            lrun[qt] = lrun[qt] * alpha + psum;
+            mrun[qt] = mnew;
+            const f16x8 pf = {(half_t)p[0], (half_t)p[1], (half_t)p[2], (half_t)p[3],
+                              (half_t)p[4], (half_t)p[5], (half_t)p[6], (half_t)p[7]};
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                f32x4 a = acc[qt][dt];
+                a[0] *= alpha; a[1] *= alpha; a[2] *= alpha; a[3] *= alpha;
+                acc[qt][dt] = mfma16(t.v[dt], pf, a);
+            }
+        }
+    };
+    // A tile is 12 vector-memory loads (4 x 16 B of K, 8 x 8 B of V^T); two tiles are kept in flight behind the one being
+    // multiplied. hipcc's own wait insertion is conservative at a loop header — whatever was requested before the
+    // back-edge is waited for in full at its first use after it (a three-tile loop body drained the tile requested one
+    // multiply earlier on every trip) — so (1) the body covers SIX tiles and crosses the back-edge with only the oldest
+    // request outstanding, (2) every multiply is preceded by an explicit counted wait (__builtin_amdgcn_s_waitcnt, which
+    // the compiler's bookkeeping understands) and a scheduling barrier that keeps the MFMAs below it. Tiles past the end
+    // (the body runs ceil(47 / 6) * 6 = 48 tiles) re-read the last tile with every key masked: p = exp(-inf) = 0,
+    // alpha = 1, so they change nothing, bit for bit.
+#define WLX_WAIT_VM(n) do { __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | 0x0F70); __builtin_amdgcn_sched_barrier(0); } while (0)
+    AttnTile tA, tB, tC;
+    load_tile(0, tA);
+#pragma unroll 1
+    for (int ti = 0; ti < NT; ti += 6) {
+        load_tile(ti + 1, tB);
+        load_tile(ti + 2, tC);
+        WLX_WAIT_VM(24); multiply(ti, tA);     load_tile(ti + 3, tA);
+        WLX_WAIT_VM(24); multiply(ti + 1, tB); load_tile(ti + 4, tB);
+        WLX_WAIT_VM(24); multiply(ti + 2, tC); load_tile(ti + 5, tC);
+        WLX_WAIT_VM(24); multiply(ti + 3, tA); load_tile(ti + 6, tA);
+        WLX_WAIT_VM(24); multiply(ti + 4, tB);
+        WLX_WAIT_VM(12); multiply(ti + 5, tC);
+    }
+#undef WLX_WAIT_VM
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float l = lrun[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = 1.0f / l;
+        const int row = q0 + qt * 16 + c;
+        if (row < T) {
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) {
+                const f16x4 o = {(half_t)(acc[qt][dt][0] * inv), (half_t)(acc[qt][dt][1] * inv),
+                                 (half_t)(acc[qt][dt][2] * inv), (half_t)(acc[qt][dt][3] * inv)};
+                *reinterpret_cast<f16x4*>(O + (long)row * ldo + dt * 16 + g * 4) = o;
+            }
+        }
+    }
+}
+
 void launch_attn_encoder(const half_t* Q, long ldq, const half_t* K, long ldk, const half_t* Vt, long ldvt,
                          half_t* O, long ldo, int T, int H, int items,
                          long isq, long isk, long isv, long iso, hipStream_t s) {
     constexpr int QT = 2;   // measured on Whisper-small: QT = 1 fills every SIMD but doubles the K/V re-reads from L2: 2.64 vs 2.35 ms per encoder
     dim3 grid((T + QT * 16 - 1) / (QT * 16), H, items);
-    hipLaunchKernelGGL((attn_encoder_kernel<QT>), grid, dim3(64), 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, T,
-                       isq, isk, isv, iso);
+    static const int form = [] { const char* e = getenv("WLX_ENC_ATTN"); return e ? atoi(e) : 2; }();   // 1 = first form (A/B)
+    if (form == 1)
+        hipLaunchKernelGGL((attn_encoder_kernel<QT>), grid, dim3(64), 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, T,
+                           isq, isk, isv, iso);
+    else
+        hipLaunchKernelGGL((attn_encoder_pf_kernel<QT>), grid, dim3(64), 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, T,
+                           isq, isk, isv, iso);
 }
 
 }  // namespace wlx

@@ -390,10 +390,25 @@ __device__ __forceinline__ float wave_sum_dpp(float v) { return dpp_wave_sum(v);
 
 // copy M rows x K fp16 (16-byte units) global -> LDS rows of stride ldxs, two units per thread in flight per trip (a rolled
 // load->store loop pays one full L2 round trip per unit; M = 5 needs one trip for K = 768 / 256 threads and K = 3072 / 1024)
-__device__ __forceinline__ void stage_rows_f16(const half_t* __restrict__ X, long ldx, int M, int K, half_t* xs, int ldxs) {
+// `after_first_loads` runs once, between the first trip's global loads and its LDS stores (every thread runs it, also
+// threads without a unit): the caller requests its weight stream there, behind the activation loads.
+template <class F>
+__device__ __forceinline__ void stage_rows_f16(const half_t* __restrict__ X, long ldx, int M, int K, half_t* xs, int ldxs,
+                                               F&& after_first_loads) {
     const int kv8 = K >> 3, total = M * kv8, nthr = blockDim.x;
+    {   // first trip, peeled: clamped units so every thread issues (and the hook sits at one program point)
+        const int u0 = (threadIdx.x < total) ? (int)threadIdx.x : total - 1;
+        const int u1 = (u0 + nthr < total) ? u0 + nthr : u0;
+        const int m0 = u0 / kv8, k0 = u0 - m0 * kv8;
+        const int m1 = u1 / kv8, k1 = u1 - m1 * kv8;
+        const f16x8 v0 = ld_f16x8(X + (long)m0 * ldx + k0 * 8);
+        const f16x8 v1 = ld_f16x8(X + (long)m1 * ldx + k1 * 8);
+        after_first_loads();
+        *reinterpret_cast<f16x8*>(xs + m0 * ldxs + k0 * 8) = v0;      // clamped duplicates rewrite a unit with its own value
+        *reinterpret_cast<f16x8*>(xs + m1 * ldxs + k1 * 8) = v1;
+    }
 #pragma unroll 1
-    for (int u0 = threadIdx.x; u0 < total; u0 += 2 * nthr) {
+    for (int u0 = threadIdx.x + 2 * nthr; u0 < total; u0 += 2 * nthr) {
         const int u1 = u0 + nthr;
         const int m0 = u0 / kv8, k0 = u0 - m0 * kv8;
         const int uc = (u1 < total) ? u1 : u0;
@@ -431,12 +446,29 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
     const half_t* wp = p.Wp + ((long)(tile * NTB) * p.KT + kw0) * 512 + lane * 8;
     const long wstep = (long)p.KT * 512;                                   // next n-tile
     f16x8 wf[CH][NTB];
-    if (IN != GEMV_IN_XATTN || wave < nw) {   // helper waves of the combine: wf stays unset, they leave before the MFMAs
+    // The weight stream is requested AFTER the activation loads have been issued (round 2; -DWLX_X_FIRST=0 restores the
+    // first order for A/B): vmcnt retires in order, so with the weights first the wave's wait for its few activation
+    // loads (L2) was a wait for its whole weight slice (HBM) as well, and the LayerNorm / staging / combine that must
+    // precede the MFMAs started only once the weights had landed (decode-step trace: "LN done" 1.4 us into a 2.2 us
+    // launch). With the activations first their wait is vmcnt(#weight loads): the prologue runs under the weight stream.
+    auto load_weights = [&]() {
+        // compile-time fence: hipcc otherwise hoists these address-independent loads back above the activation loads
+        asm volatile("" ::: "memory");
+        // helper waves of the combine (wave >= nw, they leave before the MFMAs) issue the same NUMBER of loads, all of one
+        // already-requested KiB: a branch around the loads would make hipcc count the waits that follow for the path
+        // WITHOUT weights in flight, i.e. drain the weight stream inside the combine on the waves that do have it
+        const bool streams = (IN != GEMV_IN_XATTN) || wave < nw;
+        const half_t* wq = streams ? wp : p.Wp + lane * 8;
+        const long js = streams ? 512 : 0, is = streams ? wstep : 0;
 #pragma unroll
         for (int j = 0; j < CH; ++j)
 #pragma unroll
-            for (int i = 0; i < NTB; ++i) wf[j][i] = ld_nt_f16x8(wp + i * wstep + j * 512);
-    }
+            for (int i = 0; i < NTB; ++i) wf[j][i] = ld_nt_f16x8(wq + i * is + j * js);
+    };
+#ifndef WLX_X_FIRST
+#define WLX_X_FIRST 1
+#endif
+    if (!WLX_X_FIRST) load_weights();
 
     // epilogue operands of the FIRST pair this wave finishes (pair = wave: n-tile pair / MT, row tile pair % MT),
     // requested now (every lane, clamped row: no branch around a load); further pairs (batched rows) load theirs late
@@ -469,7 +501,7 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
             // loads per wave of 64-byte pieces (16 waves x 6 = 96 load instructions per workgroup for K = 3072, as many
             // as the weights; a CU retires one per ~11 ns), the cooperative copy M * K / 8 / 64 = 30.
             const int ldxs = p.K + 8;
-            stage_rows_f16(p.Xh, p.ldxh, p.M, p.K, xs, ldxs);
+            stage_rows_f16(p.Xh, p.ldxh, p.M, p.K, xs, ldxs, [&]() { if (WLX_X_FIRST) load_weights(); });
             WLX_TR_MARK(1);
             __syncthreads();
             xr[0] = xs + crow[0] * ldxs + kw0 * 32 + g * 8;                 // lanes of rows >= M re-read a valid row (never stored)
@@ -485,6 +517,7 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
         for (int j = 0; j < CH; ++j)
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) xf[j][mt] = *reinterpret_cast<const f16x8*>(xr[mt] + j * xstep);
+        if (WLX_X_FIRST && !(MT == 1 && p.xstage)) load_weights();          // (staged form: requested inside stage_rows_f16)
 #pragma unroll 1
         for (int ch = 1; ch < p.NCH; ++ch) {                               // big-K layers of the larger models only
             f16x8 wn[CH][NTB], xn[CH][MT];
@@ -509,11 +542,21 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
         }
     } else if constexpr (IN == GEMV_IN_LN) {
         // wave w normalises rows w, w + nw, ...; a row = LNV float4 per lane (d_model = 256 LNV)
+        // first trip's rows (this wave's row and the one nw below it) are requested before anything else
+        float4 x[LNV], y[LNV];
+        {
+            const int ra = (wave < p.M) ? wave : p.M - 1, rb = (wave + nw < p.M) ? wave + nw : ra;
+            const float4* x4 = reinterpret_cast<const float4*>(p.X + (long)ra * p.ldx) + lane;
+            const float4* y4 = reinterpret_cast<const float4*>(p.X + (long)rb * p.ldx) + lane;
+#pragma unroll
+            for (int j = 0; j < LNV; ++j) { x[j] = x4[64 * j]; y[j] = y4[64 * j]; }
+        }
         const float4* g4 = reinterpret_cast<const float4*>(p.gamma) + lane;
         const float4* b4 = reinterpret_cast<const float4*>(p.beta) + lane;
         float4 gq[LNV], bq[LNV];
 #pragma unroll
         for (int j = 0; j < LNV; ++j) { gq[j] = g4[64 * j]; bq[j] = b4[64 * j]; }
+        if (WLX_X_FIRST) load_weights();
         const int ldxs = p.K + 8;
         constexpr float invK = 1.0f / (256.0f * LNV);
         auto ln_row = [&](float4 (&x)[LNV], int r) {
@@ -536,22 +579,37 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
                 *reinterpret_cast<f16x4*>(dst + 256 * j) = hv;
             }
         };
-#pragma unroll 1
-        for (int r = wave; r < p.M; r += 2 * nw) {                          // rows r and r + nw: both requested before either is reduced
-            const int r1 = r + nw;
-            const bool has1 = r1 < p.M;
-            const float4* x4 = reinterpret_cast<const float4*>(p.X + (long)r * p.ldx) + lane;
-            const float4* y4 = reinterpret_cast<const float4*>(p.X + (long)(has1 ? r1 : r) * p.ldx) + lane;
-            float4 x[LNV], y[LNV];
-#pragma unroll
-            for (int j = 0; j < LNV; ++j) { x[j] = x4[64 * j]; y[j] = y4[64 * j]; }
+        // first trip, straight-line: its rows were requested at the top. (It must not share a loop with the later trips:
+        // hipcc's wait insertion merges the two ways into a loop body by the NEWEST request of either, so a body that
+        // also re-loads x / y for a later trip makes the first trip wait for all but five of everything outstanding —
+        // i.e. for the weight stream the reordering above is meant to overlap.)
+        if (wave < p.M) {
+            const bool has1 = wave + nw < p.M;
 #pragma unroll 1
             for (int u = 0; u < (has1 ? 2 : 1); ++u) {                      // rolled: one copy of the row code (code size is latency here)
                 if (u) {
 #pragma unroll
                     for (int j = 0; j < LNV; ++j) x[j] = y[j];
                 }
-                ln_row(x, u ? r1 : r);
+                ln_row(x, u ? wave + nw : wave);
+            }
+        }
+#pragma unroll 1
+        for (int r = wave + 2 * nw; r < p.M; r += 2 * nw) {                 // batched rows (M > 2 nw): rows r and r + nw per trip
+            const int r1 = r + nw;
+            const bool has1 = r1 < p.M;
+            const float4* x4 = reinterpret_cast<const float4*>(p.X + (long)r * p.ldx) + lane;
+            const float4* y4 = reinterpret_cast<const float4*>(p.X + (long)(has1 ? r1 : r) * p.ldx) + lane;
+            float4 x2[LNV], y2[LNV];
+#pragma unroll
+            for (int j = 0; j < LNV; ++j) { x2[j] = x4[64 * j]; y2[j] = y4[64 * j]; }
+#pragma unroll 1
+            for (int u = 0; u < (has1 ? 2 : 1); ++u) {
+                if (u) {
+#pragma unroll
+                    for (int j = 0; j < LNV; ++j) x2[j] = y2[j];
+                }
+                ln_row(x2, u ? r1 : r);
             }
         }
         WLX_TR_MARK(1);
@@ -570,8 +628,12 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
         const int ldxs = p.K + 8;
         const int n_it = p.M * p.H * 8;
         const float rH = 1.0f / (float)p.H, rR = 1.0f / (float)p.R;
-#pragma unroll 1
-        for (int it = tid; it < n_it; it += blockDim.x) {
+        // One (row, head, 8-dim group) per call. The FIRST trip is straight-line code run by every thread (clamped item,
+        // result not stored when out of range) with the weight request right behind its loads; later trips (M * H * 8 >
+        // blockDim: batched rows) run in a separate loop — sharing one loop would make hipcc wait for the weights inside
+        // the first trip (its wait insertion merges loop paths by the newest request of either).
+        auto combine = [&](int it0, bool first) {
+            const int it = (it0 < n_it) ? it0 : n_it - 1;
             const int q8 = it & 7, hm = it >> 3;
             const int m = (int)(((float)hm + 0.5f) * rH), hh = hm - m * p.H;
             const int item = (int)(((float)m + 0.5f) * rR), qi = m - item * p.R;
@@ -584,6 +646,7 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
             for (int sp = 0; sp < WLX_XSPLIT / 2; ++sp) ml[sp] = mlp[sp];               // (m, l) of splits 2 sp, 2 sp + 1
 #pragma unroll
             for (int sp = 0; sp < WLX_XSPLIT; ++sp) ov[sp] = ld_f16x8(op + sp * 1024);
+            if (first && WLX_X_FIRST) load_weights();                       // behind the first trip's partial loads
             float mmax = fmaxf(ml[0].x, ml[0].z);
 #pragma unroll
             for (int sp = 1; sp < WLX_XSPLIT / 2; ++sp) mmax = fmaxf(mmax, fmaxf(ml[sp].x, ml[sp].z));
@@ -600,8 +663,11 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
             const float inv = 1.0f / den;
             const f16x8 hv = {(half_t)(num[0] * inv), (half_t)(num[1] * inv), (half_t)(num[2] * inv), (half_t)(num[3] * inv),
                               (half_t)(num[4] * inv), (half_t)(num[5] * inv), (half_t)(num[6] * inv), (half_t)(num[7] * inv)};
-            *reinterpret_cast<f16x8*>(xs + m * ldxs + hh * 64 + q8 * 8) = hv;
-        }
+            if (it0 < n_it) *reinterpret_cast<f16x8*>(xs + m * ldxs + hh * 64 + q8 * 8) = hv;
+        };
+        combine(tid, true);
+#pragma unroll 1
+        for (int it0 = tid + blockDim.x; it0 < n_it; it0 += blockDim.x) combine(it0, false);
         WLX_TR_MARK(1);
         __syncthreads();
         if (wave >= nw) return;                                             // helper waves are done (no later barrier needs them: ended waves leave the barrier count)
@@ -1075,7 +1141,25 @@ __global__ __launch_bounds__(XA_TPS * 64) void dec_cq_cross_attn_kernel(
     float* MLs = regB + TPS * 16 * 68;                                     // [6][16][2]
     half_t* qs = reinterpret_cast<half_t*>(MLs + TPS * 16 * 2);            // [16][72]
 
-    // ---- everything this wave will ever load, requested up front
+    // ---- everything this wave will ever load, requested up front — the LayerNorm row of the first trip FIRST (round 2):
+    // vmcnt retires in order, so with the 24 KiB of weights / K / V per wave ahead of it the row arrived last and the
+    // LayerNorm (which everything else waits for) started 2.6 us into a 5.9 us launch
+    const int nrow = (rows - grp * R < R) ? rows - grp * R : R;           // live rows of this group
+    float4 x0[LNV];
+    {
+        const int r0 = (wave < nrow) ? wave : nrow - 1;
+        const float4* x4 = reinterpret_cast<const float4*>(X + (long)(grp * R + r0) * ldx) + lane;
+#pragma unroll
+        for (int j = 0; j < LNV; ++j) x0[j] = x4[64 * j];
+    }
+    float4 gq[LNV], bq[LNV];
+    {
+        const float4* g4 = reinterpret_cast<const float4*>(gamma) + lane;
+        const float4* b4 = reinterpret_cast<const float4*>(beta) + lane;
+#pragma unroll
+        for (int j = 0; j < LNV; ++j) { gq[j] = g4[64 * j]; bq[j] = b4[64 * j]; }
+    }
+    asm volatile("" ::: "memory");     // compile-time fence: keep the requests below behind the ones above
     const int kw0 = wave * KPW;
     const half_t* wp = Wp + ((long)(h * 4) * KT + kw0) * 512 + lane * 8;
     f16x8 wf[KPW][4];
@@ -1095,20 +1179,9 @@ __global__ __launch_bounds__(XA_TPS * 64) void dec_cq_cross_attn_kernel(
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) vf[dt] = ld_f16x8(Vp + toff + dt * 512);
     const float4 bq4 = *reinterpret_cast<const float4*>(bias + h * 64 + (wave & 3) * 16 + g * 4);
-    const int nrow = (rows - grp * R < R) ? rows - grp * R : R;           // live rows of this group
     {   // LayerNorm: wave w normalises rows w, w + 6, ... of the group
-        const float4* g4 = reinterpret_cast<const float4*>(gamma) + lane;
-        const float4* b4 = reinterpret_cast<const float4*>(beta) + lane;
-        float4 gq[LNV], bq[LNV];
-#pragma unroll
-        for (int j = 0; j < LNV; ++j) { gq[j] = g4[64 * j]; bq[j] = b4[64 * j]; }
         constexpr float invK = 1.0f / (256.0f * LNV);
-#pragma unroll 1
-        for (int r = wave; r < nrow; r += TPS) {
-            const float4* x4 = reinterpret_cast<const float4*>(X + (long)(grp * R + r) * ldx) + lane;
-            float4 x[LNV];
-#pragma unroll
-            for (int j = 0; j < LNV; ++j) x[j] = x4[64 * j];
+        auto ln_row = [&](float4 (&x)[LNV], int r, bool keep) {
             float sm = 0.f;
 #pragma unroll
             for (int j = 0; j < LNV; ++j) sm += (x[j].x + x[j].y) + (x[j].z + x[j].w);
@@ -1125,8 +1198,19 @@ __global__ __launch_bounds__(XA_TPS * 64) void dec_cq_cross_attn_kernel(
             for (int j = 0; j < LNV; ++j) {
                 const f16x4 hv = {(half_t)(x[j].x * rstd * gq[j].x + bq[j].x), (half_t)(x[j].y * rstd * gq[j].y + bq[j].y),
                                   (half_t)(x[j].z * rstd * gq[j].z + bq[j].z), (half_t)(x[j].w * rstd * gq[j].w + bq[j].w)};
-                *reinterpret_cast<f16x4*>(dst + 256 * j) = hv;
+                if (keep) *reinterpret_cast<f16x4*>(dst + 256 * j) = hv;
             }
+        };
+        // first trip: straight-line and UNCONDITIONAL (a wave without a row normalises the clamped row it loaded and
+        // keeps nothing): inside an `if (wave < nrow)` hipcc sinks the row loads into the branch, behind the weights
+        ln_row(x0, (wave < nrow) ? wave : nrow - 1, wave < nrow);
+#pragma unroll 1
+        for (int r = wave + TPS; r < nrow; r += TPS) {                      // groups of more than six rows (prefill)
+            const float4* x4 = reinterpret_cast<const float4*>(X + (long)(grp * R + r) * ldx) + lane;
+            float4 x[LNV];
+#pragma unroll
+            for (int j = 0; j < LNV; ++j) x[j] = x4[64 * j];
+            ln_row(x, r, true);
         }
     }
     WLX_TR_MARK(1);

@@ -356,6 +356,7 @@ extern "C" int32_t wlx_engine_create(const wlx_spec* spec, const wlx_tensor* wei
     CK(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return fail(WLX_ERR_ARG, "device %d out of range (%d)", device, ndev);
     CK(hipSetDevice(device));
+    if (int pe = gemm_prepare_device()) return fail(WLX_ERR_HIP, "GEMM kernel set-up failed on device %d (hip error %d)", device, pe);
     wlx_engine* e = new wlx_engine();
     e->spec = *spec;
     e->device = device;

@@ -20,8 +20,99 @@
 // positional add, residual accumulate in fp32, q-scaling, K/V scatter with V stored transposed
 // for the attention kernels).
 #include "kernels.h"
+#include <algorithm>
+#include <cstdlib>
 
 namespace wlx {
+
+// ---------------- epilogue shared by both GEMM forms: lane owns columns n..n+3 of row m (WNT x WMT accumulator tiles of
+// the wave whose first n-tile is nt0 and first row m0)
+template <int WNT, int WMT>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[WNT][WMT], int nt0, int m0, int z, int c, int g) {
+#pragma unroll
+    for (int ni = 0; ni < WNT; ++ni) {
+        const int n = (nt0 + ni) * 16 + g * 4;
+        if (n >= p.N) continue;
+        float b4[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) {
+            float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
+            b4[0] = bv.x; b4[1] = bv.y; b4[2] = bv.z; b4[3] = bv.w;
+        }
+#pragma unroll
+        for (int mi = 0; mi < WMT; ++mi) {
+            const int m = m0 + mi * 16 + c;
+            if (m >= p.M) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] + b4[r];
+            switch (p.mode) {
+                case GEMM_STORE_F16:
+                case GEMM_GELU_F16: {
+                    if (p.mode == GEMM_GELU_F16) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                    }
+                    f16x4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                    *reinterpret_cast<f16x4*>(p.C + (long)z * p.strideC + (long)m * p.ldc + n) = o;
+                } break;
+                case GEMM_GELU_POS_F32: {
+                    float4 pv = *reinterpret_cast<const float4*>(p.pos + (long)m * p.N + n);
+                    float4 o = make_float4(gelu_erf(v[0]) + pv.x, gelu_erf(v[1]) + pv.y,
+                                           gelu_erf(v[2]) + pv.z, gelu_erf(v[3]) + pv.w);
+                    *reinterpret_cast<float4*>(p.X + (long)z * p.strideX + (long)m * p.ldx + n) = o;
+                } break;
+                case GEMM_RESID_F32: {
+                    float4* xp = reinterpret_cast<float4*>(p.X + (long)z * p.strideX + (long)m * p.ldx + n);
+                    float4 o = *xp;
+                    o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
+                    *xp = o;
+                } break;
+                case GEMM_QKV: {
+                    const int item = m / p.rows_per_item, t = m - item * p.rows_per_item;
+                    if (n < p.d) {
+                        f16x4 o = {(half_t)(v[0] * p.qscale), (half_t)(v[1] * p.qscale),
+                                   (half_t)(v[2] * p.qscale), (half_t)(v[3] * p.qscale)};
+                        *reinterpret_cast<f16x4*>(p.C + (long)m * p.ldc + n) = o;
+                    } else if (n < 2 * p.d) {
+                        f16x4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        *reinterpret_cast<f16x4*>(p.Kout + (long)item * p.kv_item_stride_k + (long)t * p.ldk + (n - p.d)) = o;
+                    } else {
+                        half_t* vt = p.Vt + (long)item * p.kv_item_stride_v + (long)(n - 2 * p.d) * p.ldvt + t;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vt[(long)r * p.ldvt] = (half_t)v[r];
+                    }
+                } break;
+                case GEMM_CROSS_KV: {
+                    // TILE-PACKED cross K / V for the decode cross-attention (decoder.hip dec_cross_attn_kernel): per
+                    // (layer, item, head, 32-key tile) a 4 KiB image in MFMA operand order —
+                    //   K: [s2][kt2][lane = g*16 + c][e]  = K[key = tile*32 + s2*16 + c][dim = kt2*32 + g*8 + e]
+                    //   V: [dt][lane = g*16 + c][e]       = V[key = tile*32 + (e < 4 ? g*4 + e : 16 + g*4 + e - 4)][dim = dt*16 + c]
+                    const int item = m / p.rows_per_item, t = m - item * p.rows_per_item;
+                    const int l = n / (2 * p.d), nn = n - l * 2 * p.d;
+                    const bool isk = nn < p.d;
+                    const int da = isk ? nn : nn - p.d;
+                    const int hd = da >> 6, dd = da & 63;
+                    const int tile = t >> 5, k32 = t & 31;
+                    const long tbase = ((long)hd * (WLX_T_AUDIO_PAD / 32) + tile) * 2048;
+                    if (isk) {
+                        const int s2 = k32 >> 4, cc = k32 & 15, kt2 = dd >> 5, gg = (dd & 31) >> 3, e0 = dd & 7;
+                        f16x4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
+                        *reinterpret_cast<f16x4*>(p.Kout + (long)l * p.kv_layer_stride_k + (long)item * p.kv_item_stride_k + tbase +
+                                                  ((s2 * 2 + kt2) * 64 + gg * 16 + cc) * 8 + e0) = o;
+                    } else {
+                        const int dt = dd >> 4, c0 = dd & 15;
+                        const int gg = (k32 & 15) >> 2, ee = (k32 & 3) + ((k32 >> 4) << 2);
+                        half_t* vp = p.Vt + (long)l * p.kv_layer_stride_v + (long)item * p.kv_item_stride_v + tbase +
+                                     (dt * 64 + gg * 16 + c0) * 8 + ee;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) vp[r * 8] = (half_t)v[r];
+                    }
+                } break;
+                default: break;
+            }
+        }
+    }
+}
 
 template <int WNT, int WMT>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
@@ -143,93 +234,165 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     }
 #endif
 
-    // ---------------- epilogue: lane owns columns n..n+3 of row m
+    gemm_epilogue<WNT, WMT>(p, acc, nt0, m0, z, c, g);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Second form (round 2): the same tiles, fragments, MFMA order and epilogue — bit-identical results — with the stage loop
+// rebuilt around what the ISA of the first form showed: its global loads for stage s+1 are issued one stage (~0.25 us of
+// MFMAs) before `s_waitcnt vmcnt(0)`, so every one of the 12-96 stages of a workgroup still pays most of an L2/HBM round
+// trip, and at ~1.1 workgroups per CU nothing else hides it. Here both operands go global -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: the per-lane SOURCE address is the fragment shape, the LDS image is lane-linear = fragment
+// order, so the ds_read_b128 of a fragment stays conflict-free) into a ring of DEPTH stages; DEPTH-1 stages are in flight
+// ahead of the MFMAs, each stage is released by a COUNTED vmcnt (this wave's pieces of the oldest stage) + one raw
+// s_barrier (everyone's pieces; also: everyone is done reading the buffer that is refilled next). `__syncthreads()` must
+// not be used here: with LDS-DMA in flight hipcc lowers it to vmcnt(0) + s_barrier and the ring drains every stage.
+typedef __attribute__((address_space(3))) void wlx_lds_void;
+
+template <int WNT, int WMT, int DEPTH>
+__global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
+    constexpr int KS = 2;                       // k-tiles (of 32) per stage
+    constexpr int FA = 2 * WNT * KS, FB = 2 * WMT * KS;
+    constexpr int CA = FA / 4, CB = FB / 4;     // fragments (1 KiB LDS-DMA pieces) each wave requests per stage
+    constexpr int NL = CA + CB;                 // = this wave's vmcnt events per stage
+    static_assert(DEPTH >= 2 && NL * (DEPTH - 2) <= 63, "vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) f16x8 ring[];        // [DEPTH][FA + FB][64 lanes] x 16 B — the ONLY LDS object
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int c = lane & 15, g = lane >> 4;
+    const int wn = wave & 1, wm = wave >> 1;
+    const int NT_total = (p.N + 15) >> 4;
+    const int ntb = blockIdx.x * (2 * WNT);
+    const int mb = blockIdx.y * (2 * WMT * 16);
+    const int nt0 = ntb + wn * WNT;
+    const int m0 = mb + wm * (WMT * 16);
+    const int z = blockIdx.z;
+    const half_t* A = p.A + (long)z * p.strideA;
+    const int KT = p.KT;
+
+    const half_t* asrc[CA];
+    const half_t* bsrc[CB];
 #pragma unroll
-    for (int ni = 0; ni < WNT; ++ni) {
-        const int n = (nt0 + ni) * 16 + g * 4;
-        if (n >= p.N) continue;
-        float b4[4] = {0.f, 0.f, 0.f, 0.f};
-        if (p.bias) {
-            float4 bv = *reinterpret_cast<const float4*>(p.bias + n);
-            b4[0] = bv.x; b4[1] = bv.y; b4[2] = bv.z; b4[3] = bv.w;
-        }
-#pragma unroll
-        for (int mi = 0; mi < WMT; ++mi) {
-            const int m = m0 + mi * 16 + c;
-            if (m >= p.M) continue;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] + b4[r];
-            switch (p.mode) {
-                case GEMM_STORE_F16:
-                case GEMM_GELU_F16: {
-                    if (p.mode == GEMM_GELU_F16) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
-                    }
-                    f16x4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                    *reinterpret_cast<f16x4*>(p.C + (long)z * p.strideC + (long)m * p.ldc + n) = o;
-                } break;
-                case GEMM_GELU_POS_F32: {
-                    float4 pv = *reinterpret_cast<const float4*>(p.pos + (long)m * p.N + n);
-                    float4 o = make_float4(gelu_erf(v[0]) + pv.x, gelu_erf(v[1]) + pv.y,
-                                           gelu_erf(v[2]) + pv.z, gelu_erf(v[3]) + pv.w);
-                    *reinterpret_cast<float4*>(p.X + (long)z * p.strideX + (long)m * p.ldx + n) = o;
-                } break;
-                case GEMM_RESID_F32: {
-                    float4* xp = reinterpret_cast<float4*>(p.X + (long)z * p.strideX + (long)m * p.ldx + n);
-                    float4 o = *xp;
-                    o.x += v[0]; o.y += v[1]; o.z += v[2]; o.w += v[3];
-                    *xp = o;
-                } break;
-                case GEMM_QKV: {
-                    const int item = m / p.rows_per_item, t = m - item * p.rows_per_item;
-                    if (n < p.d) {
-                        f16x4 o = {(half_t)(v[0] * p.qscale), (half_t)(v[1] * p.qscale),
-                                   (half_t)(v[2] * p.qscale), (half_t)(v[3] * p.qscale)};
-                        *reinterpret_cast<f16x4*>(p.C + (long)m * p.ldc + n) = o;
-                    } else if (n < 2 * p.d) {
-                        f16x4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                        *reinterpret_cast<f16x4*>(p.Kout + (long)item * p.kv_item_stride_k + (long)t * p.ldk + (n - p.d)) = o;
-                    } else {
-                        half_t* vt = p.Vt + (long)item * p.kv_item_stride_v + (long)(n - 2 * p.d) * p.ldvt + t;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) vt[(long)r * p.ldvt] = (half_t)v[r];
-                    }
-                } break;
-                case GEMM_CROSS_KV: {
-                    // TILE-PACKED cross K / V for the decode cross-attention (decoder.hip dec_cross_attn_kernel): per
-                    // (layer, item, head, 32-key tile) a 4 KiB image in MFMA operand order —
-                    //   K: [s2][kt2][lane = g*16 + c][e]  = K[key = tile*32 + s2*16 + c][dim = kt2*32 + g*8 + e]
-                    //   V: [dt][lane = g*16 + c][e]       = V[key = tile*32 + (e < 4 ? g*4 + e : 16 + g*4 + e - 4)][dim = dt*16 + c]
-                    const int item = m / p.rows_per_item, t = m - item * p.rows_per_item;
-                    const int l = n / (2 * p.d), nn = n - l * 2 * p.d;
-                    const bool isk = nn < p.d;
-                    const int da = isk ? nn : nn - p.d;
-                    const int hd = da >> 6, dd = da & 63;
-                    const int tile = t >> 5, k32 = t & 31;
-                    const long tbase = ((long)hd * (WLX_T_AUDIO_PAD / 32) + tile) * 2048;
-                    if (isk) {
-                        const int s2 = k32 >> 4, cc = k32 & 15, kt2 = dd >> 5, gg = (dd & 31) >> 3, e0 = dd & 7;
-                        f16x4 o = {(half_t)v[0], (half_t)v[1], (half_t)v[2], (half_t)v[3]};
-                        *reinterpret_cast<f16x4*>(p.Kout + (long)l * p.kv_layer_stride_k + (long)item * p.kv_item_stride_k + tbase +
-                                                  ((s2 * 2 + kt2) * 64 + gg * 16 + cc) * 8 + e0) = o;
-                    } else {
-                        const int dt = dd >> 4, c0 = dd & 15;
-                        const int gg = (k32 & 15) >> 2, ee = (k32 & 3) + ((k32 >> 4) << 2);
-                        half_t* vp = p.Vt + (long)l * p.kv_layer_stride_v + (long)item * p.kv_item_stride_v + tbase +
-                                     (dt * 64 + gg * 16 + c0) * 8 + ee;
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) vp[r * 8] = (half_t)v[r];
-                    }
-                } break;
-                default: break;
-            }
-        }
+    for (int j = 0; j < CA; ++j) {
+        const int f = wave + 4 * j, ni = f / KS, kk = f % KS;
+        int nt = ntb + ni;
+        if (nt >= NT_total) nt = NT_total - 1;
+        asrc[j] = p.Wp + ((long)nt * KT + kk) * 512 + lane * 8;
     }
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+        const int f = wave + 4 * j, mi = f / KS, kk = f % KS;
+        int row = mb + mi * 16 + c;
+        if (row >= p.M) row = p.M - 1;
+        bsrc[j] = A + (long)row * p.lda + kk * 32 + g * 8;
+    }
+    auto issue = [&](int st, int buf) {         // this wave's pieces of stage `st` -> ring buffer `buf`
+        f16x8* dst = ring + (long)buf * (FA + FB) * 64;
+#pragma unroll
+        for (int j = 0; j < CA; ++j)
+            __builtin_amdgcn_global_load_lds((const void*)(asrc[j] + (long)st * (KS * 512)), (wlx_lds_void*)(dst + (wave + 4 * j) * 64), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+            __builtin_amdgcn_global_load_lds((const void*)(bsrc[j] + (long)st * (KS * 32)), (wlx_lds_void*)(dst + (FA + wave + 4 * j) * 64), 16, 0, 0);
+    };
+
+    f32x4 acc[WNT][WMT];
+#pragma unroll
+    for (int ni = 0; ni < WNT; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < WMT; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int S = KT / KS;                      // the launcher only picks this form for KT % KS == 0
+#pragma unroll
+    for (int i = 0; i < DEPTH - 1; ++i)
+        if (i < S) issue(i, i);
+    int rbuf = 0, wbuf = DEPTH - 1;             // buffer read this trip / buffer refilled this trip (the one read last trip)
+#pragma unroll 1
+    for (int st = 0; st < S; ++st) {
+        // stages st .. min(st + DEPTH - 2, S - 1) are outstanding; stage st must have landed
+        if (st + DEPTH - 2 < S) __builtin_amdgcn_s_waitcnt(((NL * (DEPTH - 2)) & 15) | (((NL * (DEPTH - 2)) >> 4) << 14) | 0x0F70);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);                        // tail: fewer stages in flight, drain
+        __builtin_amdgcn_s_barrier();
+        if (st + DEPTH - 1 < S) issue(st + DEPTH - 1, wbuf);
+        const f16x8* src = ring + (long)rbuf * (FA + FB) * 64 + lane;
+#pragma unroll
+        for (int kk = 0; kk < KS; ++kk) {
+            f16x8 wf[WNT], af[WMT];
+#pragma unroll
+            for (int ni = 0; ni < WNT; ++ni) wf[ni] = src[((wn * WNT + ni) * KS + kk) * 64];
+#pragma unroll
+            for (int mi = 0; mi < WMT; ++mi) af[mi] = src[(FA + (wm * WMT + mi) * KS + kk) * 64];
+#pragma unroll
+            for (int ni = 0; ni < WNT; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < WMT; ++mi) acc[ni][mi] = mfma16(wf[ni], af[mi], acc[ni][mi]);
+        }
+        rbuf = (rbuf + 1 == DEPTH) ? 0 : rbuf + 1;
+        wbuf = (wbuf + 1 == DEPTH) ? 0 : wbuf + 1;
+    }
+    gemm_epilogue<WNT, WMT>(p, acc, nt0, m0, z, c, g);
+}
+
+// tile shapes of the second form: (WNT, WMT) wave tiles -> workgroup tile (32 WNT) x (32 WMT); ring depth by what fits
+// the 160 KiB of LDS with one workgroup per CU
+struct Gemm2Shape { int wnt, wmt, depth; };
+static const Gemm2Shape kGemm2Shapes[] = {{4, 4, 4}, {4, 6, 3}, {6, 4, 3}, {2, 3, 4}, {2, 4, 4}, {4, 2, 4}, {2, 2, 4}};
+template <int WNT, int WMT, int DEPTH>
+static void gemm2_go(const GemmParams& p, int zbatch, hipStream_t s) {
+    constexpr size_t shm = (size_t)DEPTH * (4 * WNT + 4 * WMT) * 1024;
+    const int NT_total = (p.N + 15) / 16;
+    dim3 grid((NT_total + 2 * WNT - 1) / (2 * WNT), (p.M + 32 * WMT - 1) / (32 * WMT), zbatch);
+    hipLaunchKernelGGL((gemm2_kernel<WNT, WMT, DEPTH>), grid, dim3(256), shm, s, p);
+}
+template <int WNT, int WMT, int DEPTH>
+static hipError_t gemm2_optin() {      // > 64 KiB of dynamic LDS needs the opt-in, per device (not a stream operation)
+    constexpr size_t shm = (size_t)DEPTH * (4 * WNT + 4 * WMT) * 1024;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<WNT, WMT, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+}
+// cost model: one workgroup per CU (LDS), so a launch takes ceil(workgroups / 256) rounds of a workgroup's time, which is
+// its MFMA work (WNT x WMT per stage) plus a fixed part (fill the ring, epilogue) worth about 3 stages of a 4x4 tile
+static int gemm2_pick(const GemmParams& p, int zbatch) {
+    static const int forced = [] { const char* e = getenv("WLX_GEMM2_SHAPE"); return e ? atoi(e) : -1; }();
+    const int n_shapes = (int)(sizeof(kGemm2Shapes) / sizeof(kGemm2Shapes[0]));
+    if (forced >= 0 && forced < n_shapes) return forced;
+    const int NT_total = (p.N + 15) / 16, S = p.KT / 2;
+    int best = 0;
+    double best_cost = 1e30;
+    for (int i = 0; i < n_shapes; ++i) {
+        const Gemm2Shape& sh = kGemm2Shapes[i];
+        const long wgs = (long)((NT_total + 2 * sh.wnt - 1) / (2 * sh.wnt)) * ((p.M + 32 * sh.wmt - 1) / (32 * sh.wmt)) * zbatch;
+        const long rounds = (wgs + 255) / 256;
+        const double per_stage = std::max((double)sh.wnt * sh.wmt, 1.5 * (sh.wnt + sh.wmt));   // MFMA issue vs LDS-DMA issue of a wave
+        const double cost = (double)rounds * (per_stage * S + 48.0 + 2.0 * sh.wnt * sh.wmt);
+        if (cost < best_cost) { best_cost = cost; best = i; }
+    }
+    return best;
+}
+int gemm_prepare_device() {      // once per engine, on the engine's device (wlx_engine_create)
+    hipError_t e = hipSuccess;
+    if (e == hipSuccess) e = gemm2_optin<4, 4, 4>();
+    if (e == hipSuccess) e = gemm2_optin<4, 6, 3>();
+    if (e == hipSuccess) e = gemm2_optin<6, 4, 3>();
+    if (e == hipSuccess) e = gemm2_optin<2, 3, 4>();
+    if (e == hipSuccess) e = gemm2_optin<2, 4, 4>();
+    if (e == hipSuccess) e = gemm2_optin<4, 2, 4>();
+    if (e == hipSuccess) e = gemm2_optin<2, 2, 4>();
+    return (int)e;
 }
 
 void launch_gemm(const GemmParams& p, int zbatch, hipStream_t s) {
+    static const int form = [] { const char* e = getenv("WLX_ENC_GEMM"); return e ? atoi(e) : 2; }();   // 1 = first form (A/B)
+    if (form != 1 && (p.KT & 1) == 0 && p.KT >= 2) {
+        switch (gemm2_pick(p, zbatch)) {
+            case 0: gemm2_go<4, 4, 4>(p, zbatch, s); return;
+            case 1: gemm2_go<4, 6, 3>(p, zbatch, s); return;
+            case 2: gemm2_go<6, 4, 3>(p, zbatch, s); return;
+            case 3: gemm2_go<2, 3, 4>(p, zbatch, s); return;
+            case 4: gemm2_go<2, 4, 4>(p, zbatch, s); return;
+            case 5: gemm2_go<4, 2, 4>(p, zbatch, s); return;
+            default: gemm2_go<2, 2, 4>(p, zbatch, s); return;
+        }
+    }
     const int NT_total = (p.N + 15) / 16;
     // tile choice: wide outputs get 128x128 workgroup tiles (4x4 wave tiles: 16 MFMAs per 8 fragment
     // loads); narrow ones (N = d) use 64x64 so the launch still spreads over the 256 CUs.

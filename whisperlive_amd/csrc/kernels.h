@@ -54,6 +54,8 @@ struct GemmParams {
     long kv_layer_stride_k, kv_layer_stride_v; // per decoder layer (mode 5)
 };
 void launch_gemm(const GemmParams& p, int zbatch, hipStream_t s);
+// per-device set-up of the GEMM kernels (large dynamic-LDS opt-in); returns a hipError_t value
+int gemm_prepare_device();
 // x fp32 [M][d] -> fp16 LN(x)*gamma+beta [M][d]
 void launch_layernorm_f16(const float* x, long ldx, const float* gamma, const float* beta,
                           half_t* out, long ldo, int M, int d, hipStream_t s);
