@@ -149,3 +149,72 @@ def test_sampling_is_seeded_and_valid():
     assert a.sequences_ids == b.sequences_ids and a.sequences_ids != c.sequences_ids
     for s in a.sequences_ids:
         assert s[0] >= L["timestamp_begin"] and s[0] <= L["timestamp_begin"] + 50 and 3 not in s and 4 not in s
+
+
+def _beam_cases():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "beam_golden.json")) as f:
+        return json.load(f)["cases"]
+
+
+class _BiasedProvider(NetProvider):
+    """oracle network + the same seeded per-token logit offset the golden HF run applied (make_beam_golden.py)"""
+
+    def __init__(self, model, enc, bias):
+        super().__init__(model, enc)
+        self.bias = bias
+
+    def prefill(self, tokens):
+        r = super().prefill(tokens)
+        return None if r is None else r + self.bias
+
+    def step(self, tokens, parents):
+        return super().step(tokens, parents) + self.bias
+
+
+@pytest.mark.parametrize("case", ["m64", "m128"])
+def test_beam_search_equals_hf_beam_search(case):
+    """The oracle's beam search (= search.hip's decision procedure) against Hugging Face's own beam search
+    (`GenerationMixin.generate(num_beams=N, early_stopping=True)` with HF's Whisper logits processors), 10 seeded cases
+    per golden model, beams 5 and 3, with and without hypotheses that finish on <|endoftext|>: HF's returned list IS the oracle's set of finished
+    hypotheses ranked by HF's length normaliser (same tokens, same order, sums of log-probs to 2e-3). The one deliberate
+    difference — CTranslate2 divides by the length WITHOUT the EOT (what transcriber_faster_whisper.py:1412-1414 relies
+    on), HF by the length with it — is checked explicitly: the oracle's own order is the CT2-convention order of the
+    same set."""
+    from tests.golden import make_beam_golden as mb
+    spec, w = mg.np_weights(case)
+    oracle = omodel.WhisperOracle(omodel.Spec(spec.n_mels, spec.d_model, spec.n_heads, spec.enc_layers, spec.dec_layers,
+                                              spec.ffn, spec.vocab), w)
+    L = mg.token_layout(spec.vocab)
+    cases = [c for c in _beam_cases() if c["model"] == case]
+    assert len(cases) == mb.N_SEEDS
+    n_eot = 0
+    for c in cases:
+        feats, bias, max_new, beams = mb.case_inputs(case, c["seed"])
+        assert (max_new, beams) == (c["max_new_tokens"], c["num_beams"])
+        enc = oracle.encode(feats)
+        # ask the oracle for EVERY finished hypothesis (a step can finish several at once, so there may be more than
+        # `beams` of them); CTranslate2 and HF then keep the best `beams` of that set under their own length normaliser
+        o = odec.GenOptions(ids=odec.TokenIds(**L), beam_size=beams, patience=1.0, num_hypotheses=4 * beams, length_penalty=1.0,
+                            suppress_blank=True, suppress_tokens=mb.suppress_ids(L), max_length=1 + max_new)
+        res = odec.generate(_BiasedProvider(oracle, enc, bias), [L["sot"]], o)
+        hf = {tuple(h["tokens"]): h for h in c["hypotheses"]}
+        full = {tuple(t): s * max(len(t), 1) for t, s in zip(res.sequences_ids, res.scores)}       # tokens -> sum of log-probs
+        assert len(full) == len(res.sequences_ids) >= beams
+        ended = {t: len(t) < max_new for t in full}          # shorter than the budget <=> it ended on <|endoftext|>
+        # (1) HF's returned list = the best `beams` of the oracle's finished set under HF's normaliser, same order
+        by_hf = sorted(full, key=lambda t: -full[t] / (len(t) + (1 if ended[t] else 0)))[:beams]
+        assert by_hf == [tuple(h["tokens"]) for h in c["hypotheses"]], (case, c["seed"], by_hf, list(hf))
+        for t in by_hf:
+            assert ended[t] == hf[t]["ended_with_eot"]
+            assert abs(full[t] - hf[t]["sum_logprob"]) <= 2e-3 * max(1.0, abs(hf[t]["sum_logprob"])), (case, c["seed"], t)
+            n_eot += hf[t]["ended_with_eot"]
+        # (2) the oracle's own order is the CTranslate2 convention: sum / len WITHOUT the EOT (min 1)
+        assert [tuple(t) for t in res.sequences_ids] == sorted(full, key=lambda t: -full[t] / max(len(t), 1)), (case, c["seed"])
+        # (3) with num_hypotheses = 1 (what the reference asks for) the winner is the head of that order
+        o1 = odec.GenOptions(ids=odec.TokenIds(**L), beam_size=beams, patience=1.0, num_hypotheses=1, length_penalty=1.0,
+                             suppress_blank=True, suppress_tokens=mb.suppress_ids(L), max_length=1 + max_new)
+        best = odec.generate(_BiasedProvider(oracle, enc, bias), [L["sot"]], o1)
+        assert best.sequences_ids[0] == res.sequences_ids[0] and abs(best.scores[0] - res.scores[0]) < 1e-6
+    assert n_eot >= 5                                  # the finished-hypothesis path was exercised
