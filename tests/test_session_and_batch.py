@@ -300,3 +300,26 @@ def test_engine_slots_are_pooled_across_client_threads():
         s.close()
     t = threading.Thread(target=session); t.start(); t.join()
     assert len(eng.slots) == 3 and seen[-1].sid >= 0
+
+
+def test_wide_batches_decode_in_lean_groups_over_the_same_encoder_output():
+    """8 items x 5 beams = 40 rows exceed what one launch of the lean decode kernels covers (32): the batch is decoded as
+    groups of 6 + 2 items over the SAME encoder output (item maps), one result per prompt, in order."""
+    eng = FakeEngine()
+    tb = eng.spec.vocab - 1501
+    seen = []
+
+    def script(prompts, ids, kw):
+        seen.append((len(prompts), kw.get("enc_items")))
+        return [GenerationResult([[tb, 300 + i, tb + 50]], [-0.1], 0.01) for i in range(len(prompts))]
+
+    eng.generate_script = [script, script]
+    m = WhisperModelHIP("fake", engine=eng, hf_tokenizer=synthetic_tokenizer(V), max_batch=8, vad_model=EnergyGateModel())
+    enc = m.encode(np.zeros((8, 80, 3000), np.float32))
+    tk = Tokenizer(m.hf_tokenizer, False)
+    res = m.model.generate(enc, [[tk.sot]] * 8, beam_size=5)
+    assert seen == [(6, [0, 1, 2, 3, 4, 5]), (2, [6, 7])] and len(res) == 8
+    seen.clear()
+    eng.generate_script = [script]
+    m.model.generate(enc, [[tk.sot]] * 6, beam_size=5)
+    assert seen == [(6, None)]                       # fits one launch: no item map needed

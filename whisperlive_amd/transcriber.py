@@ -159,6 +159,8 @@ class FeatureExtractorHIP:
 class _EngineModel:
     """The ctranslate2.models.Whisper surface the reference calls."""
 
+    MAX_LEAN_ROWS = 32      # rows one launch of the lean decode kernels covers (csrc/decoder.hip gemv2_cfg)
+
     def __init__(self, owner: "WhisperModelHIP"):
         self._o = owner
         self.device = "cuda"
@@ -194,12 +196,22 @@ class _EngineModel:
             sup = [t for t in sup if t >= 0] + list(o._base_tokenizer.non_speech_tokens)
         # CT2's generate defaults: beam_size > 1 -> beam search; beam_size == 1 -> sampling with top-k / temperature.
         temp = 0.0 if beam_size > 1 else (float(sampling_temperature) if sampling_topk != 1 else 0.0)
-        res = slot.generate(prompts, o.token_ids, beam_size=beam_size, patience=patience, num_hypotheses=num_hypotheses,
-                            length_penalty=length_penalty, repetition_penalty=repetition_penalty,
-                            no_repeat_ngram_size=no_repeat_ngram_size, max_length=max_length, suppress_blank=suppress_blank,
-                            suppress_tokens=sup, max_initial_timestamp_index=max_initial_timestamp_index,
-                            sampling_topk=sampling_topk, sampling_temperature=temp, seed=o._next_seed(),
-                            enc_items=encoder_output.items)
+        # The lean decode kernels (decoder.hip dec_gemv2_kernel) cover 32 beam rows per launch; a wider batch (the batch
+        # worker's default of 8 items x 5 beams = 40 rows) would fall back to the general first-generation kernels, ~3x
+        # slower per step. Decode such a batch as consecutive groups over the SAME resident encoder output (item maps):
+        # identical results, every launch on the fast path.
+        rows_per_item = max(1, beam_size if (beam_size > 1 and temp == 0.0) else num_hypotheses)
+        group = max(1, self.MAX_LEAN_ROWS // rows_per_item)
+        items = encoder_output.items if encoder_output.items is not None else list(range(encoder_output.batch))
+        res = []
+        for a in range(0, len(prompts), group):
+            res.extend(slot.generate(prompts[a:a + group], o.token_ids, beam_size=beam_size, patience=patience,
+                                     num_hypotheses=num_hypotheses, length_penalty=length_penalty,
+                                     repetition_penalty=repetition_penalty, no_repeat_ngram_size=no_repeat_ngram_size,
+                                     max_length=max_length, suppress_blank=suppress_blank, suppress_tokens=sup,
+                                     max_initial_timestamp_index=max_initial_timestamp_index, sampling_topk=sampling_topk,
+                                     sampling_temperature=temp, seed=o._next_seed(),
+                                     enc_items=(items[a:a + group] if (encoder_output.items is not None or len(prompts) > group) else None)))
         hf = o.hf_tokenizer
         for r in res:
             tb = o.token_ids.timestamp_begin       # ids past the tokenizer's own table are timestamps (see __init__)
