@@ -321,5 +321,6 @@ def test_wide_batches_decode_in_lean_groups_over_the_same_encoder_output():
     assert seen == [(6, [0, 1, 2, 3, 4, 5]), (2, [6, 7])] and len(res) == 8
     seen.clear()
     eng.generate_script = [script]
-    m.model.generate(enc, [[tk.sot]] * 6, beam_size=5)
+    enc6 = m.encode(np.zeros((6, 80, 3000), np.float32))
+    m.model.generate(enc6, [[tk.sot]] * 6, beam_size=5)
     assert seen == [(6, None)]                       # fits one launch: no item map needed
