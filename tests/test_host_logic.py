@@ -213,7 +213,9 @@ def test_transcribe_single_window_and_empty_after_vad(model):
     silent = np.zeros(3 * 16000, np.float32)
     assert m.transcribe(silent, vad_filter=True, vad_parameters={"threshold": 0.5}) == (None, None)
     with pytest.raises(TypeError):
-        m.transcribe("file.wav")
+        m.transcribe(12345)
+    with pytest.raises(FileNotFoundError):
+        m.transcribe("/nonexistent/file.wav")
 
 
 def test_transcribe_long_audio_seeks_and_conditions_on_previous_text(model):

@@ -23,6 +23,13 @@ EXPORTS = [
 ]
 
 
+# MFMA accumulators in VGPRs (gfx950 has ONE register file; hipcc's default puts C/D in its AGPR half): every VALU touch of
+# an accumulator — the softmax rescale of the attention kernel, the GEMM epilogues — otherwise costs a v_accvgpr_read and
+# a v_accvgpr_write per register: a third of all VALU instructions of the encoder attention kernel (576 of 1738 per six key
+# tiles), which is VALU-issue bound (rocprofv3: SQ_ACTIVE_INST_VALU 56 % of its wave cycles). No kernel spills with it.
+HIPCC_EXTRA = ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]
+
+
 class WlxError(RuntimeError):
     pass
 
@@ -74,7 +81,7 @@ def build_trace() -> Path:
     if out.exists() and all(out.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return out
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DWLX_TRACE", "-o", str(out)] + [str(s) for s in srcs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DWLX_TRACE"] + HIPCC_EXTRA + ["-o", str(out)] + [str(s) for s in srcs]
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
         raise WlxError(f"hipcc failed ({proc.returncode}):\n{proc.stderr[-4000:]}")
@@ -90,7 +97,7 @@ def build_variant(name: str, defines) -> Path:
     if out.exists() and all(out.stat().st_mtime >= d.stat().st_mtime for d in deps):
         return out
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + [f"-D{d}" for d in defines] + ["-o", str(out)] + [str(s) for s in srcs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + HIPCC_EXTRA + [f"-D{d}" for d in defines] + ["-o", str(out)] + [str(s) for s in srcs]
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
         raise WlxError(f"hipcc failed ({proc.returncode}):\n{proc.stderr[-4000:]}")
@@ -107,7 +114,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if not os.path.exists(hipcc):
         raise WlxError("hipcc not found: cannot build libwlx.so (ROCm toolchain required)")
     tmp = DEFAULT_LIB.with_suffix(".so.tmp")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-o", str(tmp)] + [str(s) for s in srcs]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + HIPCC_EXTRA + ["-o", str(tmp)] + [str(s) for s in srcs]
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if verbose or proc.returncode != 0:
         print(proc.stdout, proc.stderr)

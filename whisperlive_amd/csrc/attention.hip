@@ -12,6 +12,8 @@
 // V^T A-fragments are two 8-byte loads per lane. Everything is read straight from L2 (K/V of a
 // head are 384 KB and stay resident), no LDS, no barriers; the next key tile is prefetched into registers.
 #include "kernels.h"
+#include <cstdlib>
+#include <type_traits>
 
 namespace wlx {
 
@@ -139,15 +141,19 @@ __global__ __launch_bounds__(64) void attn_encoder_kernel(const half_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// Second form (round 2): the same arithmetic in the same order — results are bit-identical to attn_encoder_kernel —
-// with the two things the ISA of the first form showed it was waiting on removed:
+// Second form (round 2). Same tiling and MFMA order as attn_encoder_kernel; what changed is what the ISA and the
+// rocprofv3 SQ counters of the first form showed it was spending its time on (profiles/r2c_*):
 //  * hipcc collapsed the one-tile "prefetch" above (the kn/vn -> kf/vf copies were coalesced, so the loads of tile i+1
 //    land in the registers the MFMAs of tile i+1 read and every tile still waits a full L2 round trip, then drains
-//    vmcnt(0) at the loop end): here three NAMED tile register sets rotate through a loop unrolled by three, two tiles
+//    vmcnt(0) at the loop end): here three NAMED tile register sets rotate through a loop body of six tiles, two tiles
 //    are always in flight behind the one being multiplied, and nothing is copied;
-//  * the softmax row maximum crossed the four 16-lane rows of a wave with two ds_bpermute round trips per query tile
-//    (~250 cycles of LDS latency on the wave's critical path, 94 times per launch): v_permlane16_swap / v_permlane32_swap
-//    exchange rows inside the VALU.
+//  * the softmax row maximum crossed the four 16-lane rows of a wave with two ds_bpermute round trips per query tile:
+//    v_permlane16_swap / v_permlane32_swap exchange rows inside the VALU;
+//  * with the waiting gone the kernel is VALU-ISSUE bound (SQ_ACTIVE_INST_VALU 56 % of wave cycles, 290 VALU instructions
+//    per 32-key tile): a third of them were v_accvgpr_read/write around the accumulator rescale (gone with the library-
+//    wide -amdgpu-mfma-vgpr-form, _lib.py), and the rest is trimmed here — scores in the log2 domain (FMA + v_exp_f32
+//    per score), key masks only in the last tiles, the rescale skipped when no lane raised its maximum: 142 per tile.
+// Results differ from the first form by fp32 rounding of the exponent argument only (parity tests: unchanged error).
 __device__ __forceinline__ float rows4_max(float v) {
     // rows (16-lane groups) r0..r3 of a wave: after the first swap a = {r0,r0,r2,r2}, b = {r1,r1,r3,r3}; after the second
     // a = {lo,lo}, b = {hi,hi}. Written as asm with BOTH operands read-write: the builtin with two identical operands is
@@ -210,7 +216,12 @@ __global__ __launch_bounds__(64) void attn_encoder_pf_kernel(const half_t* __res
             t.v[dt] = (f16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         }
     };
-    auto multiply = [&](int ti, const AttnTile& t) {
+    // Scores stay in the log2 domain: p = 2^(s * log2(e) - m2) with m2 the running maximum times log2(e) — one FMA and one
+    // v_exp_f32 per score instead of subtract, multiply and exp (the kernel is VALU-issue bound: rocprofv3 SQ counters,
+    // profiles/r2c_*). `masked` = the tile may hold keys >= T (the last real tile and the all-masked filler).
+    constexpr float LOG2E = 1.4426950408889634f;
+    auto multiply = [&](int ti, const AttnTile& t, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
         const int key0 = ti << 5;
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
@@ -227,29 +238,35 @@ __global__ __launch_bounds__(64) void attn_encoder_pf_kernel(const half_t* __res
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int key = key0 + s * 16 + g * 4 + r;
-                    const float v = (key < T) ? st[s][r] : WLX_NEG_INF;
+                    float v = st[s][r];
+                    if (MASKED) { const int key = key0 + s * 16 + g * 4 + r; v = (key < T) ? v : WLX_NEG_INF; }
                     p[s * 4 + r] = v;
                     tmax = fmaxf(tmax, v);
                 }
-            tmax = rows4_max(tmax);
+            tmax = rows4_max(tmax) * LOG2E;                     // (log2(e) > 0: the maximum commutes with the scaling)
             const float mnew = fmaxf(mrun[qt], tmax);
-            const float alpha = __expf(mrun[qt] - mnew);
+            const float alpha = __builtin_amdgcn_exp2f(mrun[qt] - mnew);
             float psum = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) { p[i] = __expf(p[i] - mnew); psum += p[i]; }
+            for (int i = 0; i < 8; ++i) { p[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(p[i], LOG2E, -mnew)); psum += p[i]; }
             lrun[qt] = lrun[qt] * alpha + psum;
             mrun[qt] = mnew;
             const f16x8 pf = {(half_t)p[0], (half_t)p[1], (half_t)p[2], (half_t)p[3],
                               (half_t)p[4], (half_t)p[5], (half_t)p[6], (half_t)p[7]};
+            // the running maximum of most queries settles within the first tiles: when NO lane of the wave raised its
+            // maximum (alpha == 1 everywhere) the 16 accumulator multiplies are skipped — by 1.0f they change nothing
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+                float al = alpha;
+                asm volatile("" : "+v"(al));                    // opaque: keeps this a wave-uniform BRANCH (hipcc if-converts it into 16 selects otherwise)
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) {
-                f32x4 a = acc[qt][dt];
-                a[0] *= alpha; a[1] *= alpha; a[2] *= alpha; a[3] *= alpha;
-                acc[qt][dt] = mfma16(t.v[dt], pf, a);
+                for (int dt = 0; dt < 4; ++dt) { acc[qt][dt][0] *= al; acc[qt][dt][1] *= al; acc[qt][dt][2] *= al; acc[qt][dt][3] *= al; }
             }
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) acc[qt][dt] = mfma16(t.v[dt], pf, acc[qt][dt]);
         }
     };
+    using Plain = std::false_type;
+    using Masked = std::true_type;
     // A tile is 12 vector-memory loads (4 x 16 B of K, 8 x 8 B of V^T); two tiles are kept in flight behind the one being
     // multiplied. hipcc's own wait insertion is conservative at a loop header — whatever was requested before the
     // back-edge is waited for in full at its first use after it (a three-tile loop body drained the tile requested one
@@ -261,17 +278,21 @@ __global__ __launch_bounds__(64) void attn_encoder_pf_kernel(const half_t* __res
 #define WLX_WAIT_VM(n) do { __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | 0x0F70); __builtin_amdgcn_sched_barrier(0); } while (0)
     AttnTile tA, tB, tC;
     load_tile(0, tA);
+#define WLX_SIX_TILES(TAG)                                                            \
+        load_tile(ti + 1, tB);                                                        \
+        load_tile(ti + 2, tC);                                                        \
+        WLX_WAIT_VM(24); multiply(ti, tA, TAG{});     load_tile(ti + 3, tA);          \
+        WLX_WAIT_VM(24); multiply(ti + 1, tB, TAG{}); load_tile(ti + 4, tB);          \
+        WLX_WAIT_VM(24); multiply(ti + 2, tC, TAG{}); load_tile(ti + 5, tC);          \
+        WLX_WAIT_VM(24); multiply(ti + 3, tA, TAG{}); load_tile(ti + 6, tA);          \
+        WLX_WAIT_VM(24); multiply(ti + 4, tB, TAG{});                                 \
+        WLX_WAIT_VM(12); multiply(ti + 5, tC, TAG{});
+    int ti = 0;
 #pragma unroll 1
-    for (int ti = 0; ti < NT; ti += 6) {
-        load_tile(ti + 1, tB);
-        load_tile(ti + 2, tC);
-        WLX_WAIT_VM(24); multiply(ti, tA);     load_tile(ti + 3, tA);
-        WLX_WAIT_VM(24); multiply(ti + 1, tB); load_tile(ti + 4, tB);
-        WLX_WAIT_VM(24); multiply(ti + 2, tC); load_tile(ti + 5, tC);
-        WLX_WAIT_VM(24); multiply(ti + 3, tA); load_tile(ti + 6, tA);
-        WLX_WAIT_VM(24); multiply(ti + 4, tB);
-        WLX_WAIT_VM(12); multiply(ti + 5, tC);
-    }
+    for (; (ti + 6) * 32 <= T; ti += 6) { WLX_SIX_TILES(Plain) }        // six tiles entirely below T: no key masks
+#pragma unroll 1
+    for (; ti < NT; ti += 6) { WLX_SIX_TILES(Masked) }                  // the rest (at most one or two trips)
+#undef WLX_SIX_TILES
 #undef WLX_WAIT_VM
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {

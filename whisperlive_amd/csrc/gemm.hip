@@ -262,8 +262,26 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
     const int c = lane & 15, g = lane >> 4;
     const int wn = wave & 1, wm = wave >> 1;
     const int NT_total = (p.N + 15) >> 4;
-    const int ntb = blockIdx.x * (2 * WNT);
-    const int mb = blockIdx.y * (2 * WMT * 16);
+    // XCD-aware tile map (launcher: p.xcd_a x p.xcd_b = 8, 0 = off). Workgroups are dealt round-robin over the 8 XCDs
+    // (linear id % 8) and every XCD has its own 4 MiB L2: with the plain (x fastest) map each XCD's workgroups touch
+    // EVERY weight panel and EVERY activation panel — 7-14 MB per encoder GEMM through a 4 MiB L2, so most stage fills
+    // are L2 misses (measured: TCC miss bytes 4-8x the unique operand bytes) and the LDS-DMA ring waits on HBM latency.
+    // Here XCD j owns the sub-rectangle (m-part j / b, n-part j % b) of the tile grid: its working set is 1/a of the
+    // activations plus 1/b of the weights.
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (p.xcd_a > 0) {
+        const int gx = gridDim.x, gy = gridDim.y;
+        const int lin = bx + gx * by;
+        const int xcd = lin & 7, k = lin >> 3;
+        const int a = p.xcd_a, b = p.xcd_b;                 // a | gy, b | gx, (gx * gy) % 8 == 0 (launcher)
+        const int sy = gy / a, sx = gx / b;                  // tiles of one XCD: sy x sx, sy * sx == gx * gy / 8
+        const int ja = xcd / b, jb = xcd - ja * b;
+        const int ly = k % sy, lx = k / sy;
+        by = ja * sy + ly;
+        bx = jb * sx + lx;
+    }
+    const int ntb = bx * (2 * WNT);
+    const int mb = by * (2 * WMT * 16);
     const int nt0 = ntb + wn * WNT;
     const int m0 = mb + wm * (WMT * 16);
     const int z = blockIdx.z;
@@ -338,10 +356,25 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
 struct Gemm2Shape { int wnt, wmt, depth; };
 static const Gemm2Shape kGemm2Shapes[] = {{4, 4, 4}, {4, 6, 3}, {6, 4, 3}, {2, 3, 4}, {2, 4, 4}, {4, 2, 4}, {2, 2, 4}};
 template <int WNT, int WMT, int DEPTH>
-static void gemm2_go(const GemmParams& p, int zbatch, hipStream_t s) {
+static void gemm2_go(const GemmParams& p0, int zbatch, hipStream_t s) {
     constexpr size_t shm = (size_t)DEPTH * (4 * WNT + 4 * WMT) * 1024;
-    const int NT_total = (p.N + 15) / 16;
-    dim3 grid((NT_total + 2 * WNT - 1) / (2 * WNT), (p.M + 32 * WMT - 1) / (32 * WMT), zbatch);
+    const int NT_total = (p0.N + 15) / 16;
+    dim3 grid((NT_total + 2 * WNT - 1) / (2 * WNT), (p0.M + 32 * WMT - 1) / (32 * WMT), zbatch);
+    GemmParams p = p0;
+    p.xcd_a = p.xcd_b = 0;
+    static const bool swz_on = [] { const char* e = getenv("WLX_GEMM2_XCD"); return !(e && e[0] == '0'); }();   // 0 = plain map (A/B)
+    const int gx = (int)grid.x, gy = (int)grid.y;
+    if (swz_on && zbatch == 1 && (gx * gy) % 8 == 0 && gx * gy >= 16) {
+        // split of the 8 XCDs into a m-parts x b n-parts that minimises the bytes one XCD's L2 must hold:
+        // activations / a + weights / b (both x K x 2 bytes; K cancels)
+        double best = 1e300;
+        for (int a = 1; a <= 8; a <<= 1) {
+            const int b = 8 / a;
+            if (gy % a || gx % b) continue;
+            const double bytes = (double)p.M / a + (double)p.N / b;
+            if (bytes < best) { best = bytes; p.xcd_a = a; p.xcd_b = b; }
+        }
+    }
     hipLaunchKernelGGL((gemm2_kernel<WNT, WMT, DEPTH>), grid, dim3(256), shm, s, p);
 }
 template <int WNT, int WMT, int DEPTH>
@@ -349,24 +382,17 @@ static hipError_t gemm2_optin() {      // > 64 KiB of dynamic LDS needs the opt-
     constexpr size_t shm = (size_t)DEPTH * (4 * WNT + 4 * WMT) * 1024;
     return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<WNT, WMT, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
 }
-// cost model: one workgroup per CU (LDS), so a launch takes ceil(workgroups / 256) rounds of a workgroup's time, which is
-// its MFMA work (WNT x WMT per stage) plus a fixed part (fill the ring, epilogue) worth about 3 stages of a 4x4 tile
+// Tile shape. Measured on the Whisper-small encoder (MI355X, one shape forced for every GEMM, profiles/r2c_*): 64 x 96
+// workgroup tiles (2 x 3 wave tiles, ring of 4) 1.87 ms per encoder, 64 x 64 1.97, 128 x 64 2.00, 64 x 128 2.14,
+// 128 x 128 2.25, 128 x 192 2.63, and the per-GEMM "fewest rounds" choice of the first draft 1.92: the stage fills are
+// latency-bound (SQ_WAIT_ANY 41-43 % of wave cycles), so what pays is MORE workgroups per CU (two 80 KiB rings fit the
+// 160 KiB of LDS, i.e. 120 KiB of fills in flight per CU), not fewer, larger tiles. WLX_GEMM2_SHAPE=i forces entry i.
 static int gemm2_pick(const GemmParams& p, int zbatch) {
     static const int forced = [] { const char* e = getenv("WLX_GEMM2_SHAPE"); return e ? atoi(e) : -1; }();
     const int n_shapes = (int)(sizeof(kGemm2Shapes) / sizeof(kGemm2Shapes[0]));
     if (forced >= 0 && forced < n_shapes) return forced;
-    const int NT_total = (p.N + 15) / 16, S = p.KT / 2;
-    int best = 0;
-    double best_cost = 1e30;
-    for (int i = 0; i < n_shapes; ++i) {
-        const Gemm2Shape& sh = kGemm2Shapes[i];
-        const long wgs = (long)((NT_total + 2 * sh.wnt - 1) / (2 * sh.wnt)) * ((p.M + 32 * sh.wmt - 1) / (32 * sh.wmt)) * zbatch;
-        const long rounds = (wgs + 255) / 256;
-        const double per_stage = std::max((double)sh.wnt * sh.wmt, 1.5 * (sh.wnt + sh.wmt));   // MFMA issue vs LDS-DMA issue of a wave
-        const double cost = (double)rounds * (per_stage * S + 48.0 + 2.0 * sh.wnt * sh.wmt);
-        if (cost < best_cost) { best_cost = cost; best = i; }
-    }
-    return best;
+    (void)p; (void)zbatch;
+    return 3;
 }
 int gemm_prepare_device() {      // once per engine, on the engine's device (wlx_engine_create)
     hipError_t e = hipSuccess;

@@ -451,7 +451,12 @@ class WhisperModelHIP:
                                 "setting to False instead.")
             multilingual = False
         if not isinstance(audio, np.ndarray):
-            raise TypeError("audio must be a float32 numpy waveform at 16 kHz (file decoding is outside the hot path)")
+            # path / bytes / file object, like the reference's decode_audio (:821); WAV and FLAC are read natively
+            # (whisperlive_amd/audio_io.py), anything else must arrive as 16 kHz float32 PCM
+            if not isinstance(audio, (str, bytes, bytearray)) and not hasattr(audio, "read"):
+                raise TypeError("audio must be a float32 numpy waveform at 16 kHz, or a WAV / FLAC path, bytes or file object")
+            from .audio_io import load_audio
+            audio = load_audio(audio, sampling_rate=sr)
         audio = np.ascontiguousarray(audio, dtype=np.float32)
         duration = audio.shape[0] / sr
         duration_after_vad = duration
