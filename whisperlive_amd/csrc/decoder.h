@@ -26,7 +26,17 @@ void launch_dec_embed(const half_t* tok_emb, const float* pos_emb, int d, const 
                       float* x, const int* done, hipStream_t s);
 
 enum GemvIn : int { GEMV_IN_LN = 0, GEMV_IN_F16 = 1, GEMV_IN_XATTN = 2 };
-enum GemvOut : int { GEMV_OUT_F16 = 0, GEMV_OUT_GELU_F16 = 1, GEMV_OUT_F32 = 2, GEMV_OUT_RESID = 3, GEMV_OUT_QKV = 4 };
+enum GemvOut : int { GEMV_OUT_F16 = 0, GEMV_OUT_GELU_F16 = 1, GEMV_OUT_F32 = 2, GEMV_OUT_RESID = 3, GEMV_OUT_QKV = 4,
+                     GEMV_OUT_SLAB = 5 };   // K-split partial sums, reduced by the CONSUMERS (xsrc = GEMV_X_SLABS)
+// where the fp32 rows of the residual stream come from (lean kernel; GEMV_IN_LN prologue and GEMV_OUT_RESID epilogue):
+//   PLAIN  the rows in X / Xres;
+//   SLABS  those rows + the WLX_FC2_KS partial-sum slabs the K-split MLP output projection of the previous layer left
+//          (nobody materialises the sum until the next residual update writes it back);
+//   EMBED  token embedding + position (layer 0: the separate embedding launch folded into the first projection's prologue).
+enum GemvXsrc : int { GEMV_X_PLAIN = 0, GEMV_X_SLABS = 1, GEMV_X_EMBED = 2 };
+#ifndef WLX_FC2_KS
+#define WLX_FC2_KS 2          // K slices of the lean MLP output projection (compile time: the consumers unroll over the slabs)
+#endif
 
 struct GemvParams {
     int in_mode, out_mode;
@@ -51,6 +61,13 @@ struct GemvParams {
     int d; float qscale; half_t* Kc; half_t* Vc; long cache_row_stride;
     const int* row_cache; const int* row_pos;
     const int* done;
+    // residual-stream source (GemvXsrc) of the LN prologue / RESID epilogue, and the K-split form (GEMV_OUT_SLAB)
+    int xsrc;
+    float* slab; long slab_stride;           // [WLX_FC2_KS][rows][ldslab = N of the producer] fp32 partial sums; floats between slabs
+    int KTS;                                 // (set by the launcher, GEMV_OUT_SLAB) k-tiles per K slice; grid.y = KT / KTS slices
+    // GEMV_X_EMBED: rows gathered from the tables; workgroup 0 also writes them to X (the later residual updates read them)
+    // and records the fed token (RowTables::intok)
+    const half_t* tok_emb; const float* pos_emb; const int* emb_token; int* intok;   // (position / cache row: row_pos / row_cache)
     WLX_TR_FIELD
 };
 #ifdef WLX_TRACE
@@ -73,6 +90,11 @@ void launch_dec_gemv(const GemvParams& p, hipStream_t s);
 const char* dec_gemv_kernel_name(const GemvParams& p);
 // WLX_DECODE_V1=1 selects the first-generation decode kernels (kept as the in-tree A/B reference)
 extern bool g_decode_v1;
+// true when launch_dec_gemv runs these parameters on the lean kernel (the only one that knows xsrc / GEMV_OUT_SLAB)
+bool dec_gemv_is_lean(const GemvParams& p);
+// K slices the lean kernel would cut an M x K -> N residual projection into (0: keep the single RESID launch).
+// WLX_FC2_KS=0 in the environment turns the split off (A/B).
+int dec_gemv_slab_split(int M, int K, int N);
 
 // causal self-attention over the KV cache, one wave per (row, head)
 void launch_dec_self_attn(const half_t* q, long ldq, const half_t* Kc, const half_t* Vc, long cache_row_stride,

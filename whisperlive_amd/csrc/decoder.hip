@@ -425,14 +425,28 @@ __device__ __forceinline__ void stage_rows_f16(const half_t* __restrict__ X, lon
 // reduction. Numerically exact (all parity tests green) and it cuts the weight-load instructions per CU from 96 to 24, but
 // every one of the 192 workgroups must stage the whole 5 x 3072 activation block: 5.5 us per launch vs 5.1.)
 
-template <int CH, int LNV, int IN, int OUT, int NTB, int MT>
-__global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
+// Round 2, second half — three changes that each remove latency the decode-step trace showed (profiles/r2e_*):
+//   * XS (GemvXsrc): the residual rows of the LayerNorm prologue / residual epilogue may be "rows + partial-sum slabs"
+//     (GEMV_OUT_SLAB below) or, for layer 0, gathered from the embedding tables (the embedding launch is gone);
+//   * GEMV_OUT_SLAB: the MLP output projection (K = 4 d_model: 96 KiB of weights and the whole 5 x 3072 activation block
+//     per 16-column workgroup, on 48 CUs — the slowest launch of a layer, 4.8 us) is cut into WLX_FC2_KS K slices, grid
+//     (tiles, slices); every slice workgroup writes its fp32 partial tile to its own slab and NOBODY reduces them in that
+//     launch: the next layer's first projection sums rows + slabs in its LayerNorm prologue, and the next residual update
+//     (the attention output projection) writes the sum back — a cross-workgroup reduction costs a launch boundary or a
+//     grid barrier (>= 3 us either way), the deferred one costs WLX_FC2_KS more 1 KiB loads per row;
+//   (Measured and dropped: LayerNorm helper waves beyond the nw MFMA waves, a wave per row — their dummy weight requests,
+//   needed to keep hipcc's wait counting uniform, delayed the real weight stream by 0.6 us per launch, profiles/r2f_*.)
+template <int CH, int LNV, int IN, int OUT, int NTB, int MT, int XS>
+__global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB) ? 512 : 1024) void dec_gemv2_kernel(GemvParams p) {
+    static_assert(XS == GEMV_X_PLAIN || (MT == 1 && (IN == GEMV_IN_LN || (IN == GEMV_IN_F16 && OUT == GEMV_OUT_RESID && NTB == 1))),
+                  "slab / embedding sources: single-row-tile LayerNorm prologue or residual epilogue only");
+    static_assert(OUT != GEMV_OUT_SLAB || (IN == GEMV_IN_F16 && MT == 1 && NTB == 1), "K-split form: fp16 rows in, one row tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    // nw = waves that stream weights and run MFMAs; the cross-attention combine brings extra waves that only help
-    // with the prologue (and load no weights: their wp is clamped to wave 0's slice, results unused)
-    const int nw = (IN == GEMV_IN_XATTN) ? p.nwm : (int)(blockDim.x >> 6);
+    // nw = waves that stream weights and run MFMAs; the LayerNorm prologue and the cross-attention combine may bring extra
+    // waves that only help with the prologue (and load no weights: their wp is clamped to wave 0's slice, results unused)
+    const int nw = p.nwm;
     WLX_TR_BEGIN();
     constexpr int NP = NTB * MT;                                           // (n-tile, 16-row tile) pairs of this workgroup
     float* accred = smem;                                                  // [nw][NP][64][4]
@@ -442,7 +456,10 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
     // the weight rows with the other lanes masked. It spreads N = 768 layers over 192 CUs but does not reduce the number
     // of load INSTRUCTIONS a CU issues, which is what bounds these launches (~11 ns per wave-level load): no gain.)
     const int tile = blockIdx.x;
-    const int kw0 = ((IN == GEMV_IN_XATTN && wave >= nw) ? 0 : wave) * p.KTW;   // first k-tile of this wave
+    const bool streams = (IN != GEMV_IN_XATTN) || wave < nw;               // this wave streams weights and runs MFMAs (helper waves: XATTN only)
+    const int kx0 = (streams ? wave : 0) * p.KTW;                          // first k-tile of this wave inside its K slice
+    const int ks0 = (OUT == GEMV_OUT_SLAB) ? (int)blockIdx.y * p.KTS : 0;  // first k-tile of this workgroup's K slice
+    const int kw0 = ks0 + kx0;                                             // ... of this wave, inside the weight matrix
     const half_t* wp = p.Wp + ((long)(tile * NTB) * p.KT + kw0) * 512 + lane * 8;
     const long wstep = (long)p.KT * 512;                                   // next n-tile
     f16x8 wf[CH][NTB];
@@ -457,7 +474,6 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
         // helper waves of the combine (wave >= nw, they leave before the MFMAs) issue the same NUMBER of loads, all of one
         // already-requested KiB: a branch around the loads would make hipcc count the waits that follow for the path
         // WITHOUT weights in flight, i.e. drain the weight stream inside the combine on the waves that do have it
-        const bool streams = (IN != GEMV_IN_XATTN) || wave < nw;
         const half_t* wq = streams ? wp : p.Wp + lane * 8;
         const long js = streams ? 512 : 0, is = streams ? wstep : 0;
 #pragma unroll
@@ -485,6 +501,13 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
     if constexpr (OUT != GEMV_OUT_F32) bias_e = *reinterpret_cast<const float4*>(p.bias + n_e);
     if constexpr (OUT == GEMV_OUT_RESID) res_e = *reinterpret_cast<const float4*>(p.Xres + (long)row_e * p.ldxres + n_e);
     if constexpr (OUT == GEMV_OUT_QKV) { rc_e = p.row_cache[row_e]; rp_e = p.row_pos[row_e]; }
+    float4 slab_e[(OUT == GEMV_OUT_RESID && XS == GEMV_X_SLABS) ? WLX_FC2_KS : 1];
+    if constexpr (OUT == GEMV_OUT_RESID && XS == GEMV_X_SLABS) {           // the residual is rows + slabs (summed at the store)
+#pragma unroll
+        for (int sl = 0; sl < WLX_FC2_KS; ++sl)
+            slab_e[sl] = *reinterpret_cast<const float4*>(p.slab + sl * p.slab_stride + (long)row_e * p.ldxres + n_e);
+    }
+    if constexpr (OUT == GEMV_OUT_SLAB) { if (blockIdx.y != 0) bias_e = make_float4(0.f, 0.f, 0.f, 0.f); }   // the bias once: slice 0
 
     f32x4 acc[NTB][MT];
 #pragma unroll
@@ -500,11 +523,12 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
             // One stream (M <= 16): the fp16 rows go through LDS — fetching B fragments straight from global costs CH
             // loads per wave of 64-byte pieces (16 waves x 6 = 96 load instructions per workgroup for K = 3072, as many
             // as the weights; a CU retires one per ~11 ns), the cooperative copy M * K / 8 / 64 = 30.
-            const int ldxs = p.K + 8;
-            stage_rows_f16(p.Xh, p.ldxh, p.M, p.K, xs, ldxs, [&]() { if (WLX_X_FIRST) load_weights(); });
+            const int Ks = (OUT == GEMV_OUT_SLAB) ? p.KTS * 32 : p.K;      // columns of the rows this workgroup multiplies
+            const int ldxs = Ks + 8;
+            stage_rows_f16(p.Xh + ks0 * 32, p.ldxh, p.M, Ks, xs, ldxs, [&]() { if (WLX_X_FIRST) load_weights(); });
             WLX_TR_MARK(1);
             __syncthreads();
-            xr[0] = xs + crow[0] * ldxs + kw0 * 32 + g * 8;                 // lanes of rows >= M re-read a valid row (never stored)
+            xr[0] = xs + crow[0] * ldxs + kx0 * 32 + g * 8;                 // lanes of rows >= M re-read a valid row (never stored)
             xstep = 32;
         } else {
             // batched rows, or K too large for the LDS budget (large-v3 fc2: 5 x 5120 fp16 + partials > 64 KiB):
@@ -539,6 +563,113 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) xf[j][mt] = xn[j][mt];
             }
+        }
+    } else if constexpr (IN == GEMV_IN_LN && XS != GEMV_X_PLAIN) {
+        // rows from slabs or the embedding tables: ONE row per wave in the first trip (its pieces are 3-5x the registers of a
+        // plain row, so no second row is prefetched; the host picks a K split with at least as many waves as rows, all of them
+        // streaming weights — helper waves with clamped dummy loads were measured 0.6 us SLOWER per launch, profiles/r2f_*).
+        // wave w normalises rows w, w + nw, ...; a row = LNV float4 per lane (d_model = 256 LNV).
+        const int nwl = nw;
+        constexpr int NSL = (XS == GEMV_X_SLABS) ? WLX_FC2_KS : 1;
+        float4 x[LNV], sl[NSL][LNV];
+        f16x4 te[LNV];
+        int tok0 = 0, pos0 = 0;
+        // request the pieces of row r (wave-uniform, clamped by the caller): rows, + slabs, or embedding + position
+        auto request_row = [&](int r, float4 (&x)[LNV], float4 (&sl)[NSL][LNV], f16x4 (&te)[LNV], int& tok, int& pos) {
+            if constexpr (XS == GEMV_X_EMBED) {
+                tok = p.emb_token[r];
+                // (position and cache row in one word: both are scalar loads here — a vector load inside the lane-0 store
+                // branch below would make hipcc drain the whole weight stream in front of it)
+                pos = p.row_pos[r] | (p.row_cache[r] << 16);               // position < 448, cache row < 64
+                const half_t* tp = p.tok_emb + (long)tok * p.K + lane * 4;
+                const float4* pp = reinterpret_cast<const float4*>(p.pos_emb + (long)(pos & 0xffff) * p.K) + lane;
+#pragma unroll
+                for (int j = 0; j < LNV; ++j) { te[j] = ld_f16x4(tp + 256 * j); x[j] = pp[64 * j]; }
+            } else {
+                const float4* x4 = reinterpret_cast<const float4*>(p.X + (long)r * p.ldx) + lane;
+#pragma unroll
+                for (int j = 0; j < LNV; ++j) x[j] = x4[64 * j];
+                if constexpr (XS == GEMV_X_SLABS) {
+#pragma unroll
+                    for (int q = 0; q < NSL; ++q) {
+                        const float4* s4 = reinterpret_cast<const float4*>(p.slab + q * p.slab_stride + (long)r * p.ldx) + lane;
+#pragma unroll
+                        for (int j = 0; j < LNV; ++j) sl[q][j] = s4[64 * j];
+                    }
+                }
+            }
+        };
+        // the row itself from its pieces (same association as the residual epilogue: ((x + s0) + s1) ...)
+        auto combine_row = [&](int r, bool keep, float4 (&x)[LNV], const float4 (&sl)[NSL][LNV], const f16x4 (&te)[LNV], int tok, int pos) {
+            if constexpr (XS == GEMV_X_SLABS) {
+#pragma unroll
+                for (int q = 0; q < NSL; ++q)
+#pragma unroll
+                    for (int j = 0; j < LNV; ++j) { x[j].x += sl[q][j].x; x[j].y += sl[q][j].y; x[j].z += sl[q][j].z; x[j].w += sl[q][j].w; }
+            }
+            if constexpr (XS == GEMV_X_EMBED) {
+#pragma unroll
+                for (int j = 0; j < LNV; ++j) { x[j].x += (float)te[j][0]; x[j].y += (float)te[j][1]; x[j].z += (float)te[j][2]; x[j].w += (float)te[j][3]; }
+                if (blockIdx.x == 0 && keep) {      // workgroup 0 leaves the rows where the residual updates expect them
+                    float4* o4 = reinterpret_cast<float4*>(p.Xres + (long)r * p.ldxres) + lane;
+#pragma unroll
+                    for (int j = 0; j < LNV; ++j) o4[64 * j] = x[j];
+                    if (lane == 0) p.intok[(long)(pos >> 16) * WLX_T_TEXT + (pos & 0xffff)] = tok;
+                }
+            }
+        };
+        const int ra = (wave < p.M) ? wave : p.M - 1;
+        request_row(ra, x, sl, te, tok0, pos0);
+        const float4* g4 = reinterpret_cast<const float4*>(p.gamma) + lane;
+        const float4* b4 = reinterpret_cast<const float4*>(p.beta) + lane;
+        float4 gq[LNV], bq[LNV];
+#pragma unroll
+        for (int j = 0; j < LNV; ++j) { gq[j] = g4[64 * j]; bq[j] = b4[64 * j]; }
+        if (WLX_X_FIRST) load_weights();
+        const int ldxs = p.K + 8;
+        constexpr float invK = 1.0f / (256.0f * LNV);
+        auto ln_row = [&](float4 (&x)[LNV], int r, bool keep) {
+            float sm = 0.f;
+#pragma unroll
+            for (int j = 0; j < LNV; ++j) sm += (x[j].x + x[j].y) + (x[j].z + x[j].w);
+            const float mean = wave_sum_dpp(sm) * invK;
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < LNV; ++j) {
+                x[j].x -= mean; x[j].y -= mean; x[j].z -= mean; x[j].w -= mean;
+                q += (x[j].x * x[j].x + x[j].y * x[j].y) + (x[j].z * x[j].z + x[j].w * x[j].w);
+            }
+            const float rstd = rsqrtf(wave_sum_dpp(q) * invK + 1e-5f);
+            half_t* dst = xs + (long)r * ldxs + lane * 4;
+#pragma unroll
+            for (int j = 0; j < LNV; ++j) {
+                const f16x4 hv = {(half_t)(x[j].x * rstd * gq[j].x + bq[j].x), (half_t)(x[j].y * rstd * gq[j].y + bq[j].y),
+                                  (half_t)(x[j].z * rstd * gq[j].z + bq[j].z), (half_t)(x[j].w * rstd * gq[j].w + bq[j].w)};
+                if (keep) *reinterpret_cast<f16x4*>(dst + 256 * j) = hv;
+            }
+        };
+        // first trip: straight-line and UNCONDITIONAL (a wave without a row normalises the clamped row it loaded and keeps
+        // nothing): inside an `if (wave < M)` hipcc sinks the row loads into the branch, behind the weights. It must not
+        // share a loop with the later trips either: hipcc's wait insertion merges the two ways into a loop body by the
+        // NEWEST request of either, so the first trip would wait for the weight stream it is meant to overlap.
+        combine_row(ra, wave < p.M, x, sl, te, tok0, pos0);
+        ln_row(x, ra, wave < p.M);
+#pragma unroll 1
+        for (int r = wave + nwl; r < p.M; r += nwl) {                       // more rows than waves (batched streams)
+            float4 x2[LNV], sl2[NSL][LNV];
+            f16x4 te2[LNV];
+            int tok2 = 0, pos2 = 0;
+            request_row(r, x2, sl2, te2, tok2, pos2);
+            combine_row(r, true, x2, sl2, te2, tok2, pos2);
+            ln_row(x2, r, true);
+        }
+        WLX_TR_MARK(1);
+        __syncthreads();
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const half_t* xr = xs + crow[mt] * ldxs + kx0 * 32 + g * 8;     // lanes of rows >= M re-read a valid row (never stored)
+#pragma unroll
+            for (int j = 0; j < CH; ++j) xf[j][mt] = *reinterpret_cast<const f16x8*>(xr + j * 32);
         }
     } else if constexpr (IN == GEMV_IN_LN) {
         // wave w normalises rows w, w + nw, ...; a row = LNV float4 per lane (d_model = 256 LNV)
@@ -616,7 +747,7 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
         __syncthreads();
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const half_t* xr = xs + crow[mt] * ldxs + kw0 * 32 + g * 8;     // lanes of rows >= M re-read a valid row (never stored)
+            const half_t* xr = xs + crow[mt] * ldxs + kx0 * 32 + g * 8;     // lanes of rows >= M re-read a valid row (never stored)
 #pragma unroll
             for (int j = 0; j < CH; ++j) xf[j][mt] = *reinterpret_cast<const f16x8*>(xr + j * 32);
         }
@@ -670,10 +801,10 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
         for (int it0 = tid + blockDim.x; it0 < n_it; it0 += blockDim.x) combine(it0, false);
         WLX_TR_MARK(1);
         __syncthreads();
-        if (wave >= nw) return;                                             // helper waves are done (no later barrier needs them: ended waves leave the barrier count)
+        if (!streams) return;                                               // helper waves are done (no later barrier needs them: ended waves leave the barrier count)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
-            const half_t* xr = xs + crow[mt] * ldxs + kw0 * 32 + g * 8;
+            const half_t* xr = xs + crow[mt] * ldxs + kx0 * 32 + g * 8;
 #pragma unroll
             for (int j = 0; j < CH; ++j) xf[j][mt] = *reinterpret_cast<const f16x8*>(xr + j * 32);
         }
@@ -731,8 +862,14 @@ __global__ __launch_bounds__(1024) void dec_gemv2_kernel(GemvParams p) {
             if (n_e + 3 < p.N) *reinterpret_cast<float4*>(yp) = make_float4(o0, o1, o2, o3);
             else { if (n_e < p.N) yp[0] = o0; if (n_e + 1 < p.N) yp[1] = o1; if (n_e + 2 < p.N) yp[2] = o2; }
         } else if constexpr (OUT == GEMV_OUT_RESID) {
+            if constexpr (XS == GEMV_X_SLABS) {                             // rows + slabs (the LayerNorm prologue's association)
+#pragma unroll
+                for (int sl = 0; sl < WLX_FC2_KS; ++sl) { res_e.x += slab_e[sl].x; res_e.y += slab_e[sl].y; res_e.z += slab_e[sl].z; res_e.w += slab_e[sl].w; }
+            }
             *reinterpret_cast<float4*>(p.Xres + (long)c * p.ldxres + n_e) =
                 make_float4(res_e.x + o0, res_e.y + o1, res_e.z + o2, res_e.w + o3);
+        } else if constexpr (OUT == GEMV_OUT_SLAB) {                        // this K slice's partial tile; summed by the consumers
+            *reinterpret_cast<float4*>(p.slab + blockIdx.y * p.slab_stride + (long)c * p.ldxres + n_e) = make_float4(o0, o1, o2, o3);
         } else {   // GEMV_OUT_QKV: the 16-column tile lies entirely in q, k or v (d % 16 == 0)
             if (n_e < p.d) {
                 const f16x4 h = {(half_t)(o0 * p.qscale), (half_t)(o1 * p.qscale), (half_t)(o2 * p.qscale), (half_t)(o3 * p.qscale)};
@@ -758,15 +895,37 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     if (p.bias ? (p.N & 15) != 0 : p.out_mode != GEMV_OUT_F32) return c;      // bias <=> not the vocabulary projection
     const bool combo = (p.in_mode == GEMV_IN_LN && (p.out_mode == GEMV_OUT_QKV || p.out_mode == GEMV_OUT_F16 ||
                                                     p.out_mode == GEMV_OUT_GELU_F16 || p.out_mode == GEMV_OUT_F32)) ||
-                       (p.in_mode != GEMV_IN_LN && p.out_mode == GEMV_OUT_RESID);
+                       (p.in_mode != GEMV_IN_LN && p.out_mode == GEMV_OUT_RESID) ||
+                       (p.in_mode == GEMV_IN_F16 && p.out_mode == GEMV_OUT_SLAB);
     if (!combo || p.K != p.KT * 32) return c;
+    // sources other than the plain rows: one row tile, and only where the kernel is instantiated for them
+    if (p.xsrc != GEMV_X_PLAIN) {
+        const bool ln_ok = p.in_mode == GEMV_IN_LN && p.out_mode == GEMV_OUT_QKV;
+        const bool res_ok = p.in_mode == GEMV_IN_F16 && p.out_mode == GEMV_OUT_RESID && p.xsrc == GEMV_X_SLABS;
+        if (p.M > 16 || !(ln_ok || res_ok)) return c;
+    }
+    int KTf = p.KT;                                                           // k-tiles one workgroup multiplies
+    if (p.out_mode == GEMV_OUT_SLAB) {
+        if (p.M > 16 || p.KTS < 1 || p.KT % p.KTS || p.KT / p.KTS != WLX_FC2_KS) return c;
+        KTf = p.KTS;
+    }
     static const int f16cap = [] { const char* e = getenv("WLX_GEMV_F16_NW"); return e ? atoi(e) : 16; }();
-    const int cap = (p.in_mode == GEMV_IN_F16) ? f16cap : 8;
-    // exact factorisation KT = nw * CH * NCH, CH in {6, 5, 4}: fewest chunks first, then the widest chunk
+    const int cap = (p.in_mode == GEMV_IN_F16 && p.out_mode != GEMV_OUT_SLAB) ? f16cap : 8;
+    // exact factorisation KTf = nw * CH * NCH, CH in {6, 5, 4}: fewest chunks first, then the widest chunk
     int best_nch = 1 << 30;
+    if (p.in_mode == GEMV_IN_LN && p.xsrc != GEMV_X_PLAIN) {
+        // slab / embedding rows: one row per wave, so at least min(M, 8) waves, each streaming CH >= 2 k-tiles
+        static const int want_env = [] { const char* e = getenv("WLX_XS_WAVES"); return e ? atoi(e) : 0; }();   // (A/B: 8 = CH 3 on d_model 768)
+        const int want = std::max(std::min(p.M, 8), std::min(want_env, 8));
+        for (int CH = 6; CH >= 2; --CH) {
+            if (KTf % CH || KTf / CH > 8 || KTf / CH < want) continue;
+            best_nch = 1; c.nw = KTf / CH; c.CH = CH; c.NCH = 1;
+            break;
+        }
+    } else
     for (int CH = 6; CH >= 4; --CH) {
-        if (p.KT % CH) continue;
-        const int q = p.KT / CH;                    // = nw * NCH
+        if (KTf % CH) continue;
+        const int q = KTf / CH;                     // = nw * NCH
         for (int nw = std::min(cap, q); nw >= 1; --nw) {
             if (q % nw) continue;
             const int nch = q / nw;
@@ -784,7 +943,7 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     c.NTB = (p.out_mode == GEMV_OUT_F32 && p.N > 8192) ? 2 : 1;
     c.MT = (p.M + 15) / 16;
     c.shm = sizeof(float) * (size_t)c.nw * c.NTB * c.MT * 256;
-    const size_t xs_bytes = (size_t)p.M * (p.K + 8) * sizeof(half_t);  // fp16 activation rows
+    const size_t xs_bytes = (size_t)p.M * (KTf * 32 + 8) * sizeof(half_t);    // fp16 activation rows
     c.xstage = true;
     if (p.in_mode == GEMV_IN_F16 && (c.MT > 1 || c.shm + xs_bytes > 64 * 1024)) c.xstage = false;   // fragments from global instead
     if (c.xstage) c.shm += xs_bytes;
@@ -795,40 +954,61 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
 
 template <int CH, int LNV, int MT>
 static bool gemv2_launch_ln(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, dim3 block, hipStream_t s) {
+#define WLX_G2(OUT_, NTB_, XS_) hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, OUT_, NTB_, MT, XS_>), grid, block, c.shm, s, p)
     switch (p.out_mode) {
-        case GEMV_OUT_QKV: hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, GEMV_OUT_QKV, 1, MT>), grid, block, c.shm, s, p); return true;
-        case GEMV_OUT_F16: hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, GEMV_OUT_F16, 1, MT>), grid, block, c.shm, s, p); return true;
-        case GEMV_OUT_GELU_F16: hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, GEMV_OUT_GELU_F16, 1, MT>), grid, block, c.shm, s, p); return true;
+        case GEMV_OUT_QKV: WLX_G2(GEMV_OUT_QKV, 1, GEMV_X_PLAIN); return true;
+        case GEMV_OUT_F16: WLX_G2(GEMV_OUT_F16, 1, GEMV_X_PLAIN); return true;
+        case GEMV_OUT_GELU_F16: WLX_G2(GEMV_OUT_GELU_F16, 1, GEMV_X_PLAIN); return true;
         case GEMV_OUT_F32:
-            if (c.NTB == 2) hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, GEMV_OUT_F32, 2, MT>), grid, block, c.shm, s, p);
-            else hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, GEMV_OUT_F32, 1, MT>), grid, block, c.shm, s, p);
+            if (c.NTB == 2) WLX_G2(GEMV_OUT_F32, 2, GEMV_X_PLAIN);
+            else WLX_G2(GEMV_OUT_F32, 1, GEMV_X_PLAIN);
             return true;
         default: return false;
     }
+#undef WLX_G2
+}
+// the first projection of a layer reading slab / embedding rows (one row tile): its own (CH, LNV) pairs, see gemv2_cfg
+template <int CH, int LNV>
+static bool gemv2_launch_qkv_xs(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, dim3 block, hipStream_t s) {
+    if (p.xsrc == GEMV_X_SLABS) hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, GEMV_OUT_QKV, 1, 1, GEMV_X_SLABS>), grid, block, c.shm, s, p);
+    else hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, GEMV_OUT_QKV, 1, 1, GEMV_X_EMBED>), grid, block, c.shm, s, p);
+    return true;
 }
 template <int CH, int MT>
 static bool gemv2_launch_other(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, dim3 block, hipStream_t s) {
-    if (p.in_mode == GEMV_IN_F16) hipLaunchKernelGGL((dec_gemv2_kernel<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, MT>), grid, block, c.shm, s, p);
-    else hipLaunchKernelGGL((dec_gemv2_kernel<CH, 1, GEMV_IN_XATTN, GEMV_OUT_RESID, 1, MT>), grid, block, c.shm, s, p);
+    if (p.in_mode == GEMV_IN_F16) {
+        if constexpr (MT == 1) {
+            if (p.out_mode == GEMV_OUT_SLAB) { hipLaunchKernelGGL((dec_gemv2_kernel<CH, 1, GEMV_IN_F16, GEMV_OUT_SLAB, 1, 1, GEMV_X_PLAIN>), grid, block, c.shm, s, p); return true; }
+            if (p.xsrc == GEMV_X_SLABS) { hipLaunchKernelGGL((dec_gemv2_kernel<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, 1, GEMV_X_SLABS>), grid, block, c.shm, s, p); return true; }
+        }
+        hipLaunchKernelGGL((dec_gemv2_kernel<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, MT, GEMV_X_PLAIN>), grid, block, c.shm, s, p);
+    } else hipLaunchKernelGGL((dec_gemv2_kernel<CH, 1, GEMV_IN_XATTN, GEMV_OUT_RESID, 1, MT, GEMV_X_PLAIN>), grid, block, c.shm, s, p);
     return true;
 }
 // the (CH, LNV) pairs of the Whisper family: d_model 512 (4,2), 768 (6,3), 1024 (4,4), 1280 (5,5)
 static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s) {
     GemvParams p = p0;
-    p.KTW = c.CH * c.NCH; p.NCH = c.NCH; p.xstage = c.xstage ? 1 : 0;
+    p.KTW = c.CH * c.NCH; p.NCH = c.NCH; p.xstage = c.xstage ? 1 : 0; p.nwm = c.nw;
 #ifdef WLX_TRACE
     { static thread_local char nm[512][48]; const int q = g_trace_seq < 512 ? g_trace_seq : 511;
-      snprintf(nm[q], 48, "gemv2<%d,%d> N%d K%d", p.in_mode, p.out_mode, p.N, p.K); p.trc = trace_next(nm[q]); }
+      snprintf(nm[q], 48, "gemv2<%d,%d,%d> N%d K%d", p.in_mode, p.out_mode, p.xsrc, p.N, p.K); p.trc = trace_next(nm[q]); }
 #endif
     const int NT_total = (p.N + 15) / 16;
-    dim3 grid((NT_total + c.NTB - 1) / c.NTB), block(c.nw * 64);
+    dim3 grid((NT_total + c.NTB - 1) / c.NTB, p.out_mode == GEMV_OUT_SLAB ? p.KT / p.KTS : 1), block(c.nw * 64);
     if (p.in_mode == GEMV_IN_XATTN) {      // helper waves for the combine: one thread per (row, head, 4-float group), <= 1024
-        p.nwm = c.nw;
         const int want = (p.M * p.H * 8 + 63) / 64;
         block.x = 64 * std::max(c.nw, std::min(16, want));
     }
 #define WLX_G2_LN(CH_, LNV_) (c.MT == 1 ? gemv2_launch_ln<CH_, LNV_, 1>(p, c, grid, block, s) : gemv2_launch_ln<CH_, LNV_, 2>(p, c, grid, block, s))
 #define WLX_G2_OT(CH_) (c.MT == 1 ? gemv2_launch_other<CH_, 1>(p, c, grid, block, s) : gemv2_launch_other<CH_, 2>(p, c, grid, block, s))
+    if (p.in_mode == GEMV_IN_LN && p.xsrc != GEMV_X_PLAIN) {
+        if (c.CH == 4 && c.LNV == 3) return gemv2_launch_qkv_xs<4, 3>(p, c, grid, block, s);
+        if (c.CH == 3 && c.LNV == 3) return gemv2_launch_qkv_xs<3, 3>(p, c, grid, block, s);
+        if (c.CH == 2 && c.LNV == 2) return gemv2_launch_qkv_xs<2, 2>(p, c, grid, block, s);
+        if (c.CH == 4 && c.LNV == 4) return gemv2_launch_qkv_xs<4, 4>(p, c, grid, block, s);
+        if (c.CH == 5 && c.LNV == 5) return gemv2_launch_qkv_xs<5, 5>(p, c, grid, block, s);
+        return false;
+    }
     if (p.in_mode == GEMV_IN_LN) {
         if (c.CH == 6 && c.LNV == 3) return WLX_G2_LN(6, 3);
         if (c.CH == 5 && c.LNV == 5) return WLX_G2_LN(5, 5);
@@ -847,12 +1027,29 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
 static bool gemv2_ok(const GemvParams& p, Gemv2Cfg* out) {
     const Gemv2Cfg c = gemv2_cfg(p);
     if (!c.ok) return false;
-    if (p.in_mode == GEMV_IN_LN) {
+    if (p.in_mode == GEMV_IN_LN && p.xsrc != GEMV_X_PLAIN) {
+        const bool pair = (c.CH == 4 && c.LNV == 3) || (c.CH == 3 && c.LNV == 3) || (c.CH == 2 && c.LNV == 2) || (c.CH == 4 && c.LNV == 4) || (c.CH == 5 && c.LNV == 5);
+        if (!pair) return false;
+    } else if (p.in_mode == GEMV_IN_LN) {
         const bool pair = (c.CH == 6 && c.LNV == 3) || (c.CH == 5 && c.LNV == 5) || (c.CH == 4 && c.LNV == 2) || (c.CH == 4 && c.LNV == 4);
         if (!pair) return false;
     }
     if (out) *out = c;
     return true;
+}
+bool dec_gemv_is_lean(const GemvParams& p) { return gemv2_ok(p, nullptr); }
+
+int dec_gemv_slab_split(int M, int K, int N) {
+    static const int ks_env = [] { const char* e = getenv("WLX_FC2_KS"); return e ? atoi(e) : WLX_FC2_KS; }();
+    if (ks_env != WLX_FC2_KS || WLX_FC2_KS < 2) return 0;                     // (the slab count is a compile-time constant of the consumers)
+    if (g_decode_v1 || M < 1 || M > 16 || K % 32 || (K / 32) % WLX_FC2_KS || K < 2048) return 0;
+    GemvParams p{};
+    p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_SLAB; p.M = M; p.K = K; p.KT = K / 32; p.N = N; p.KTS = p.KT / WLX_FC2_KS;
+    static const float dummy_bias = 0.f;
+    p.bias = &dummy_bias;                                                     // (cfg only asks whether there is one)
+    Gemv2Cfg c;
+    if (!gemv2_ok(p, &c) || !c.xstage) return 0;
+    return WLX_FC2_KS;
 }
 
 const char* dec_gemv_kernel_name(const GemvParams& p) {
@@ -860,7 +1057,7 @@ const char* dec_gemv_kernel_name(const GemvParams& p) {
     const int MT = (p.M + 15) / 16;
     Gemv2Cfg c2;
     if (gemv2_ok(p, &c2)) {
-        snprintf(buf, sizeof(buf), "dec_gemv2_kernel<%d, %d, %d, %d, %d, %d>", c2.CH, c2.LNV ? c2.LNV : 1, p.in_mode, p.out_mode, c2.NTB, c2.MT);
+        snprintf(buf, sizeof(buf), "dec_gemv2_kernel<%d, %d, %d, %d, %d, %d, %d>", c2.CH, c2.LNV ? c2.LNV : 1, p.in_mode, p.out_mode, c2.NTB, c2.MT, p.xsrc);
         return buf;
     }
     snprintf(buf, sizeof(buf), "dec_gemv_kernel<%d, %d, %d>", MT > 4 ? 4 : MT, MT == 1 ? 2 : 1, p.in_mode);

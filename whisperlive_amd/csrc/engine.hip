@@ -489,6 +489,7 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         CKR(dalloc(s->allocs, &s->qd, (size_t)RC * d));
         CKR(dalloc(s->allocs, &s->attnd, (size_t)RC * d));
         CKR(dalloc(s->allocs, &s->hd, (size_t)RC * F));
+        CKR(dalloc(s->allocs, &s->slab, (size_t)WLX_FC2_KS * 16 * d));
         CKR(dalloc(s->allocs, &s->part_o, (size_t)s->groups_cap * e->H * WLX_XSPLIT * 16 * 64));
         CKR(dalloc(s->allocs, &s->part_ml, (size_t)s->groups_cap * e->H * WLX_XSPLIT * 16 * 2));
         s->ldl = ((sp.vocab + 15) / 16) * 16;
@@ -776,24 +777,59 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
     // kernels do not test the flag: the test was a dependent scalar load at the head of ~100 launches per step.
     const int* done = (check_done && g_decode_v1) ? s->st.done : nullptr;
     RowTables rt{s->d_token, s->d_pos, s->d_cache, s->d_ancrow, s->d_anc, s->d_intok};
-    plaunch(s, "dec_embed_kernel", (double)rows * d * (2 + 4), [&] { launch_dec_embed(e->tok_emb16, e->dec_pos, d, rt, rows, s->xd, done, st); });
     const long crs = (long)WLX_T_TEXT * d;
+    // ---- the parameter sets of one layer (the first projection's residual source is filled in below)
+    auto qkv_params = [&](int l, int xsrc) {
+        const DecLayerW& w = e->dec[l];
+        GemvParams p{};
+        p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_QKV; p.M = rows; p.K = d; p.KT = d / 32; p.N = 3 * d;
+        p.Wp = w.Wqkv; p.bias = w.bqkv; p.X = s->xd; p.ldx = d; p.gamma = w.ln1_g; p.beta = w.ln1_b;
+        p.Yh = s->qd; p.ldyh = d; p.d = d; p.qscale = 0.125f;
+        p.Kc = s->kc + (size_t)l * s->cache_rows * crs; p.Vc = s->vc + (size_t)l * s->cache_rows * crs; p.cache_row_stride = crs;
+        p.row_cache = s->d_cache; p.row_pos = s->d_pos; p.done = done;
+        p.xsrc = xsrc; p.slab = s->slab; p.slab_stride = (long)16 * d;
+        if (xsrc == GEMV_X_EMBED) {
+            p.tok_emb = e->tok_emb16; p.pos_emb = e->dec_pos; p.emb_token = s->d_token; p.intok = s->d_intok;
+            p.Xres = s->xd; p.ldxres = d;
+        }
+        return p;
+    };
+    auto oproj_params = [&](int l, int xsrc) {
+        const DecLayerW& w = e->dec[l];
+        GemvParams p{};
+        p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
+        p.Wp = w.Wo; p.bias = w.bo; p.Xh = s->attnd; p.ldxh = d; p.Xres = s->xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
+        p.xsrc = xsrc; p.slab = s->slab; p.slab_stride = (long)16 * d;
+        return p;
+    };
+    auto vocab_params = [&](int xsrc) {
+        GemvParams p{};
+        p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_F32; p.M = rows; p.K = d; p.KT = d / 32; p.N = sp.vocab;
+        p.Wp = e->Wvocab; p.bias = nullptr; p.X = s->xd; p.ldx = d; p.gamma = e->dec_ln_g; p.beta = e->dec_ln_b;
+        p.Y = s->logits; p.ldy = s->ldl; p.qscale = 1.f; p.done = done;
+        p.xsrc = xsrc; p.slab = s->slab; p.slab_stride = (long)16 * d;
+        return p;
+    };
+    // ---- what this pass may use (decided once, from the shapes only — never from what a profiling filter lets through):
+    // the K-split MLP output projection needs every consumer of its slabs on the lean kernel; the embedding folds into
+    // layer 0's first projection under the same condition. WLX_NO_EMBED_FOLD=1 keeps the embedding launch (A/B).
+    static const bool no_fold = [] { const char* v = getenv("WLX_NO_EMBED_FOLD"); return v && v[0] == '1'; }();
+    int KS = dec_gemv_slab_split(rows, F, d);
+    if (KS && !(dec_gemv_is_lean(qkv_params(0, GEMV_X_SLABS)) && dec_gemv_is_lean(oproj_params(0, GEMV_X_SLABS)))) KS = 0;
+    const bool fold_embed = !no_fold && rows <= 16 && dec_gemv_is_lean(qkv_params(0, GEMV_X_EMBED));
+    if (!fold_embed)
+        plaunch(s, "dec_embed_kernel", (double)rows * d * (2 + 4), [&] { launch_dec_embed(e->tok_emb16, e->dec_pos, d, rt, rows, s->xd, done, st); });
+    bool slabs_pending = false;             // the residual stream is xd + slabs until the next residual update writes the sum back
     for (int l = 0; l < sp.dec_layers; ++l) {
         const DecLayerW& w = e->dec[l];
         half_t* kc = s->kc + (size_t)l * s->cache_rows * crs;
         half_t* vc = s->vc + (size_t)l * s->cache_rows * crs;
-        GemvParams p{};
         // LN1 + QKV, K/V appended to the self-attention cache
-        p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_QKV; p.M = rows; p.K = d; p.KT = d / 32; p.N = 3 * d;
-        p.Wp = w.Wqkv; p.bias = w.bqkv; p.X = s->xd; p.ldx = d; p.gamma = w.ln1_g; p.beta = w.ln1_b;
-        p.Yh = s->qd; p.ldyh = d; p.d = d; p.qscale = 0.125f; p.Kc = kc; p.Vc = vc; p.cache_row_stride = crs;
-        p.row_cache = s->d_cache; p.row_pos = s->d_pos; p.done = done;
-        pgemv(s, p);
+        pgemv(s, qkv_params(l, (l == 0 && fold_embed) ? GEMV_X_EMBED : (slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN)));
         plaunch(s, "dec_self_attn2_kernel", 4.0 * rows * d * (s->prof ? s->prof->t + 1 : 1), [&] { launch_dec_self_attn(s->qd, d, kc, vc, crs, d, H, rt, rows, s->attnd, d, done, st); });
-        p = GemvParams{};
-        p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
-        p.Wp = w.Wo; p.bias = w.bo; p.Xh = s->attnd; p.ldxh = d; p.Xres = s->xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
-        pgemv(s, p);
+        pgemv(s, oproj_params(l, slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN));
+        slabs_pending = false;
+        GemvParams p{};
         // LN2 + cross-attention query + cross-attention partials: one fused launch when the shape allows and nobody needs
         // the query rows (word alignment captures them), else projection and attention separately
         const half_t* ckl = s->ck + (size_t)l * s->B * WLX_T_AUDIO_PAD * d;
@@ -835,15 +871,15 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
         p = GemvParams{};
         p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = F; p.KT = F / 32; p.N = d;
         p.Wp = w.W2; p.bias = w.b2; p.Xh = s->hd; p.ldxh = F; p.Xres = s->xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
+        // the last layer keeps the single launch: its consumer would be the vocabulary projection, thousands of workgroups
+        // that would each sum the slabs (measured: +2.2 us there against 1.2 us saved here, profiles/r2f_*)
+        if (KS && l + 1 < sp.dec_layers) {
+            p.out_mode = GEMV_OUT_SLAB; p.KTS = p.KT / KS; p.slab = s->slab; p.slab_stride = (long)16 * d;
+            slabs_pending = true;
+        }
         pgemv(s, p);
     }
-    if (with_logits) {
-        GemvParams p{};
-        p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_F32; p.M = rows; p.K = d; p.KT = d / 32; p.N = sp.vocab;
-        p.Wp = e->Wvocab; p.bias = nullptr; p.X = s->xd; p.ldx = d; p.gamma = e->dec_ln_g; p.beta = e->dec_ln_b;
-        p.Y = s->logits; p.ldy = s->ldl; p.qscale = 1.f; p.done = done;
-        pgemv(s, p);
-    }
+    if (with_logits) pgemv(s, vocab_params(GEMV_X_PLAIN));
 }
 
 // upload row tables for a pass: token/pos/cache/ancrow [rows], group_item [groups]
