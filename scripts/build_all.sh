@@ -1,0 +1,12 @@
+#!/bin/bash
+# Build libwlx.so + libwlx_trace.so (+ named A/B variants) and FAIL LOUDLY: a GPU call after a failed build would measure the old library.
+set -e
+python - "$@" <<'PY'
+import sys
+from whisperlive_amd import _lib
+_lib.build(force=True); _lib.build_trace()
+for v in sys.argv[1:]:
+    name, *defs = v.split(":")
+    _lib.build_variant(name, defs)
+print("build ok")
+PY

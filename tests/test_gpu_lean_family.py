@@ -57,9 +57,10 @@ def test_encoder_parity(fam):
     _check(slot.encoder_output(0), enc[0].numpy(), f"{name} encoder")
 
 
-@pytest.mark.parametrize("n_tok", [1, 5, 16, 20, 32])
-def test_decoder_logits_rows_1_to_32(fam, n_tok):
-    """teacher-forced rows in ONE pass: 1..16 rows = one MFMA row tile, 17..32 = two (batched streams)."""
+@pytest.mark.parametrize("n_tok", [1, 5, 16, 20, 32, 40, 48])
+def test_decoder_logits_rows_1_to_48(fam, n_tok):
+    """teacher-forced rows in ONE pass: 1..16 rows = one MFMA row tile, 17..32 = two, 33..48 = three (batched streams;
+    at d_model 1280 the staged rows exceed the default 64 KiB of dynamic LDS: the raised-limit path)."""
     name, spec, eng, oracle, slot, enc = fam
     toks = np.random.default_rng(n_tok).integers(0, spec.vocab, size=n_tok)
     got = slot.debug_decode_logits(toks)
@@ -100,6 +101,28 @@ def test_five_items_batched_equal_singles(fam):
         sb.encode(5, seek=[0] * 5, seg=[t - 1 for t in Ts])
         res = sb.generate([[ids.sot]] * 5, H.engine_ids(ids), **kw)
         for i in range(5):
+            assert res[i].sequences_ids == singles[i].sequences_ids, (name, i)
+            assert abs(res[i].scores[0] - singles[i].scores[0]) < 1e-3
+    finally:
+        sb.close()
+
+
+def test_eight_items_batched_equal_singles(fam):
+    """40 beam rows in one decode (three row tiles: the batch worker's default of 8 clips) == each clip decoded alone."""
+    name, spec, eng, oracle, slot, enc = fam
+    ids = H.token_ids_for(spec.vocab)
+    kw = dict(beam_size=5, max_length=1 + 8, suppress_tokens=H.default_suppress(ids))
+    clips = [olm.speech_like_pcm(2.0 + 0.5 * i, seed=80 + i) for i in range(8)]
+    singles = []
+    for c in clips:
+        T = slot.logmel(c); slot.encode(1, seek=[0], seg=[T - 1])
+        singles.append(slot.generate([[ids.sot]], H.engine_ids(ids), **kw)[0])
+    sb = eng.create_slot(8, 5)
+    try:
+        Ts = [sb.logmel(c, item=i) for i, c in enumerate(clips)]
+        sb.encode(8, seek=[0] * 8, seg=[t - 1 for t in Ts])
+        res = sb.generate([[ids.sot]] * 8, H.engine_ids(ids), **kw)
+        for i in range(8):
             assert res[i].sequences_ids == singles[i].sequences_ids, (name, i)
             assert abs(res[i].scores[0] - singles[i].scores[0]) < 1e-3
     finally:

@@ -303,8 +303,9 @@ def test_engine_slots_are_pooled_across_client_threads():
 
 
 def test_wide_batches_decode_in_lean_groups_over_the_same_encoder_output():
-    """8 items x 5 beams = 40 rows exceed what one launch of the lean decode kernels covers (32): the batch is decoded as
-    groups of 6 + 2 items over the SAME encoder output (item maps), one result per prompt, in order."""
+    """12 items x 5 beams = 60 rows exceed what one launch of the lean decode kernels covers (48 = three 16-row tiles): the
+    batch is decoded as groups of 9 + 3 items over the SAME encoder output (item maps), one result per prompt, in order;
+    the batch worker's default of 8 items (40 rows) is ONE decode."""
     eng = FakeEngine()
     tb = eng.spec.vocab - 1501
     seen = []
@@ -314,13 +315,13 @@ def test_wide_batches_decode_in_lean_groups_over_the_same_encoder_output():
         return [GenerationResult([[tb, 300 + i, tb + 50]], [-0.1], 0.01) for i in range(len(prompts))]
 
     eng.generate_script = [script, script]
-    m = WhisperModelHIP("fake", engine=eng, hf_tokenizer=synthetic_tokenizer(V), max_batch=8, vad_model=EnergyGateModel())
-    enc = m.encode(np.zeros((8, 80, 3000), np.float32))
+    m = WhisperModelHIP("fake", engine=eng, hf_tokenizer=synthetic_tokenizer(V), max_batch=12, vad_model=EnergyGateModel())
+    enc = m.encode(np.zeros((12, 80, 3000), np.float32))
     tk = Tokenizer(m.hf_tokenizer, False)
-    res = m.model.generate(enc, [[tk.sot]] * 8, beam_size=5)
-    assert seen == [(6, [0, 1, 2, 3, 4, 5]), (2, [6, 7])] and len(res) == 8
+    res = m.model.generate(enc, [[tk.sot]] * 12, beam_size=5)
+    assert seen == [(9, list(range(9))), (3, [9, 10, 11])] and len(res) == 12
     seen.clear()
     eng.generate_script = [script]
-    enc6 = m.encode(np.zeros((6, 80, 3000), np.float32))
-    m.model.generate(enc6, [[tk.sot]] * 6, beam_size=5)
-    assert seen == [(6, None)]                       # fits one launch: no item map needed
+    enc8 = m.encode(np.zeros((8, 80, 3000), np.float32))
+    m.model.generate(enc8, [[tk.sot]] * 8, beam_size=5)
+    assert seen == [(8, None)]                       # fits one launch: no item map needed

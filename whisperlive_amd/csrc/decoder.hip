@@ -474,7 +474,7 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB) ? 512 : 
         // helper waves of the combine (wave >= nw, they leave before the MFMAs) issue the same NUMBER of loads, all of one
         // already-requested KiB: a branch around the loads would make hipcc count the waits that follow for the path
         // WITHOUT weights in flight, i.e. drain the weight stream inside the combine on the waves that do have it
-        const half_t* wq = streams ? wp : p.Wp + lane * 8;
+        const half_t* wq = streams ? wp : p.Wp + ((long)(tile * NTB) * p.KT + ks0) * 512 + lane * 8;   // (helpers: this workgroup's own first KiB — one shared line for every workgroup's helpers was a hot spot in L2)
         const long js = streams ? 512 : 0, is = streams ? wstep : 0;
 #pragma unroll
         for (int j = 0; j < CH; ++j)
@@ -887,11 +887,28 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB) ? 512 : 
     WLX_TR_END_WAVES(p.trc);
 }
 
+// one launch of an instantiation; workgroups that need more than the default 64 KiB of dynamic LDS (batched rows of the
+// larger models: 30 rows x 1280 fp16 = 77 KiB of staged activations) raise the kernel's limit first, once. The first
+// launch of every shape happens OUTSIDE stream capture (engine.hip runs a decoder pass eagerly before it captures one).
+#define WLX_G2_LDS_MAX (152 * 1024)
+template <int CH, int LNV, int IN, int OUT, int NTB, int MT, int XS>
+static void g2_launch(dim3 grid, dim3 block, size_t shm, hipStream_t s, const GemvParams& p) {
+    if (shm > 64 * 1024) {
+        static size_t granted = 0;
+        if (shm > granted) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemv2_kernel<CH, LNV, IN, OUT, NTB, MT, XS>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, WLX_G2_LDS_MAX);
+            granted = WLX_G2_LDS_MAX;
+        }
+    }
+    hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, IN, OUT, NTB, MT, XS>), grid, block, shm, s, p);
+}
+
 struct Gemv2Cfg { bool ok, xstage; int nw, CH, NCH, LNV, NTB, MT; size_t shm; };
 static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     Gemv2Cfg c{};
     c.ok = false;
-    if (g_decode_v1 || p.M > 32 || p.M < 1) return c;
+    if (g_decode_v1 || p.M > 48 || p.M < 1) return c;
     if (p.bias ? (p.N & 15) != 0 : p.out_mode != GEMV_OUT_F32) return c;      // bias <=> not the vocabulary projection
     const bool combo = (p.in_mode == GEMV_IN_LN && (p.out_mode == GEMV_OUT_QKV || p.out_mode == GEMV_OUT_F16 ||
                                                     p.out_mode == GEMV_OUT_GELU_F16 || p.out_mode == GEMV_OUT_F32)) ||
@@ -910,6 +927,7 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
         KTf = p.KTS;
     }
     static const int f16cap = [] { const char* e = getenv("WLX_GEMV_F16_NW"); return e ? atoi(e) : 16; }();
+    static const bool xattn_nw8 = [] { const char* e = getenv("WLX_XATTN_NW8"); return e && e[0] == '1'; }();   // measured equal to 4 + helpers (profiles/r2h_*): off
     const int cap = (p.in_mode == GEMV_IN_F16 && p.out_mode != GEMV_OUT_SLAB) ? f16cap : 8;
     // exact factorisation KTf = nw * CH * NCH, CH in {6, 5, 4}: fewest chunks first, then the widest chunk
     int best_nch = 1 << 30;
@@ -922,6 +940,10 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
             best_nch = 1; c.nw = KTf / CH; c.CH = CH; c.NCH = 1;
             break;
         }
+    } else if (p.in_mode == GEMV_IN_XATTN && xattn_nw8 && p.M <= 16 && KTf % 8 == 0 && KTf / 8 >= 2 && KTf / 8 <= 6) {
+        // the split combine wants ~8 waves (M * H * 8 threads): let all of them stream weights (8 x KT/8 k-tiles) instead of
+        // 4 MFMA waves + helper waves with dummy requests
+        best_nch = 1; c.nw = 8; c.CH = KTf / 8; c.NCH = 1;
     } else
     for (int CH = 6; CH >= 4; --CH) {
         if (KTf % CH) continue;
@@ -947,14 +969,14 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     c.xstage = true;
     if (p.in_mode == GEMV_IN_F16 && (c.MT > 1 || c.shm + xs_bytes > 64 * 1024)) c.xstage = false;   // fragments from global instead
     if (c.xstage) c.shm += xs_bytes;
-    if (c.shm > 64 * 1024) return c;                                   // beyond the default dynamic-LDS limit: older kernel
+    if (c.shm > WLX_G2_LDS_MAX) return c;                              // beyond a CU's LDS (160 KiB, less a margin): older kernel
     c.ok = true;
     return c;
 }
 
 template <int CH, int LNV, int MT>
 static bool gemv2_launch_ln(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, dim3 block, hipStream_t s) {
-#define WLX_G2(OUT_, NTB_, XS_) hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, OUT_, NTB_, MT, XS_>), grid, block, c.shm, s, p)
+#define WLX_G2(OUT_, NTB_, XS_) g2_launch<CH, LNV, GEMV_IN_LN, OUT_, NTB_, MT, XS_>(grid, block, c.shm, s, p)
     switch (p.out_mode) {
         case GEMV_OUT_QKV: WLX_G2(GEMV_OUT_QKV, 1, GEMV_X_PLAIN); return true;
         case GEMV_OUT_F16: WLX_G2(GEMV_OUT_F16, 1, GEMV_X_PLAIN); return true;
@@ -970,19 +992,19 @@ static bool gemv2_launch_ln(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, d
 // the first projection of a layer reading slab / embedding rows (one row tile): its own (CH, LNV) pairs, see gemv2_cfg
 template <int CH, int LNV>
 static bool gemv2_launch_qkv_xs(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, dim3 block, hipStream_t s) {
-    if (p.xsrc == GEMV_X_SLABS) hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, GEMV_OUT_QKV, 1, 1, GEMV_X_SLABS>), grid, block, c.shm, s, p);
-    else hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, GEMV_IN_LN, GEMV_OUT_QKV, 1, 1, GEMV_X_EMBED>), grid, block, c.shm, s, p);
+    if (p.xsrc == GEMV_X_SLABS) g2_launch<CH, LNV, GEMV_IN_LN, GEMV_OUT_QKV, 1, 1, GEMV_X_SLABS>(grid, block, c.shm, s, p);
+    else g2_launch<CH, LNV, GEMV_IN_LN, GEMV_OUT_QKV, 1, 1, GEMV_X_EMBED>(grid, block, c.shm, s, p);
     return true;
 }
 template <int CH, int MT>
 static bool gemv2_launch_other(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, dim3 block, hipStream_t s) {
     if (p.in_mode == GEMV_IN_F16) {
         if constexpr (MT == 1) {
-            if (p.out_mode == GEMV_OUT_SLAB) { hipLaunchKernelGGL((dec_gemv2_kernel<CH, 1, GEMV_IN_F16, GEMV_OUT_SLAB, 1, 1, GEMV_X_PLAIN>), grid, block, c.shm, s, p); return true; }
-            if (p.xsrc == GEMV_X_SLABS) { hipLaunchKernelGGL((dec_gemv2_kernel<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, 1, GEMV_X_SLABS>), grid, block, c.shm, s, p); return true; }
+            if (p.out_mode == GEMV_OUT_SLAB) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_SLAB, 1, 1, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
+            if (p.xsrc == GEMV_X_SLABS) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, 1, GEMV_X_SLABS>(grid, block, c.shm, s, p); return true; }
         }
-        hipLaunchKernelGGL((dec_gemv2_kernel<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, MT, GEMV_X_PLAIN>), grid, block, c.shm, s, p);
-    } else hipLaunchKernelGGL((dec_gemv2_kernel<CH, 1, GEMV_IN_XATTN, GEMV_OUT_RESID, 1, MT, GEMV_X_PLAIN>), grid, block, c.shm, s, p);
+        g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p);
+    } else g2_launch<CH, 1, GEMV_IN_XATTN, GEMV_OUT_RESID, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p);
     return true;
 }
 // the (CH, LNV) pairs of the Whisper family: d_model 512 (4,2), 768 (6,3), 1024 (4,4), 1280 (5,5)
@@ -999,8 +1021,8 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
         const int want = (p.M * p.H * 8 + 63) / 64;
         block.x = 64 * std::max(c.nw, std::min(16, want));
     }
-#define WLX_G2_LN(CH_, LNV_) (c.MT == 1 ? gemv2_launch_ln<CH_, LNV_, 1>(p, c, grid, block, s) : gemv2_launch_ln<CH_, LNV_, 2>(p, c, grid, block, s))
-#define WLX_G2_OT(CH_) (c.MT == 1 ? gemv2_launch_other<CH_, 1>(p, c, grid, block, s) : gemv2_launch_other<CH_, 2>(p, c, grid, block, s))
+#define WLX_G2_LN(CH_, LNV_) (c.MT == 1 ? gemv2_launch_ln<CH_, LNV_, 1>(p, c, grid, block, s) : c.MT == 2 ? gemv2_launch_ln<CH_, LNV_, 2>(p, c, grid, block, s) : gemv2_launch_ln<CH_, LNV_, 3>(p, c, grid, block, s))
+#define WLX_G2_OT(CH_) (c.MT == 1 ? gemv2_launch_other<CH_, 1>(p, c, grid, block, s) : c.MT == 2 ? gemv2_launch_other<CH_, 2>(p, c, grid, block, s) : gemv2_launch_other<CH_, 3>(p, c, grid, block, s))
     if (p.in_mode == GEMV_IN_LN && p.xsrc != GEMV_X_PLAIN) {
         if (c.CH == 4 && c.LNV == 3) return gemv2_launch_qkv_xs<4, 3>(p, c, grid, block, s);
         if (c.CH == 3 && c.LNV == 3) return gemv2_launch_qkv_xs<3, 3>(p, c, grid, block, s);
@@ -1015,6 +1037,12 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
         if (c.CH == 4 && c.LNV == 2) return WLX_G2_LN(4, 2);
         if (c.CH == 4 && c.LNV == 4) return WLX_G2_LN(4, 4);
         return false;
+    }
+    if (p.in_mode == GEMV_IN_XATTN && c.CH < 4) {
+        if (c.MT != 1) return false;                                       // (the 8-wave combine is picked for one row tile only, gemv2_cfg)
+        if (c.CH == 3) g2_launch<3, 1, GEMV_IN_XATTN, GEMV_OUT_RESID, 1, 1, GEMV_X_PLAIN>(grid, block, c.shm, s, p);
+        else g2_launch<2, 1, GEMV_IN_XATTN, GEMV_OUT_RESID, 1, 1, GEMV_X_PLAIN>(grid, block, c.shm, s, p);
+        return true;
     }
     switch (c.CH) {
         case 6: return WLX_G2_OT(6);

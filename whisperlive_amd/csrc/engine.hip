@@ -952,6 +952,11 @@ static int get_step_graph(Engine* e, Slot* s, int rows, int R, int groups, bool 
     auto it = s->graphs.find(key);
     if (it != s->graphs.end()) { *out = it->second; return WLX_OK; }
     hipGraph_t graph;
+    // One eager pass first: the first launch of a kernel instantiation may have to raise its dynamic-LDS limit
+    // (decoder.hip g2_launch), which must not happen inside a capture. It only rewrites scratch and re-appends the K/V the
+    // captured replay appends again (same rows, same positions); the search, which mutates state, is not run.
+    decoder_pass(e, s, rows, R, groups, true, true);
+    CK(hipGetLastError());
     CK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
     decoder_pass(e, s, rows, R, groups, true, true);
     launch_search(e, s, rows, groups, sampling);
@@ -1476,21 +1481,26 @@ extern "C" int32_t wlx_debug_time_decode_step(wlx_engine* e, int32_t slot, int32
     SlotGuard sg_;
     CKR(slot_acquire(e, slot, sg_));
     Slot* s = sg_.s;
-    if (rows < 1 || rows > s->cache_rows || rows > 16 || t < 0 || t >= WLX_T_TEXT || iters < 1 || !avg_ms_out)
+    if (rows < 1 || rows > s->cache_rows || rows > 64 || t < 0 || t >= WLX_T_TEXT || iters < 1 || !avg_ms_out)
         return fail(WLX_ERR_ARG, "bad arguments");
+    if (rows > 16 && (rows % s->R != 0 || rows / s->R > s->B)) return fail(WLX_ERR_ARG, "more than 16 rows: a multiple of the slot's rows per item");
     if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "decode before encode");
     CK(hipSetDevice(e->device));
     hipStream_t st = s->stream;
-    // one item, `rows` beams all at position t with identity history (timing only: cache content is whatever is there)
-    std::vector<int> tk(rows, 0), ps(rows, t), ca(rows), an(rows), gi(1, 0);
+    // one item, `rows` beams all at position t with identity history (timing only: cache content is whatever is there);
+    // more than 16 rows: rows / R items of R beams each, as a batched decode has them
+    const int tR = rows > 16 ? s->R : rows, tG = rows / tR;
+    std::vector<int> tk(rows, 0), ps(rows, t), ca(rows), an(rows), gi(tG, 0);
+    for (int g = 0; g < tG; ++g) gi[g] = g % std::max(1, s->enc_batch);
     std::vector<short> anc((size_t)rows * WLX_T_TEXT);
     for (int r = 0; r < rows; ++r) { ca[r] = an[r] = r; for (int p = 0; p < WLX_T_TEXT; ++p) anc[(size_t)r * WLX_T_TEXT + p] = (short)r; }
     CKR(set_anc_rows(s, anc, 0, rows));
     CKR(upload_rows(s, tk, ps, ca, an, gi));
     CK(hipMemsetAsync(s->st.done, 0, 4, st));
     hipGraph_t graph; hipGraphExec_t exec;
+    decoder_pass(e, s, rows, tR, tG, true, true);      // eager first (dynamic-LDS limits are raised outside capture)
     CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    decoder_pass(e, s, rows, rows, 1, true, true);
+    decoder_pass(e, s, rows, tR, tG, true, true);
     CK(hipStreamEndCapture(st, &graph));
     CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     CK(hipGraphDestroy(graph));

@@ -159,7 +159,7 @@ class FeatureExtractorHIP:
 class _EngineModel:
     """The ctranslate2.models.Whisper surface the reference calls."""
 
-    MAX_LEAN_ROWS = 32      # rows one launch of the lean decode kernels covers (csrc/decoder.hip gemv2_cfg)
+    MAX_LEAN_ROWS = 48      # rows one launch of the lean decode kernels covers (csrc/decoder.hip gemv2_cfg: three 16-row tiles)
 
     def __init__(self, owner: "WhisperModelHIP"):
         self._o = owner
@@ -196,7 +196,7 @@ class _EngineModel:
             sup = [t for t in sup if t >= 0] + list(o._base_tokenizer.non_speech_tokens)
         # CT2's generate defaults: beam_size > 1 -> beam search; beam_size == 1 -> sampling with top-k / temperature.
         temp = 0.0 if beam_size > 1 else (float(sampling_temperature) if sampling_topk != 1 else 0.0)
-        # The lean decode kernels (decoder.hip dec_gemv2_kernel) cover 32 beam rows per launch; a wider batch (the batch
+        # The lean decode kernels (decoder.hip dec_gemv2_kernel) cover 48 beam rows per launch (three 16-row MFMA tiles); a wider batch (e.g. the batch
         # worker's default of 8 items x 5 beams = 40 rows) would fall back to the general first-generation kernels, ~3x
         # slower per step. Decode such a batch as consecutive groups over the SAME resident encoder output (item maps):
         # identical results, every launch on the fast path.
