@@ -5,7 +5,7 @@ timeout 600 python -m pytest tests/test_gpu_lean_family.py tests/test_gpu_full_d
 tail -3 "$OUT/pytest_sub.log"
 timeout 200 python scripts/trace_step.py --csv "$OUT/trace.csv" > "$OUT/trace.txt" 2>&1; echo "trace rc=$?"
 head -10 "$OUT/trace.txt"; tail -4 "$OUT/trace.txt"
-for cfg in "X=0" "WLX_XATTN_NW8=0" "X=1" "WLX_XATTN_NW8=0"; do
+for cfg in "X=0" "WLX_SELF_ATTN_IDENT=0" "X=1" "WLX_SELF_ATTN_IDENT=0"; do
   env $cfg timeout 300 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-stream --no-pmc > "$OUT/bench_quick.json" 2> "$OUT/bench_quick.err"
   python - "$OUT/bench_quick.json" "[$cfg]" <<'PY'
 import json, sys

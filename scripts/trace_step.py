@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--t", type=int, default=33)
     ap.add_argument("--csv", default=None)
     ap.add_argument("--build-only", action="store_true")
+    ap.add_argument("--items", type=int, default=1, help="audio items in the slot (rows = items x 5 beams: 8 -> the batch worker's 40 rows)")
     ap.add_argument("--waves", action="store_true", help="per-wave detail for the lean GEMV launches of the first layer")
     args = ap.parse_args()
     from whisperlive_amd import _lib
@@ -38,14 +39,17 @@ def main():
 
     spec = get_spec(args.model)
     eng = HipWhisperEngine(spec, random_weights(spec, seed=0), device=0)
-    slot = eng.create_slot(1, 5)
+    slot = eng.create_slot(args.items, 5)
     ids = bench.token_ids(spec.vocab)
-    slot.pcm_put(olm.speech_like_pcm(30.0, seed=1234))
-    T = slot.logmel_resident()
-    slot.encode(1, seek=[0], seg=[min(T - 1, 3000)])
-    slot.generate([[ids["sot"]]], TokenIds(**ids), beam_size=5, patience=1.0, max_length=65,
+    B = args.items
+    Ts = []
+    for i in range(B):
+        slot.pcm_put(olm.speech_like_pcm(30.0, seed=1234 + i), item=i)
+        Ts.append(slot.logmel_resident(item=i))
+    slot.encode(B, seek=[0] * B, seg=[min(t - 1, 3000) for t in Ts])
+    slot.generate([[ids["sot"]]] * B, TokenIds(**ids), beam_size=5, patience=1.0, max_length=65 if B == 1 else 9,
                   suppress_tokens=bench.suppress_list(ids, True))
-    names, rec = slot.debug_trace_step(5, args.t, True)
+    names, rec = slot.debug_trace_step(5 * B, args.t, True)
     n = len(names)
     t0 = None
     prev_end = None

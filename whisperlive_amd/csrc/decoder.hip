@@ -1132,6 +1132,10 @@ void launch_dec_gemv(const GemvParams& p0, hipStream_t s) {
 //   scores by in-lane dot product, block max / sum by DPP, probabilities through LDS to the (pg, dc) lanes, which
 //   accumulate their 8 dims over their 8 positions with the running-max rescale.
 //   tail: the 8 position groups are summed through LDS, lane d writes output dim d.
+// IDENT: the rows read their history through their OWN ancestry row (every decode step; prefill rows share one): the
+// ancestry row address then needs no table lookup, so the first block's cache-row lookup is requested at once, next to
+// the scalar loads of the row's position, instead of behind them — one dependent trip less (of three) per launch.
+template <bool IDENT>
 __global__ __launch_bounds__(64) void dec_self_attn2_kernel(const half_t* __restrict__ q, long ldq,
                                                             const half_t* __restrict__ Kc,
                                                             const half_t* __restrict__ Vc, long crs, int d,
@@ -1145,8 +1149,10 @@ __global__ __launch_bounds__(64) void dec_self_attn2_kernel(const half_t* __rest
     const int lane = threadIdx.x;
     const int r = blockIdx.x, h = blockIdx.y;
     WLX_TR_BEGIN();
+    const short* ar = anc + (long)(IDENT ? r : ancrow[r]) * WLX_T_TEXT;
+    int cr0 = 0;
+    if constexpr (IDENT) cr0 = ar[lane];                    // block 0's cache rows (lane < 448: always inside the row)
     const int len = pos[r] + 1;
-    const short* ar = anc + (long)ancrow[r] * WLX_T_TEXT;
     f16x8 qv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) qv[i] = ld_f16x8(q + (long)r * ldq + h * WLX_HEAD_DIM + i * 8);
@@ -1160,7 +1166,9 @@ __global__ __launch_bounds__(64) void dec_self_attn2_kernel(const half_t* __rest
     for (int p0 = 0; p0 < len; p0 += 64) {
         const int p = p0 + lane;
         const bool ok = p < len;
-        const int cr = ar[ok ? p : len - 1];
+        int cr;
+        if (IDENT && p0 == 0) cr = ok ? cr0 : __builtin_amdgcn_readlane(cr0, 0);      // (a masked lane: any valid row — position 0's)
+        else cr = ar[ok ? p : len - 1];
         crow[lane] = cr;
         // K row of position p (lane = position); the LDS write above is visible to this same wave after the wait below
         const half_t* kp = Kc + (unsigned)(cr * icrs + (ok ? p : len - 1) * d + hoff);
@@ -1210,10 +1218,15 @@ __global__ __launch_bounds__(64) void dec_self_attn2_kernel(const half_t* __rest
 }
 
 void launch_dec_self_attn(const half_t* q, long ldq, const half_t* Kc, const half_t* Vc, long crs, int d, int H,
-                          const RowTables& rt, int rows, half_t* out, long ldo, const int* done, hipStream_t s) {
+                          const RowTables& rt, int rows, half_t* out, long ldo, const int* done, bool ident_ancestry, hipStream_t s) {
     (void)done;   // a step that runs after the search raised `done` only rewrites scratch (engine.hip decoder_pass)
-    hipLaunchKernelGGL(dec_self_attn2_kernel, dim3(rows, H), dim3(64), 0, s, q, ldq, Kc, Vc, crs, d, rt.pos,
-                       rt.ancrow, rt.anc, out, ldo WLX_TR_ARG("self_attn"));
+    static const bool no_ident = [] { const char* e = getenv("WLX_SELF_ATTN_IDENT"); return e && e[0] == '0'; }();   // (A/B)
+    if (ident_ancestry && !no_ident)
+        hipLaunchKernelGGL(dec_self_attn2_kernel<true>, dim3(rows, H), dim3(64), 0, s, q, ldq, Kc, Vc, crs, d, rt.pos,
+                           rt.ancrow, rt.anc, out, ldo WLX_TR_ARG("self_attn"));
+    else
+        hipLaunchKernelGGL(dec_self_attn2_kernel<false>, dim3(rows, H), dim3(64), 0, s, q, ldq, Kc, Vc, crs, d, rt.pos,
+                           rt.ancrow, rt.anc, out, ldo WLX_TR_ARG("self_attn"));
 }
 
 // ------------------------------------------------------------------ decode cross-attention (flash-decoding split over keys)

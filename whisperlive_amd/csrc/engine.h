@@ -68,6 +68,7 @@ struct Slot {
     long ldl = 0;
     int *d_token = nullptr, *d_pos = nullptr, *d_cache = nullptr, *d_ancrow = nullptr, *d_group_item = nullptr;
     short* d_anc = nullptr; int* d_intok = nullptr;
+    bool anc_ident = false;                          // the uploaded row tables have ancrow[r] == r (decode steps; upload_rows)
     SearchState st{};
     SearchParams* d_sp = nullptr;
     unsigned* d_suppress = nullptr;

@@ -826,7 +826,7 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
         half_t* vc = s->vc + (size_t)l * s->cache_rows * crs;
         // LN1 + QKV, K/V appended to the self-attention cache
         pgemv(s, qkv_params(l, (l == 0 && fold_embed) ? GEMV_X_EMBED : (slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN)));
-        plaunch(s, "dec_self_attn2_kernel", 4.0 * rows * d * (s->prof ? s->prof->t + 1 : 1), [&] { launch_dec_self_attn(s->qd, d, kc, vc, crs, d, H, rt, rows, s->attnd, d, done, st); });
+        plaunch(s, "dec_self_attn2_kernel", 4.0 * rows * d * (s->prof ? s->prof->t + 1 : 1), [&] { launch_dec_self_attn(s->qd, d, kc, vc, crs, d, H, rt, rows, s->attnd, d, done, s->anc_ident, st); });
         pgemv(s, oproj_params(l, slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN));
         slabs_pending = false;
         GemvParams p{};
@@ -887,6 +887,8 @@ static int upload_rows(Slot* s, const std::vector<int>& token, const std::vector
                        const std::vector<int>& cache, const std::vector<int>& ancrow, const std::vector<int>& group_item) {
     const size_t rows = token.size(), ng = group_item.size();
     if (4 * rows + ng > s->h_stage_ints) return fail(WLX_ERR_ARG, "row table too large");
+    s->anc_ident = true;                                    // every row reads its history through its own ancestry row
+    for (size_t i = 0; i < rows; ++i) s->anc_ident = s->anc_ident && ancrow[i] == (int)i;
     CK(hipStreamSynchronize(s->stream));   // staging buffer reuse
     int* h = s->h_stage;
     memcpy(h, token.data(), rows * 4); memcpy(h + rows, pos.data(), rows * 4);
@@ -1499,8 +1501,9 @@ extern "C" int32_t wlx_debug_time_decode_step(wlx_engine* e, int32_t slot, int32
     CK(hipMemsetAsync(s->st.done, 0, 4, st));
     hipGraph_t graph; hipGraphExec_t exec;
     decoder_pass(e, s, rows, tR, tG, true, true);      // eager first (dynamic-LDS limits are raised outside capture)
+    static const int passes = [] { const char* v = getenv("WLX_PROBE_PASSES_PER_GRAPH"); return v ? std::max(1, atoi(v)) : 1; }();   // (experiment: graph-to-graph boundary)
     CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    decoder_pass(e, s, rows, tR, tG, true, true);
+    for (int q = 0; q < passes; ++q) decoder_pass(e, s, rows, tR, tG, true, true);
     CK(hipStreamEndCapture(st, &graph));
     CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     CK(hipGraphDestroy(graph));
@@ -1511,7 +1514,7 @@ extern "C" int32_t wlx_debug_time_decode_step(wlx_engine* e, int32_t slot, int32
     CK(hipStreamSynchronize(st));
     float ms = 0.f;
     CK(hipEventElapsedTime(&ms, s->ev0, s->ev1));
-    *avg_ms_out = ms / (float)iters;
+    *avg_ms_out = ms / (float)iters / (float)passes;
     CK(hipGraphExecDestroy(exec));
     return WLX_OK;
 }
@@ -1527,12 +1530,15 @@ extern "C" int32_t wlx_debug_trace_step(wlx_engine* e, int32_t slot, int32_t row
     SlotGuard sg_;
     CKR(slot_acquire(e, slot, sg_));
     Slot* s = sg_.s;
-    if (rows < 1 || rows > s->cache_rows || rows > 16 || t < 0 || t >= WLX_T_TEXT || !out || !names || !n_launches_out)
+    if (rows < 1 || rows > s->cache_rows || rows > 64 || t < 0 || t >= WLX_T_TEXT || !out || !names || !n_launches_out)
         return fail(WLX_ERR_ARG, "bad arguments");
+    if (rows > 16 && (rows % s->R != 0 || rows / s->R > s->B)) return fail(WLX_ERR_ARG, "more than 16 rows: a multiple of the slot's rows per item");
     if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "decode before encode");
     CK(hipSetDevice(e->device));
     hipStream_t st = s->stream;
-    std::vector<int> tk(rows, 0), ps(rows, t), ca(rows), an(rows), gi(1, 0);
+    const int tR = rows > 16 ? s->R : rows, tG = rows / tR;
+    std::vector<int> tk(rows, 0), ps(rows, t), ca(rows), an(rows), gi(tG, 0);
+    for (int g = 0; g < tG; ++g) gi[g] = g % std::max(1, s->enc_batch);
     std::vector<short> anc((size_t)rows * WLX_T_TEXT);
     for (int r = 0; r < rows; ++r) { ca[r] = an[r] = r; for (int p = 0; p < WLX_T_TEXT; ++p) anc[(size_t)r * WLX_T_TEXT + p] = (short)r; }
     const size_t max_launch = 320;
@@ -1551,9 +1557,11 @@ extern "C" int32_t wlx_debug_trace_step(wlx_engine* e, int32_t slot, int32_t row
         return WLX_OK;
     };
     CKR(reset_state());
+    { const int seq0 = g_trace_seq; unsigned long long* b0 = g_trace_buf; g_trace_buf = nullptr;   // eager pass (LDS limits), untraced
+      decoder_pass(e, s, rows, tR, tG, true, true); g_trace_seq = seq0; g_trace_buf = b0; }
     CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-    decoder_pass(e, s, rows, rows, 1, true, true);
-    if (with_search) launch_search(e, s, rows, 1, false);
+    decoder_pass(e, s, rows, tR, tG, true, true);
+    if (with_search) launch_search(e, s, rows, tG, false);
     CK(hipStreamEndCapture(st, &graph));
     CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     CK(hipGraphDestroy(graph));
