@@ -312,12 +312,182 @@ __global__ __launch_bounds__(64) void attn_encoder_pf_kernel(const half_t* __res
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Third form (round 2): K / V^T tiles SHARED by the four waves of a workgroup through an LDS ring filled by LDS-DMA.
+// What the second form still paid (rocprofv3: 52 us per layer launch, 5 % of the MFMA peak): 564 one-wave workgroups =
+// 0.55 waves per SIMD, every wave pulling its own copy of every K / V tile from L2 (212 MB of L2 -> L1 traffic per layer)
+// and nothing on its SIMD to overlap its softmax with. Here a workgroup owns 64 query rows of a head (4 waves x 16 rows:
+// twice the waves, so ~1.1 per SIMD and two workgroups on the CUs that get two), a tile of 32 keys is fetched ONCE per
+// workgroup — eight 1 KiB global_load_lds_dwordx4 pieces, two per wave, DEPTH - 1 tiles in flight — and every wave reads
+// its MFMA operands from LDS (lane-linear 16 B, conflict-free), so L2 traffic drops 4x and the loads of tile i + 3 run
+// under the arithmetic of tile i. One counted vmcnt + one raw s_barrier per tile (no __syncthreads: hipcc lowers it to
+// vmcnt(0) with LDS-DMA in flight and the ring would drain every trip, see gemm.hip).
+//   Key order inside a tile: K fragment s (of 2) holds keys g8*8 + s*4 + r  (g8 = 0..3, r = 0..3) in its 16 A-rows, so
+// the transposed score tile leaves lane (query c, g) with keys g*8 + s*4 + r — i.e. its 8 probabilities are the 8
+// CONSECUTIVE keys g*8 .. g*8+7, exactly one 16-byte piece of a V^T row: V^T fragments become single dwordx4 LDS-DMA
+// pieces (the second form needed two 8-byte loads per fragment, which LDS-DMA cannot express).
+typedef __attribute__((address_space(3))) void wlx_lds_void_a;
+
+template <int DEPTH, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_encoder_lds_kernel(const half_t* __restrict__ Q, long ldq,
+                                                               const half_t* __restrict__ K, long ldk,
+                                                               const half_t* __restrict__ Vt, long ldvt,
+                                                               half_t* __restrict__ O, long ldo, int T,
+                                                               long isq, long isk, long isv, long iso) {
+    constexpr int NL = 8 / NW;                              // LDS-DMA pieces (vmcnt events) per wave per tile
+    static_assert((NW == 4 || NW == 8) && DEPTH >= 3 && NL * (DEPTH - 2) <= 63, "8 pieces per tile over 4 or 8 waves; vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) f16x8 aring[];      // [DEPTH][8 fragments][64 lanes] x 16 B — the ONLY LDS object
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    const int h = blockIdx.y, item = blockIdx.z;
+    const int q0 = blockIdx.x * (NW * 16) + wave * 16;
+    Q += (long)item * isq + h * WLX_HEAD_DIM;
+    K += (long)item * isk + h * WLX_HEAD_DIM;
+    Vt += (long)item * isv + (long)h * WLX_HEAD_DIM * ldvt;
+    O += (long)item * iso + h * WLX_HEAD_DIM;
+    const int NT = (T + 31) >> 5;
+
+    // this wave's pieces of a tile: fragments NL * wave .. of (K s0kt0, K s0kt1, K s1kt0, K s1kt1, V dt0..3)
+    const int f0 = NL * wave;                               // first fragment of this wave
+    const bool frag_is_k = f0 < 4;
+    const half_t* src0;
+    long step;                                              // halfs per tile
+    long frag_step;                                         // halfs between this wave's two fragments (NL == 2)
+    const int ks = (f0 >> 1) & 1, kkt = f0 & 1;             // K fragment (s, kt) of piece 0
+    if (frag_is_k) {
+        const int krow = (c >> 2) * 8 + ks * 4 + (c & 3);   // rows in the permuted key order
+        src0 = K + (long)krow * ldk + kkt * 32 + g * 8;
+        step = 32 * ldk; frag_step = 32;
+    } else {
+        const int dt = f0 - 4;                              // V^T fragment dt: 8 consecutive keys of dim row dt*16 + c
+        src0 = Vt + (long)(dt * 16 + c) * ldvt + g * 8;
+        step = 32; frag_step = 16 * ldvt;
+    }
+    const long kclamp = (long)(T - 1) * ldk;                // K rows past the end re-read the last row (their scores are masked)
+    auto issue = [&](int ti, int buf) {
+        f16x8* dst = aring + ((long)buf * 8 + f0) * 64;
+        const half_t* a0 = src0 + (long)ti * step;
+        if (frag_is_k) {                                          // (wave-uniform) only the last tile can run past row T - 1
+            const long row = (long)ti * 32 + (c >> 2) * 8 + ks * 4 + (c & 3);
+            if (row >= T) a0 = K + kclamp + kkt * 32 + g * 8;
+        }
+        __builtin_amdgcn_global_load_lds((const void*)a0, (wlx_lds_void_a*)dst, 16, 0, 0);
+        if constexpr (NL == 2) __builtin_amdgcn_global_load_lds((const void*)(a0 + frag_step), (wlx_lds_void_a*)(dst + 64), 16, 0, 0);
+    };
+    // The query fragments go through LDS as well (LDS-DMA into a per-wave 2 KiB area behind the ring, FIRST so that they
+    // are the oldest requests): with an ordinary VGPR-destination load anywhere near an LDS-DMA pipeline hipcc's wait
+    // insertion falls back to vmcnt(0) at the first use of that register on EVERY trip of the loop — the whole ring drained
+    // per tile, one L2 round trip per tile (measured: 46 us per layer launch whatever the ring depth; an explicit counted
+    // wait in front of the loop did not change its mind). All-LDS-DMA kernels get counted waits only.
+    f16x8* qarea = aring + (long)DEPTH * 8 * 64 + wave * 2 * 64;
+    {
+        int row = q0 + c;
+        if (row >= T) row = T - 1;
+        const half_t* qsrc = Q + (long)row * ldq + g * 8;
+        __builtin_amdgcn_global_load_lds((const void*)qsrc, (wlx_lds_void_a*)qarea, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)(qsrc + 32), (wlx_lds_void_a*)(qarea + 64), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < DEPTH - 1; ++i)
+        if (i < NT) issue(i, i);
+    // the two Q pieces are the oldest requests: the DEPTH - 1 fills behind them stay in flight (NT >= DEPTH - 1 always)
+    __builtin_amdgcn_s_waitcnt(((NL * (DEPTH - 1)) & 15) | (((NL * (DEPTH - 1)) >> 4) << 14) | 0x0F70);
+    f16x8 qf[2];
+    qf[0] = qarea[lane];
+    qf[1] = qarea[64 + lane];
+    f32x4 acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrun = WLX_NEG_INF, lrun = 0.f;
+    constexpr float LOG2E = 1.4426950408889634f;
+
+    int rbuf = 0, wbuf = DEPTH - 1;
+    auto tile = [&](int ti, auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        // tiles ti .. min(ti + DEPTH - 2, NT - 1) are outstanding; tile ti must have landed (this wave's pieces: counted
+        // vmcnt; everyone's: the barrier, which also says everyone is done reading the buffer refilled next)
+        if (ti + DEPTH - 2 < NT) __builtin_amdgcn_s_waitcnt(((NL * (DEPTH - 2)) & 15) | (((NL * (DEPTH - 2)) >> 4) << 14) | 0x0F70);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();
+        if (ti + DEPTH - 1 < NT) issue(ti + DEPTH - 1, wbuf);
+        const f16x8* src = aring + (long)rbuf * 8 * 64 + lane;
+        f32x4 st[2];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            st[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) st[s] = mfma16(src[(s * 2 + kt) * 64], qf[kt], st[s]);
+        }
+        float p[8];
+        float tmax = WLX_NEG_INF;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = st[s][r];
+                if (MASKED) { const int key = ti * 32 + g * 8 + s * 4 + r; v = (key < T) ? v : WLX_NEG_INF; }
+                p[s * 4 + r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        tmax = rows4_max(tmax) * LOG2E;
+        const float mnew = fmaxf(mrun, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { p[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(p[i], LOG2E, -mnew)); psum += p[i]; }
+        lrun = lrun * alpha + psum;
+        mrun = mnew;
+        const f16x8 pf = {(half_t)p[0], (half_t)p[1], (half_t)p[2], (half_t)p[3],
+                          (half_t)p[4], (half_t)p[5], (half_t)p[6], (half_t)p[7]};
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+            float al = alpha;
+            asm volatile("" : "+v"(al));
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { acc[dt][0] *= al; acc[dt][1] *= al; acc[dt][2] *= al; acc[dt][3] *= al; }
+        }
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma16(src[(4 + dt) * 64], pf, acc[dt]);
+        rbuf = (rbuf + 1 == DEPTH) ? 0 : rbuf + 1;
+        wbuf = (wbuf + 1 == DEPTH) ? 0 : wbuf + 1;
+    };
+    int ti = 0;
+#pragma unroll 1
+    for (; (ti + 1) * 32 <= T; ++ti) tile(ti, std::false_type{});          // tiles entirely below T: no key masks
+#pragma unroll 1
+    for (; ti < NT; ++ti) tile(ti, std::true_type{});                       // the last tile (keys >= T masked)
+    float l = lrun;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int row = q0 + c;
+    if (row < T) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const f16x4 o = {(half_t)(acc[dt][0] * inv), (half_t)(acc[dt][1] * inv),
+                             (half_t)(acc[dt][2] * inv), (half_t)(acc[dt][3] * inv)};
+            *reinterpret_cast<f16x4*>(O + (long)row * ldo + dt * 16 + g * 4) = o;
+        }
+    }
+}
+
+int attn_prepare_device() { return 0; }                     // (the ring is 32 KiB: below the default dynamic-LDS limit)
+
 void launch_attn_encoder(const half_t* Q, long ldq, const half_t* K, long ldk, const half_t* Vt, long ldvt,
                          half_t* O, long ldo, int T, int H, int items,
                          long isq, long isk, long isv, long iso, hipStream_t s) {
     constexpr int QT = 2;   // measured on Whisper-small: QT = 1 fills every SIMD but doubles the K/V re-reads from L2: 2.64 vs 2.35 ms per encoder
     dim3 grid((T + QT * 16 - 1) / (QT * 16), H, items);
-    static const int form = [] { const char* e = getenv("WLX_ENC_ATTN"); return e ? atoi(e) : 2; }();   // 1 = first form (A/B)
+    static const int form = [] { const char* e = getenv("WLX_ENC_ATTN"); return e ? atoi(e) : 3; }();   // 1 / 2 = earlier forms (A/B)
+    if (form >= 3) {      // 3: 4 waves, ring of 4; 4: 4 waves, ring of 7 (56 KiB); 5: 8 waves (128 rows), ring of 7
+#define WLX_ATTN_LDS(DEPTH_, NW_) hipLaunchKernelGGL((attn_encoder_lds_kernel<DEPTH_, NW_>), dim3((T + NW_ * 16 - 1) / (NW_ * 16), H, items), \
+                                                     dim3(NW_ * 64), DEPTH_ * 8 * 1024 + NW_ * 2048, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, T, isq, isk, isv, iso)
+        if (form == 3) WLX_ATTN_LDS(4, 4);
+        else if (form == 4) WLX_ATTN_LDS(7, 4);
+        else WLX_ATTN_LDS(7, 8);
+#undef WLX_ATTN_LDS
+        return;
+    }
     if (form == 1)
         hipLaunchKernelGGL((attn_encoder_kernel<QT>), grid, dim3(64), 0, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, T,
                            isq, isk, isv, iso);
