@@ -358,6 +358,10 @@ def test_align_parity(tiny, n_text):
         assert c_got <= c_ref + 5e-3 * abs(c_ref) + 1e-3, (c_got, c_ref)
         same = len(set(zip(ti.tolist(), fi.tolist())) & set(zip(rti.tolist(), rfi.tolist()))) / len(rti)
         print("align", n_text, "path overlap", same, "cost", c_got, c_ref)
-        assert same >= 0.8
+        # "mostly identical" only means something where the optimum is well separated: on these seeded random weights the
+        # attention matrix is nearly flat, two monotone paths that share half their cells can differ by 2e-4 of the cost
+        # (seen when the encoder attention kernel changed its summation order), and DTW then picks either. A path that is
+        # as good as the oracle's ON THE ORACLE'S MATRIX to 0.1 % passes whatever its overlap.
+        assert same >= 0.8 or c_got <= c_ref + 1e-3 * abs(c_ref), (same, c_got, c_ref)
     finally:
         slot.close()
