@@ -127,3 +127,33 @@ def test_eight_items_batched_equal_singles(fam):
             assert abs(res[i].scores[0] - singles[i].scores[0]) < 1e-3
     finally:
         sb.close()
+
+
+@pytest.mark.parametrize("seed,beam", [(0, 5), (1, 5), (2, 3), (3, 4), (4, 5)])
+def test_search_on_injected_logits_full_vocabulary(fam, seed, beam):
+    """the device search (chunked scan + merge/update, search.hip) on INJECTED logits at the real vocabulary size (27 chunks
+    per row; the micro model of test_gpu_parity.py has two), token-exact against the oracle's beam search: ties included —
+    logits are quantised to a coarse grid so that equal values (broken by the smaller id) occur in every list, several of
+    the best candidates are planted in ONE lane / one chunk / adjacent chunks, and a few steps have fewer than 2 x beam
+    allowed ids in most chunks."""
+    name, spec, eng, oracle, slot, enc = fam
+    if spec.vocab < 50000:
+        pytest.skip("full-vocabulary case: the small-like member of the family")
+    ids = H.token_ids_for(spec.vocab)
+    rng = np.random.default_rng(100 + seed)
+    steps, V = 14, spec.vocab
+    lg = (rng.standard_normal((steps, beam, V)) * 3.0).astype(np.float32)
+    lg = np.round(lg * 4.0) / 4.0                                   # ties everywhere
+    lg[:, :, ids.timestamp_begin:] += 2.0
+    lg[:, :, ids.eot] += (5.0 if seed % 2 else 0.0)
+    for t in range(steps):                                          # clustered winners
+        base = int(rng.integers(1000, V - 9000))
+        lg[t, :, base:base + 2048 * 2:256] += 9.0                   # same lane of a chunk (stride = threads per scan workgroup)
+        lg[t, :, base + 7:base + 19] += 8.75                        # neighbours inside one chunk
+    lg[5:7, :, 3000:ids.eot - 200] = -np.inf                        # nearly empty text chunks
+    prompt = [ids.sot]
+    kw = dict(beam_size=beam, patience=1.0, max_length=1 + steps - 2, suppress_tokens=H.default_suppress(ids), length_penalty=1.0)
+    ref = odec.generate(odec.InjectedLogits(lg), prompt, odec.GenOptions(ids=ids, **kw))
+    got = slot.debug_search(lg, prompt, H.engine_ids(ids), **kw)
+    assert got.sequences_ids == ref.sequences_ids, (got.sequences_ids, ref.sequences_ids)
+    np.testing.assert_allclose(got.scores, ref.scores, rtol=1e-3, atol=1e-3)

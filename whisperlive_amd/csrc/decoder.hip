@@ -437,10 +437,12 @@ __device__ __forceinline__ void stage_rows_f16(const half_t* __restrict__ X, lon
 //   (Measured and dropped: LayerNorm helper waves beyond the nw MFMA waves, a wave per row — their dummy weight requests,
 //   needed to keep hipcc's wait counting uniform, delayed the real weight stream by 0.6 us per launch, profiles/r2f_*.)
 template <int CH, int LNV, int IN, int OUT, int NTB, int MT, int XS>
-__global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB) ? 512 : 1024) void dec_gemv2_kernel(GemvParams p) {
-    static_assert(XS == GEMV_X_PLAIN || (MT == 1 && (IN == GEMV_IN_LN || (IN == GEMV_IN_F16 && OUT == GEMV_OUT_RESID && NTB == 1))),
-                  "slab / embedding sources: single-row-tile LayerNorm prologue or residual epilogue only");
-    static_assert(OUT != GEMV_OUT_SLAB || (IN == GEMV_IN_F16 && MT == 1 && NTB == 1), "K-split form: fp16 rows in, one row tile");
+// (<= 8 waves wherever the kernel holds more than one row tile of fragments: 256 VGPRs per lane — at 16 waves the
+// two- and three-tile residual projections spilled, 36-180 bytes of scratch per lane)
+__global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1) ? 512 : 1024) void dec_gemv2_kernel(GemvParams p) {
+    static_assert(XS == GEMV_X_PLAIN || IN == GEMV_IN_LN || (IN == GEMV_IN_F16 && OUT == GEMV_OUT_RESID && NTB == 1),
+                  "slab / embedding sources: LayerNorm prologue or residual epilogue only");
+    static_assert(OUT != GEMV_OUT_SLAB || (IN == GEMV_IN_F16 && NTB == 1), "K-split form: fp16 rows in");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -654,14 +656,33 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB) ? 512 : 
         // NEWEST request of either, so the first trip would wait for the weight stream it is meant to overlap.
         combine_row(ra, wave < p.M, x, sl, te, tok0, pos0);
         ln_row(x, ra, wave < p.M);
+        if constexpr (MT == 1) {
 #pragma unroll 1
-        for (int r = wave + nwl; r < p.M; r += nwl) {                       // more rows than waves (batched streams)
-            float4 x2[LNV], sl2[NSL][LNV];
-            f16x4 te2[LNV];
-            int tok2 = 0, pos2 = 0;
-            request_row(r, x2, sl2, te2, tok2, pos2);
-            combine_row(r, true, x2, sl2, te2, tok2, pos2);
-            ln_row(x2, r, true);
+            for (int r = wave + nwl; r < p.M; r += nwl) {                   // more rows than waves (9..16 rows)
+                float4 x2[LNV], sl2[NSL][LNV];
+                f16x4 te2[LNV];
+                int tok2 = 0, pos2 = 0;
+                request_row(r, x2, sl2, te2, tok2, pos2);
+                combine_row(r, true, x2, sl2, te2, tok2, pos2);
+                ln_row(x2, r, true);
+            }
+        } else {
+            // batched streams (17..48 rows: 3..6 rows per wave): two rows per trip, both requested before either is
+            // normalised, so a trip pays ONE round trip to L2 instead of one per row
+#pragma unroll 1
+            for (int r = wave + nwl; r < p.M; r += 2 * nwl) {
+                const int r1 = r + nwl;
+                const bool has1 = r1 < p.M;
+                float4 x2[LNV], sl2[NSL][LNV], x3[LNV], sl3[NSL][LNV];
+                f16x4 te2[LNV], te3[LNV];
+                int tok2 = 0, pos2 = 0, tok3 = 0, pos3 = 0;
+                request_row(r, x2, sl2, te2, tok2, pos2);
+                request_row(has1 ? r1 : r, x3, sl3, te3, tok3, pos3);
+                combine_row(r, true, x2, sl2, te2, tok2, pos2);
+                ln_row(x2, r, true);
+                combine_row(has1 ? r1 : r, has1, x3, sl3, te3, tok3, pos3);
+                ln_row(x3, has1 ? r1 : r, has1);
+            }
         }
         WLX_TR_MARK(1);
         __syncthreads();
@@ -839,6 +860,12 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB) ? 512 : 
         const int rr = (row_p < p.M) ? row_p : p.M - 1;
         if constexpr (OUT != GEMV_OUT_F32) bias_e = *reinterpret_cast<const float4*>(p.bias + n_p);
         if constexpr (OUT == GEMV_OUT_RESID) res_e = *reinterpret_cast<const float4*>(p.Xres + (long)rr * p.ldxres + n_p);
+        if constexpr (OUT == GEMV_OUT_RESID && XS == GEMV_X_SLABS) {
+#pragma unroll
+            for (int sl = 0; sl < WLX_FC2_KS; ++sl)
+                slab_e[sl] = *reinterpret_cast<const float4*>(p.slab + sl * p.slab_stride + (long)rr * p.ldxres + n_p);
+        }
+        if constexpr (OUT == GEMV_OUT_SLAB) { if (blockIdx.y != 0) bias_e = make_float4(0.f, 0.f, 0.f, 0.f); }
         if constexpr (OUT == GEMV_OUT_QKV) { rc_e = p.row_cache[rr]; rp_e = p.row_pos[rr]; }
     }
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -919,16 +946,16 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     if (p.xsrc != GEMV_X_PLAIN) {
         const bool ln_ok = p.in_mode == GEMV_IN_LN && p.out_mode == GEMV_OUT_QKV;
         const bool res_ok = p.in_mode == GEMV_IN_F16 && p.out_mode == GEMV_OUT_RESID && p.xsrc == GEMV_X_SLABS;
-        if (p.M > 16 || !(ln_ok || res_ok)) return c;
+        if (!(ln_ok || res_ok)) return c;
     }
     int KTf = p.KT;                                                           // k-tiles one workgroup multiplies
     if (p.out_mode == GEMV_OUT_SLAB) {
-        if (p.M > 16 || p.KTS < 1 || p.KT % p.KTS || p.KT / p.KTS != WLX_FC2_KS) return c;
+        if (p.KTS < 1 || p.KT % p.KTS || p.KT / p.KTS != WLX_FC2_KS) return c;
         KTf = p.KTS;
     }
     static const int f16cap = [] { const char* e = getenv("WLX_GEMV_F16_NW"); return e ? atoi(e) : 16; }();
     static const bool xattn_nw8 = [] { const char* e = getenv("WLX_XATTN_NW8"); return e && e[0] == '1'; }();   // measured equal to 4 + helpers (profiles/r2h_*): off
-    const int cap = (p.in_mode == GEMV_IN_F16 && p.out_mode != GEMV_OUT_SLAB) ? f16cap : 8;
+    const int cap = (p.in_mode == GEMV_IN_F16 && p.out_mode != GEMV_OUT_SLAB && p.M <= 16) ? f16cap : 8;
     // exact factorisation KTf = nw * CH * NCH, CH in {6, 5, 4}: fewest chunks first, then the widest chunk
     int best_nch = 1 << 30;
     if (p.in_mode == GEMV_IN_LN && p.xsrc != GEMV_X_PLAIN) {
@@ -963,6 +990,10 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
         c.LNV = p.K / 256;
     }
     c.NTB = (p.out_mode == GEMV_OUT_F32 && p.N > 8192) ? 2 : 1;
+    // more 16-column tiles than CUs (large-v3's first MLP projection: 320): two tiles per workgroup keep the launch to one
+    // round of workgroups and halve the redundant LayerNorm prologues. WLX_GELU_NTB2=0 keeps one tile (A/B).
+    static const bool gelu_ntb2 = [] { const char* e = getenv("WLX_GELU_NTB2"); return !(e && e[0] == '0'); }();
+    if (gelu_ntb2 && p.in_mode == GEMV_IN_LN && p.out_mode == GEMV_OUT_GELU_F16 && p.xsrc == GEMV_X_PLAIN && (p.N + 15) / 16 > 256 && ((p.N + 15) / 16) % 2 == 0) c.NTB = 2;
     c.MT = (p.M + 15) / 16;
     c.shm = sizeof(float) * (size_t)c.nw * c.NTB * c.MT * 256;
     const size_t xs_bytes = (size_t)p.M * (KTf * 32 + 8) * sizeof(half_t);    // fp16 activation rows
@@ -980,7 +1011,10 @@ static bool gemv2_launch_ln(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, d
     switch (p.out_mode) {
         case GEMV_OUT_QKV: WLX_G2(GEMV_OUT_QKV, 1, GEMV_X_PLAIN); return true;
         case GEMV_OUT_F16: WLX_G2(GEMV_OUT_F16, 1, GEMV_X_PLAIN); return true;
-        case GEMV_OUT_GELU_F16: WLX_G2(GEMV_OUT_GELU_F16, 1, GEMV_X_PLAIN); return true;
+        case GEMV_OUT_GELU_F16:
+            if (c.NTB == 2) WLX_G2(GEMV_OUT_GELU_F16, 2, GEMV_X_PLAIN);
+            else WLX_G2(GEMV_OUT_GELU_F16, 1, GEMV_X_PLAIN);
+            return true;
         case GEMV_OUT_F32:
             if (c.NTB == 2) WLX_G2(GEMV_OUT_F32, 2, GEMV_X_PLAIN);
             else WLX_G2(GEMV_OUT_F32, 1, GEMV_X_PLAIN);
@@ -990,19 +1024,23 @@ static bool gemv2_launch_ln(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, d
 #undef WLX_G2
 }
 // the first projection of a layer reading slab / embedding rows (one row tile): its own (CH, LNV) pairs, see gemv2_cfg
+template <int CH, int LNV, int MT>
+static bool gemv2_launch_qkv_xs_mt(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, dim3 block, hipStream_t s) {
+    if (p.xsrc == GEMV_X_SLABS) g2_launch<CH, LNV, GEMV_IN_LN, GEMV_OUT_QKV, 1, MT, GEMV_X_SLABS>(grid, block, c.shm, s, p);
+    else g2_launch<CH, LNV, GEMV_IN_LN, GEMV_OUT_QKV, 1, MT, GEMV_X_EMBED>(grid, block, c.shm, s, p);
+    return true;
+}
 template <int CH, int LNV>
 static bool gemv2_launch_qkv_xs(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, dim3 block, hipStream_t s) {
-    if (p.xsrc == GEMV_X_SLABS) g2_launch<CH, LNV, GEMV_IN_LN, GEMV_OUT_QKV, 1, 1, GEMV_X_SLABS>(grid, block, c.shm, s, p);
-    else g2_launch<CH, LNV, GEMV_IN_LN, GEMV_OUT_QKV, 1, 1, GEMV_X_EMBED>(grid, block, c.shm, s, p);
-    return true;
+    return c.MT == 1 ? gemv2_launch_qkv_xs_mt<CH, LNV, 1>(p, c, grid, block, s)
+         : c.MT == 2 ? gemv2_launch_qkv_xs_mt<CH, LNV, 2>(p, c, grid, block, s)
+                     : gemv2_launch_qkv_xs_mt<CH, LNV, 3>(p, c, grid, block, s);
 }
 template <int CH, int MT>
 static bool gemv2_launch_other(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, dim3 block, hipStream_t s) {
     if (p.in_mode == GEMV_IN_F16) {
-        if constexpr (MT == 1) {
-            if (p.out_mode == GEMV_OUT_SLAB) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_SLAB, 1, 1, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
-            if (p.xsrc == GEMV_X_SLABS) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, 1, GEMV_X_SLABS>(grid, block, c.shm, s, p); return true; }
-        }
+        if (p.out_mode == GEMV_OUT_SLAB) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_SLAB, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
+        if (p.xsrc == GEMV_X_SLABS) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, MT, GEMV_X_SLABS>(grid, block, c.shm, s, p); return true; }
         g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p);
     } else g2_launch<CH, 1, GEMV_IN_XATTN, GEMV_OUT_RESID, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p);
     return true;
@@ -1019,7 +1057,7 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
     dim3 grid((NT_total + c.NTB - 1) / c.NTB, p.out_mode == GEMV_OUT_SLAB ? p.KT / p.KTS : 1), block(c.nw * 64);
     if (p.in_mode == GEMV_IN_XATTN) {      // helper waves for the combine: one thread per (row, head, 4-float group), <= 1024
         const int want = (p.M * p.H * 8 + 63) / 64;
-        block.x = 64 * std::max(c.nw, std::min(16, want));
+        block.x = 64 * std::max(c.nw, std::min(c.MT > 1 ? 8 : 16, want));
     }
 #define WLX_G2_LN(CH_, LNV_) (c.MT == 1 ? gemv2_launch_ln<CH_, LNV_, 1>(p, c, grid, block, s) : c.MT == 2 ? gemv2_launch_ln<CH_, LNV_, 2>(p, c, grid, block, s) : gemv2_launch_ln<CH_, LNV_, 3>(p, c, grid, block, s))
 #define WLX_G2_OT(CH_) (c.MT == 1 ? gemv2_launch_other<CH_, 1>(p, c, grid, block, s) : c.MT == 2 ? gemv2_launch_other<CH_, 2>(p, c, grid, block, s) : gemv2_launch_other<CH_, 3>(p, c, grid, block, s))
@@ -1070,13 +1108,13 @@ bool dec_gemv_is_lean(const GemvParams& p) { return gemv2_ok(p, nullptr); }
 int dec_gemv_slab_split(int M, int K, int N) {
     static const int ks_env = [] { const char* e = getenv("WLX_FC2_KS"); return e ? atoi(e) : WLX_FC2_KS; }();
     if (ks_env != WLX_FC2_KS || WLX_FC2_KS < 2) return 0;                     // (the slab count is a compile-time constant of the consumers)
-    if (g_decode_v1 || M < 1 || M > 16 || K % 32 || (K / 32) % WLX_FC2_KS || K < 2048) return 0;
+    if (g_decode_v1 || M < 1 || M > 48 || K % 32 || (K / 32) % WLX_FC2_KS || K < 2048) return 0;
     GemvParams p{};
     p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_SLAB; p.M = M; p.K = K; p.KT = K / 32; p.N = N; p.KTS = p.KT / WLX_FC2_KS;
     static const float dummy_bias = 0.f;
     p.bias = &dummy_bias;                                                     // (cfg only asks whether there is one)
     Gemv2Cfg c;
-    if (!gemv2_ok(p, &c) || !c.xstage) return 0;
+    if (!gemv2_ok(p, &c) || (M <= 16 && !c.xstage)) return 0;
     return WLX_FC2_KS;
 }
 

@@ -489,7 +489,7 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         CKR(dalloc(s->allocs, &s->qd, (size_t)RC * d));
         CKR(dalloc(s->allocs, &s->attnd, (size_t)RC * d));
         CKR(dalloc(s->allocs, &s->hd, (size_t)RC * F));
-        CKR(dalloc(s->allocs, &s->slab, (size_t)WLX_FC2_KS * 16 * d));
+        CKR(dalloc(s->allocs, &s->slab, (size_t)WLX_FC2_KS * 48 * d));
         CKR(dalloc(s->allocs, &s->part_o, (size_t)s->groups_cap * e->H * WLX_XSPLIT * 16 * 64));
         CKR(dalloc(s->allocs, &s->part_ml, (size_t)s->groups_cap * e->H * WLX_XSPLIT * 16 * 2));
         s->ldl = ((sp.vocab + 15) / 16) * 16;
@@ -787,7 +787,7 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
         p.Yh = s->qd; p.ldyh = d; p.d = d; p.qscale = 0.125f;
         p.Kc = s->kc + (size_t)l * s->cache_rows * crs; p.Vc = s->vc + (size_t)l * s->cache_rows * crs; p.cache_row_stride = crs;
         p.row_cache = s->d_cache; p.row_pos = s->d_pos; p.done = done;
-        p.xsrc = xsrc; p.slab = s->slab; p.slab_stride = (long)16 * d;
+        p.xsrc = xsrc; p.slab = s->slab; p.slab_stride = (long)48 * d;
         if (xsrc == GEMV_X_EMBED) {
             p.tok_emb = e->tok_emb16; p.pos_emb = e->dec_pos; p.emb_token = s->d_token; p.intok = s->d_intok;
             p.Xres = s->xd; p.ldxres = d;
@@ -799,7 +799,7 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
         GemvParams p{};
         p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
         p.Wp = w.Wo; p.bias = w.bo; p.Xh = s->attnd; p.ldxh = d; p.Xres = s->xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
-        p.xsrc = xsrc; p.slab = s->slab; p.slab_stride = (long)16 * d;
+        p.xsrc = xsrc; p.slab = s->slab; p.slab_stride = (long)48 * d;
         return p;
     };
     auto vocab_params = [&](int xsrc) {
@@ -807,7 +807,7 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
         p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_F32; p.M = rows; p.K = d; p.KT = d / 32; p.N = sp.vocab;
         p.Wp = e->Wvocab; p.bias = nullptr; p.X = s->xd; p.ldx = d; p.gamma = e->dec_ln_g; p.beta = e->dec_ln_b;
         p.Y = s->logits; p.ldy = s->ldl; p.qscale = 1.f; p.done = done;
-        p.xsrc = xsrc; p.slab = s->slab; p.slab_stride = (long)16 * d;
+        p.xsrc = xsrc; p.slab = s->slab; p.slab_stride = (long)48 * d;
         return p;
     };
     // ---- what this pass may use (decided once, from the shapes only — never from what a profiling filter lets through):
@@ -816,7 +816,7 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
     static const bool no_fold = [] { const char* v = getenv("WLX_NO_EMBED_FOLD"); return v && v[0] == '1'; }();
     int KS = dec_gemv_slab_split(rows, F, d);
     if (KS && !(dec_gemv_is_lean(qkv_params(0, GEMV_X_SLABS)) && dec_gemv_is_lean(oproj_params(0, GEMV_X_SLABS)))) KS = 0;
-    const bool fold_embed = !no_fold && rows <= 16 && dec_gemv_is_lean(qkv_params(0, GEMV_X_EMBED));
+    const bool fold_embed = !no_fold && rows <= 48 && dec_gemv_is_lean(qkv_params(0, GEMV_X_EMBED));
     if (!fold_embed)
         plaunch(s, "dec_embed_kernel", (double)rows * d * (2 + 4), [&] { launch_dec_embed(e->tok_emb16, e->dec_pos, d, rt, rows, s->xd, done, st); });
     bool slabs_pending = false;             // the residual stream is xd + slabs until the next residual update writes the sum back
@@ -874,7 +874,7 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
         // the last layer keeps the single launch: its consumer would be the vocabulary projection, thousands of workgroups
         // that would each sum the slabs (measured: +2.2 us there against 1.2 us saved here, profiles/r2f_*)
         if (KS && l + 1 < sp.dec_layers) {
-            p.out_mode = GEMV_OUT_SLAB; p.KTS = p.KT / KS; p.slab = s->slab; p.slab_stride = (long)16 * d;
+            p.out_mode = GEMV_OUT_SLAB; p.KTS = p.KT / KS; p.slab = s->slab; p.slab_stride = (long)48 * d;
             slabs_pending = true;
         }
         pgemv(s, p);
