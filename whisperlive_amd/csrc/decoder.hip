@@ -1606,6 +1606,53 @@ void launch_dec_cq_cross_attn(const float* X, long ldx, const float* gamma, cons
                        Wp, bias, qscale, KT, Kp, Vp, item_stride, H, R, rows, group_item, part_o, part_ml WLX_TR_ARG("cq_cross_attn"));
 }
 
+// ------------------------------------------------------------------ split combine of the cross attention, on its own
+// For batched rows (> 16) the fused form — every workgroup of the output projection combining ALL rows' eight split
+// partials in its prologue — costs 12 us of a 14.6 us launch at 40 rows x 20 heads (80 workgroups each looping 13 times
+// over 6400 (row, head, 8-dim) items; profiles/r2s decode-step timeline). Here one thread per item does it once, the
+// result goes to the fp16 attention rows and the projection runs as a plain fp16-rows-in launch. (Up to 16 rows the fused
+// form stays: one trip, no extra launch.)
+__global__ __launch_bounds__(256) void dec_xattn_combine_kernel(const half_t* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                                int M, int H, int R, half_t* __restrict__ out, long ldo WLX_TR_PARAM) {
+    WLX_TR_BEGIN();
+    const int it0 = blockIdx.x * 256 + threadIdx.x;
+    const bool live = it0 < M * H * 8;
+    const int it = live ? it0 : M * H * 8 - 1;              // (clamped: every thread runs the same code; only live ones store)
+    const int q8 = it & 7, hm = it >> 3;
+    const int m = hm / H, hh = hm - m * H;
+    const int item = m / R, qi = m - item * R;
+    const long ih = (long)item * H + hh;
+    const float4* mlp = reinterpret_cast<const float4*>(part_ml + (ih * 16 + qi) * (WLX_XSPLIT * 2));
+    const half_t* op = part_o + (ih * WLX_XSPLIT * 16 + qi) * 64 + q8 * 8;
+    float4 ml[WLX_XSPLIT / 2];
+    f16x8 ov[WLX_XSPLIT];
+#pragma unroll
+    for (int sp = 0; sp < WLX_XSPLIT / 2; ++sp) ml[sp] = mlp[sp];
+#pragma unroll
+    for (int sp = 0; sp < WLX_XSPLIT; ++sp) ov[sp] = ld_f16x8(op + sp * 1024);
+    float mmax = fmaxf(ml[0].x, ml[0].z);
+#pragma unroll
+    for (int sp = 1; sp < WLX_XSPLIT / 2; ++sp) mmax = fmaxf(mmax, fmaxf(ml[sp].x, ml[sp].z));
+    float den = 0.f;
+    float num[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sp = 0; sp < WLX_XSPLIT; ++sp) {        // (the arithmetic and its order are the fused combine's: identical rows)
+        const float mm = (sp & 1) ? ml[sp >> 1].z : ml[sp >> 1].x, ll = (sp & 1) ? ml[sp >> 1].w : ml[sp >> 1].y;
+        const float w = __expf(mm - mmax) * ll;
+        den += w;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) num[e] += w * (float)ov[sp][e];
+    }
+    const float inv = 1.0f / den;
+    const f16x8 hv = {(half_t)(num[0] * inv), (half_t)(num[1] * inv), (half_t)(num[2] * inv), (half_t)(num[3] * inv),
+                      (half_t)(num[4] * inv), (half_t)(num[5] * inv), (half_t)(num[6] * inv), (half_t)(num[7] * inv)};
+    if (live) *reinterpret_cast<f16x8*>(out + (long)m * ldo + hh * 64 + q8 * 8) = hv;
+    WLX_TR_END(trc);
+}
+void launch_dec_xattn_combine(const half_t* part_o, const float* part_ml, int M, int H, int R, half_t* out, long ldo, hipStream_t s) {
+    hipLaunchKernelGGL(dec_xattn_combine_kernel, dim3((M * H * 8 + 255) / 256), dim3(256), 0, s, part_o, part_ml, M, H, R, out, ldo WLX_TR_ARG("xattn_combine"));
+}
+
 // ------------------------------------------------------------------ cross-attention scores of one head, for word alignment
 // (ctranslate2 Whisper.align, called from transcriber_faster_whisper.py:1657: the QK of the alignment heads over a
 // teacher-forced pass). Raw scores q.k (q already carries head_dim^-0.5) of `rows` query rows against the 1536 padded

@@ -861,6 +861,12 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
         p.in_mode = GEMV_IN_XATTN; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
         p.Wp = w.Wco; p.bias = w.bco; p.part_o = s->part_o; p.part_ml = s->part_ml; p.H = H; p.R = R;
         p.Xres = s->xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
+        static const bool no_sep = [] { const char* v = getenv("WLX_XATTN_SEPARATE"); return v && v[0] == '0'; }();   // (A/B)
+        if (rows > 16 && !no_sep) {
+            // batched rows: the split combine once, in its own launch, then a plain fp16-rows-in projection (decoder.hip)
+            plaunch(s, "dec_xattn_combine_kernel", 0.0, [&] { launch_dec_xattn_combine(s->part_o, s->part_ml, rows, H, R, s->attnd, d, st); });
+            p.in_mode = GEMV_IN_F16; p.Xh = s->attnd; p.ldxh = d;
+        }
         pgemv(s, p);
         // LN3 + MLP
         p = GemvParams{};
