@@ -921,11 +921,13 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
 template <int CH, int LNV, int IN, int OUT, int NTB, int MT, int XS>
 static void g2_launch(dim3 grid, dim3 block, size_t shm, hipStream_t s, const GemvParams& p) {
     if (shm > 64 * 1024) {
-        static size_t granted = 0;
-        if (shm > granted) {
+        static bool granted[64] = {};                       // per device: the opt-in is a property of the function ON a device
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && !granted[dev]) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemv2_kernel<CH, LNV, IN, OUT, NTB, MT, XS>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, WLX_G2_LDS_MAX);
-            granted = WLX_G2_LDS_MAX;
+            granted[dev] = true;
         }
     }
     hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, IN, OUT, NTB, MT, XS>), grid, block, shm, s, p);
