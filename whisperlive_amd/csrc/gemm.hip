@@ -389,8 +389,9 @@ static hipError_t gemm2_optin() {      // > 64 KiB of dynamic LDS needs the opt-
 // 160 KiB of LDS, i.e. 120 KiB of fills in flight per CU), not fewer, larger tiles. WLX_GEMM2_SHAPE=i forces entry i.
 // Measured later in round 2 and NOT adopted (encoder-only runs, profiles/r2q / r2v): a ring of 7 stages (140 KiB) for the
 // launches with <= 1 workgroup per CU (1.65 vs 1.63 ms), every LDS fragment read of a stage issued before its first MFMA
-// (sched_barrier; 1.62-1.65 vs 1.61-1.63), 64 x 64 or 64 x 128 tiles for the N = d_model GEMMs (1.71-1.75 / 1.73): neither
-// the fill latency nor the LDS read latency of a stage is what its 0.7 us (12 MFMAs = 0.08 us) are spent on.
+// (sched_barrier; 1.62-1.65 vs 1.61-1.63), 64 x 64 or 64 x 128 tiles for the N = d_model GEMMs (1.71-1.75 / 1.73), four k-tiles per stage
+// with a ring of 3 (half the barriers: 1.74): neither the fill latency, nor the LDS read latency, nor the barrier count of a
+// stage is what its 0.7 us (12 MFMAs = 0.08 us) are spent on.
 static int gemm2_pick(const GemmParams& p, int zbatch) {
     static const int forced = [] { const char* e = getenv("WLX_GEMM2_SHAPE"); return e ? atoi(e) : -1; }();
     const int n_shapes = (int)(sizeof(kGemm2Shapes) / sizeof(kGemm2Shapes[0]));
