@@ -172,6 +172,8 @@ void launch_search_scan3(const float* logits, long ldl, int V, const SearchParam
                          hipStream_t s);
 void launch_search_merge_update3(const float* logits, long ldl, int V, const SearchParams* sp_dev, int items,
                                  const SearchState& st, hipStream_t s);
+// zero the per-call search state (step, done, finished counters, per-item / per-row flags, hypothesis lengths)
+void launch_search_reset(const SearchState& st, int items, int rows, hipStream_t s);
 // softmax over ids [0, vlim) of row r, probability of token toks[r] -> out[r]   (text_token_probs of Whisper.align)
 void launch_token_prob_rows(const float* logits, long ldl, int vlim, int rows, const int* toks, float* out, hipStream_t s);
 // softmax prob of token `tok` in given logits rows -> out[rows]

@@ -75,6 +75,9 @@ struct Slot {
     int* d_lang_ids = nullptr; float* d_probs = nullptr; float* d_tokprob = nullptr;
     // pinned host staging
     int* h_stage = nullptr; size_t h_stage_ints = 0;
+    // pinned staging of wlx_generate: set-up tables in (one async copy each, no synchronisation) and results out
+    unsigned char* h_gen = nullptr; size_t h_gen_bytes = 0;
+    std::vector<int> last_suppress; bool suppress_valid = false;   // the suppress mask on the device was built from this list
     std::map<StepGraphKey, hipGraphExec_t> graphs;
     wlx_timings tm{};
     Prof* prof = nullptr;

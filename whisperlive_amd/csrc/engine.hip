@@ -381,6 +381,7 @@ static void slot_free(Slot* s) {
     for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void* p : s->allocs) (void)hipFree(p);
     if (s->h_stage) (void)hipHostFree(s->h_stage);
+    if (s->h_gen) (void)hipHostFree(s->h_gen);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->ev_poll0) (void)hipEventDestroy(s->ev_poll0);
@@ -530,6 +531,11 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         CK(hipHostMalloc(reinterpret_cast<void**>(&s->h_stage), s->h_stage_ints * sizeof(int), hipHostMallocDefault));
         // the search kernels raise this pinned word themselves when every item is finished (no per-step D2H copy)
         s->st.done_host = s->h_stage + (s->h_stage_ints - 4);
+        // wlx_generate's pinned staging: [set-up: SearchParams | cum | rule | plen | nsp | ancestry rows] [results: n_hyp |
+        // hyp_len | hyp_score | no_speech | step | hyp_tokens]
+        s->h_gen_bytes = 4096 + (size_t)RC * (4 + 16 + 4) + (size_t)B * 4 + (size_t)RC * WLX_T_TEXT * 2 + 256 + ((size_t)RC * 4 + B) * 4 + 128 +
+                         (size_t)B * (4 + WLX_MAX_HYP * 8 + 4) + 64 + (size_t)B * WLX_MAX_HYP * WLX_T_TEXT * 4;
+        CK(hipHostMalloc(reinterpret_cast<void**>(&s->h_gen), s->h_gen_bytes, hipHostMallocDefault));
         CK(hipStreamSynchronize(s->stream));      // (allocations were zeroed on the utility stream and waited for in dalloc)
         return WLX_OK;
     }();
@@ -890,13 +896,16 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
 
 // upload row tables for a pass: token/pos/cache/ancrow [rows], group_item [groups]
 static int upload_rows(Slot* s, const std::vector<int>& token, const std::vector<int>& pos,
-                       const std::vector<int>& cache, const std::vector<int>& ancrow, const std::vector<int>& group_item) {
+                       const std::vector<int>& cache, const std::vector<int>& ancrow, const std::vector<int>& group_item,
+                       int* own_staging = nullptr) {
     const size_t rows = token.size(), ng = group_item.size();
     if (4 * rows + ng > s->h_stage_ints) return fail(WLX_ERR_ARG, "row table too large");
     s->anc_ident = true;                                    // every row reads its history through its own ancestry row
     for (size_t i = 0; i < rows; ++i) s->anc_ident = s->anc_ident && ancrow[i] == (int)i;
-    CK(hipStreamSynchronize(s->stream));   // staging buffer reuse
-    int* h = s->h_stage;
+    // the shared staging buffer may still be the source of an earlier pass's copies: wait; a caller that brings its own
+    // pinned area (wlx_generate: written once per call) does not have to
+    if (!own_staging) CK(hipStreamSynchronize(s->stream));
+    int* h = own_staging ? own_staging : s->h_stage;
     memcpy(h, token.data(), rows * 4); memcpy(h + rows, pos.data(), rows * 4);
     memcpy(h + 2 * rows, cache.data(), rows * 4); memcpy(h + 3 * rows, ancrow.data(), rows * 4);
     memcpy(h + 4 * rows, group_item.data(), ng * 4);
@@ -1041,6 +1050,11 @@ static int validate_opts(Engine* e, Slot* s, int batch, const wlx_gen_opts* o) {
 
 static int upload_suppress(Engine* e, Slot* s, const wlx_gen_opts* o) {
     const int V = e->spec.vocab, words = (V + 31) / 32;
+    // a session passes the same list on every call: the mask on the device is then already the right one
+    if (s->suppress_valid && (int)s->last_suppress.size() == o->n_suppress_tokens &&
+        (o->n_suppress_tokens == 0 || memcmp(s->last_suppress.data(), o->suppress_tokens, (size_t)o->n_suppress_tokens * 4) == 0))
+        return WLX_OK;
+    s->suppress_valid = false;
     std::vector<unsigned> mask(words, 0u);
     for (int i = 0; i < o->n_suppress_tokens; ++i) {
         const int id = o->suppress_tokens[i];
@@ -1048,6 +1062,8 @@ static int upload_suppress(Engine* e, Slot* s, const wlx_gen_opts* o) {
     }
     CK(hipMemcpyAsync(s->d_suppress, mask.data(), words * 4, hipMemcpyHostToDevice, s->stream));
     CK(hipStreamSynchronize(s->stream));
+    s->last_suppress.assign(o->suppress_tokens, o->suppress_tokens + o->n_suppress_tokens);
+    s->suppress_valid = true;
     return WLX_OK;
 }
 
@@ -1079,35 +1095,42 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
     }
     CK(hipEventRecord(s->ev0, st));
     CKR(upload_suppress(e, s, o));
-    SearchParams sp;
-    CKR(fill_search_params(e, s, batch, R, o, apply_ts, &sp));
-    CK(hipMemcpyAsync(s->d_sp, &sp, sizeof(sp), hipMemcpyHostToDevice, st));
-    // ---- reset search state
+    // ---- per-call state: everything the host prepares goes through the slot's pinned staging (h_gen) — asynchronous
+    // copies with no synchronisation in between (pageable sources made every one of them a blocking, bounce-buffered copy)
+    // — and the zeroing is one launch. The staging is only rewritten by the next call, after this one's final wait.
     SearchState& S = s->st;
-    CK(hipMemsetAsync(S.step, 0, 4, st)); CK(hipMemsetAsync(S.done, 0, 4, st)); CK(hipMemsetAsync(S.n_finished, 0, 4, st));
-    CK(hipMemsetAsync(S.item_done, 0, (size_t)batch * 4, st)); CK(hipMemsetAsync(S.n_hyp, 0, (size_t)batch * 4, st));
-    CK(hipMemsetAsync(S.row_done, 0, (size_t)rows * 4, st)); CK(hipMemsetAsync(S.no_speech, 0, (size_t)batch * 4, st));
-    CK(hipMemsetAsync(S.hyp_len, 0, (size_t)batch * WLX_MAX_HYP * 4, st));
-    std::vector<float> cum(rows);
+    unsigned char* hg = s->h_gen;
+    SearchParams* h_sp = reinterpret_cast<SearchParams*>(hg);                       hg += 4096;
+    float* h_cum = reinterpret_cast<float*>(hg);                                    hg += (size_t)s->rows_cap * 4;
+    int* h_rule = reinterpret_cast<int*>(hg);                                       hg += (size_t)s->rows_cap * 16;
+    int* h_nsp = reinterpret_cast<int*>(hg);                                        hg += (size_t)s->rows_cap * 4;
+    int* h_plen = reinterpret_cast<int*>(hg);                                       hg += (size_t)s->B * 4;
+    short* h_anc = reinterpret_cast<short*>(hg);                                    hg += (size_t)s->rows_cap * WLX_T_TEXT * 2 + 192;
+    int* h_rows = reinterpret_cast<int*>(hg);                                       hg += ((size_t)s->rows_cap * 4 + s->B) * 4 + 64;
+    unsigned char* h_res = s->h_gen + ((hg - s->h_gen + 63) / 64) * 64;
+    static_assert(sizeof(SearchParams) <= 4096, "SearchParams staging");
+    CKR(fill_search_params(e, s, batch, R, o, apply_ts, h_sp));
+    CK(hipMemcpyAsync(s->d_sp, h_sp, sizeof(SearchParams), hipMemcpyHostToDevice, st));
+    launch_search_reset(S, batch, rows, st);
     std::vector<int> nsp(rows, 0), pl(batch);
-    std::vector<short> anc((size_t)rows * WLX_T_TEXT, 0);
+    memset(h_anc, 0, (size_t)rows * WLX_T_TEXT * 2);
     for (int b = 0; b < batch; ++b) {
         pl[b] = plens[b];
+        h_plen[b] = plens[b];
         for (int r = 0; r < R; ++r) {
             const int row = b * R + r;
-            cum[row] = (sampling || r == 0) ? 0.f : -INFINITY;
-            short* a = anc.data() + (size_t)row * WLX_T_TEXT;
+            h_cum[row] = (sampling || r == 0) ? 0.f : -INFINITY;
+            short* a = h_anc + (size_t)row * WLX_T_TEXT;
             for (int p = 0; p < pl[b] - 1; ++p) a[p] = (short)(b * R);   // prompt K/V live in the item's first cache row
             a[pl[b] - 1] = (short)row;
+            // rule state before the first generated token: no last token, "one before last" counts as a timestamp, no timestamp yet
+            h_rule[4 * row] = 0; h_rule[4 * row + 1] = 1; h_rule[4 * row + 2] = -1; h_rule[4 * row + 3] = 0;
         }
     }
-    CK(hipMemcpyAsync(S.cum, cum.data(), rows * 4, hipMemcpyHostToDevice, st));
-    // rule state before the first generated token: no last token, "one before last" counts as a timestamp, no timestamp yet
-    std::vector<int> rule0((size_t)rows * 4);
-    for (int r = 0; r < rows; ++r) { rule0[4 * r] = 0; rule0[4 * r + 1] = 1; rule0[4 * r + 2] = -1; rule0[4 * r + 3] = 0; }
-    CK(hipMemcpyAsync(S.rule, rule0.data(), rule0.size() * 4, hipMemcpyHostToDevice, st));
-    CK(hipMemcpyAsync(S.plen, pl.data(), batch * 4, hipMemcpyHostToDevice, st));
-    CKR(set_anc_rows(s, anc, 0, rows));
+    CK(hipMemcpyAsync(S.cum, h_cum, rows * 4, hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(S.rule, h_rule, (size_t)rows * 16, hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(S.plen, h_plen, batch * 4, hipMemcpyHostToDevice, st));
+    CK(hipMemcpyAsync(s->d_anc, h_anc, (size_t)rows * WLX_T_TEXT * sizeof(short), hipMemcpyHostToDevice, st));
     // ---- prefill prompt[0 .. plen-2]; no_speech_prob is read at the sot position
     if (!injected_logits) {
         for (int b = 0; b < batch; ++b) {
@@ -1130,9 +1153,9 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
                 tk[row] = prompts[(size_t)b * pstride + pl[b] - 1]; ps[row] = pl[b] - 1; ca[row] = row; an[row] = row;
             }
         }
-        CKR(upload_rows(s, tk, ps, ca, an, gi));
-        CK(hipMemcpyAsync(S.nsp_row, nsp.data(), rows * 4, hipMemcpyHostToDevice, st));
-        CK(hipStreamSynchronize(st));
+        CKR(upload_rows(s, tk, ps, ca, an, gi, h_rows));
+        memcpy(h_nsp, nsp.data(), (size_t)rows * 4);
+        CK(hipMemcpyAsync(S.nsp_row, h_nsp, rows * 4, hipMemcpyHostToDevice, st));     // (pinned: no wait needed before the loop)
     }
     // ---- autoregressive loop: one graph replay per step. The host never lets the stream run dry: step k+1 is
     // enqueued BEFORE the host looks at the done flag copied after step k (double-buffered pinned words, one event
@@ -1176,22 +1199,26 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
         }
     }
     const double tg2 = now_us();
-    CK(hipStreamSynchronize(st));
+    if (gen_trace) CK(hipStreamSynchronize(st));             // (only to tell the drain from the readback in the trace line)
     const double tg3 = now_us();
-    // ---- results
-    std::vector<int> n_hyp(batch), hyp_len((size_t)batch * WLX_MAX_HYP);
-    std::vector<float> hyp_score((size_t)batch * WLX_MAX_HYP), nspv(batch);
-    std::vector<int> hyp_tok((size_t)batch * WLX_MAX_HYP * WLX_T_TEXT);
-    // result readback on the SLOT stream (never the legacy stream: a synchronous hipMemcpy here would try to order the
-    // legacy stream against another slot's stream while that one is capturing its step graph, and fail both)
-    CK(hipMemcpyAsync(n_hyp.data(), S.n_hyp, batch * 4, hipMemcpyDeviceToHost, st));
-    CK(hipMemcpyAsync(hyp_len.data(), S.hyp_len, hyp_len.size() * 4, hipMemcpyDeviceToHost, st));
-    CK(hipMemcpyAsync(hyp_score.data(), S.hyp_score, hyp_score.size() * 4, hipMemcpyDeviceToHost, st));
-    CK(hipMemcpyAsync(hyp_tok.data(), S.hyp_tokens, hyp_tok.size() * 4, hipMemcpyDeviceToHost, st));
-    CK(hipMemcpyAsync(nspv.data(), S.no_speech, batch * 4, hipMemcpyDeviceToHost, st));
-    int step_dev = 0;
-    CK(hipMemcpyAsync(&step_dev, S.step, 4, hipMemcpyDeviceToHost, st));
+    // ---- results: into the pinned staging, on the SLOT stream (never the legacy stream: a synchronous hipMemcpy here would
+    // try to order the legacy stream against another slot's stream while that one is capturing its step graph, and fail
+    // both), ONE wait for the decode's tail, the copies and the timing event together
+    int* n_hyp = reinterpret_cast<int*>(h_res);
+    int* hyp_len = n_hyp + batch;
+    float* hyp_score = reinterpret_cast<float*>(hyp_len + (size_t)batch * WLX_MAX_HYP);
+    float* nspv = hyp_score + (size_t)batch * WLX_MAX_HYP;
+    int* step_dev_p = reinterpret_cast<int*>(nspv + batch);
+    int* hyp_tok = step_dev_p + 16;
+    CK(hipMemcpyAsync(n_hyp, S.n_hyp, batch * 4, hipMemcpyDeviceToHost, st));
+    CK(hipMemcpyAsync(hyp_len, S.hyp_len, (size_t)batch * WLX_MAX_HYP * 4, hipMemcpyDeviceToHost, st));
+    CK(hipMemcpyAsync(hyp_score, S.hyp_score, (size_t)batch * WLX_MAX_HYP * 4, hipMemcpyDeviceToHost, st));
+    CK(hipMemcpyAsync(hyp_tok, S.hyp_tokens, (size_t)batch * WLX_MAX_HYP * WLX_T_TEXT * 4, hipMemcpyDeviceToHost, st));
+    CK(hipMemcpyAsync(nspv, S.no_speech, batch * 4, hipMemcpyDeviceToHost, st));
+    CK(hipMemcpyAsync(step_dev_p, S.step, 4, hipMemcpyDeviceToHost, st));
+    CK(hipEventRecord(s->ev1, st));
     CK(hipStreamSynchronize(st));
+    const int step_dev = *step_dev_p;
     const int NH = std::max(1, o->num_hypotheses);
     for (int b = 0; b < batch; ++b) {
         std::vector<int> order(std::min(n_hyp[b], WLX_MAX_HYP));
@@ -1215,8 +1242,6 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
         }
         if (nsp_out) nsp_out[b] = nspv[b];
     }
-    CK(hipEventRecord(s->ev1, st));
-    CK(hipStreamSynchronize(st));
     CK(hipEventElapsedTime(&s->tm.generate_ms, s->ev0, s->ev1));
     s->tm.decode_steps = step_dev;
     if (gen_trace)
