@@ -114,6 +114,104 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
     }
 }
 
+// ---------------- LDS-transposed epilogue of the second form (round 2; the phase-removal probe of round 1,
+// profiles/r03m, priced the direct epilogue above at 35 % of the MLP-up launch and 27 % of the QKV launch: a wave-level
+// store of it covers 16 rows x 32 bytes, V^T and the tile-packed cross-V go out as 2-byte pieces). Here the workgroup's
+// 32 WNT x 32 WMT output tile goes through LDS once (the ring is free by then) as fp16 T[m][n] and leaves in the shape the
+// destination wants: row-major destinations (C, q, K rows, tile-packed cross-K) as 16-byte pieces, a wave covering 8 full
+// 128-byte rows; column-major ones (V^T, tile-packed cross-V) as 8-byte pieces of 4 consecutive rows.
+// Values are bit-identical to gemm_epilogue's. The fp32 modes keep the direct form (a lane already owns 16 bytes).
+template <int WNT, int WMT>
+__device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&acc)[WNT][WMT], half_t* T, int ntb, int mb, int wn, int wm,
+                                                  int z, int c, int g, int tid) {
+    constexpr int TN = 32 * WNT, TM = 32 * WMT, PT = TN + 8;         // tile columns / rows, LDS pitch in halfs (16-byte aligned rows)
+    const int n_wg = ntb * 16;                                        // first column of the workgroup (multiple of 32 WNT)
+    // what the workgroup's columns are (uniform: d_model is a multiple of the tile width)
+    int part = 0;                                                     // QKV: 0 q, 1 k, 2 v;  CROSS_KV: 0 k, 1 v
+    int layer = 0, col0 = n_wg;                                       // column inside its part
+    if (p.mode == GEMM_QKV) { part = n_wg / p.d; col0 = n_wg - part * p.d; }
+    else if (p.mode == GEMM_CROSS_KV) { layer = n_wg / (2 * p.d); const int nn = n_wg - layer * 2 * p.d; part = nn / p.d; col0 = nn - part * p.d; }
+    const float scale = (p.mode == GEMM_QKV && part == 0) ? p.qscale : 1.0f;
+#pragma unroll
+    for (int ni = 0; ni < WNT; ++ni) {
+        const int nl = (wn * WNT + ni) * 16 + g * 4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && n_wg + nl < p.N) bv = *reinterpret_cast<const float4*>(p.bias + n_wg + nl);
+#pragma unroll
+        for (int mi = 0; mi < WMT; ++mi) {
+            const int ml = (wm * WMT + mi) * 16 + c;
+            float v0 = acc[ni][mi][0] + bv.x, v1 = acc[ni][mi][1] + bv.y, v2 = acc[ni][mi][2] + bv.z, v3 = acc[ni][mi][3] + bv.w;
+            if (p.mode == GEMM_GELU_F16) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+            const f16x4 o = {(half_t)(v0 * scale), (half_t)(v1 * scale), (half_t)(v2 * scale), (half_t)(v3 * scale)};
+            *reinterpret_cast<f16x4*>(T + ml * PT + nl) = o;
+        }
+    }
+    __syncthreads();
+    const bool colmajor = (p.mode == GEMM_QKV && part == 2) || (p.mode == GEMM_CROSS_KV && part == 1);
+    if (!colmajor) {
+        // 16-byte pieces: (row, 8-column segment). Row-major destinations: segment fastest (a wave = 8 full rows);
+        // tile-packed cross-K: row fastest (16 consecutive keys of a segment are 256 contiguous bytes of the image)
+        constexpr int SEG = TN / 8, UNITS = TM * SEG;
+        for (int u = tid; u < UNITS; u += 256) {
+            int row, seg;
+            if (p.mode == GEMM_CROSS_KV) { seg = u / TM; row = u - seg * TM; } else { row = u / SEG; seg = u - row * SEG; }
+            const int m = mb + row, n = n_wg + seg * 8;
+            if (m >= p.M || n >= p.N) continue;
+            const f16x8 v = *reinterpret_cast<const f16x8*>(T + row * PT + seg * 8);
+            half_t* dst;
+            if (p.mode == GEMM_QKV) {
+                if (part == 0) dst = p.C + (long)m * p.ldc + n;
+                else {
+                    const int item = m / p.rows_per_item, t = m - item * p.rows_per_item;
+                    dst = p.Kout + (long)item * p.kv_item_stride_k + (long)t * p.ldk + (col0 + seg * 8);
+                }
+            } else if (p.mode == GEMM_CROSS_KV) {
+                const int item = m / p.rows_per_item, t = m - item * p.rows_per_item;
+                const int da = col0 + seg * 8, hd = da >> 6, dd = da & 63;
+                const int tile = t >> 5, k32 = t & 31;
+                const long tbase = ((long)hd * (WLX_T_AUDIO_PAD / 32) + tile) * 2048;
+                const int s2 = k32 >> 4, cc = k32 & 15, kt2 = dd >> 5, gg = (dd & 31) >> 3;
+                dst = p.Kout + (long)layer * p.kv_layer_stride_k + (long)item * p.kv_item_stride_k + tbase + ((s2 * 2 + kt2) * 64 + gg * 16 + cc) * 8;
+            } else dst = p.C + (long)z * p.strideC + (long)m * p.ldc + n;
+            *reinterpret_cast<f16x8*>(dst) = v;
+        }
+    } else {
+        // 8-byte pieces: (column, 4 consecutive rows); rows_per_item is a multiple of 4, so a piece never straddles two items
+        constexpr int MG = TM / 4, UNITS = TN * MG;
+        for (int u = tid; u < UNITS; u += 256) {
+            int col, mg;
+            if (p.mode == GEMM_CROSS_KV) { mg = u / TN; col = u - mg * TN; } else { col = u / MG; mg = u - col * MG; }
+            const int m0 = mb + mg * 4, n = n_wg + col;
+            if (m0 >= p.M || n >= p.N) continue;
+            const half_t* tp = T + (mg * 4) * PT + col;
+            const f16x4 v = {tp[0], tp[PT], tp[2 * PT], tp[3 * PT]};
+            const int item = m0 / p.rows_per_item, t = m0 - item * p.rows_per_item;
+            half_t* dst;
+            if (p.mode == GEMM_QKV) dst = p.Vt + (long)item * p.kv_item_stride_v + (long)(col0 + col) * p.ldvt + t;
+            else {
+                const int da = col0 + col, hd = da >> 6, dd = da & 63;
+                const int tile = t >> 5, k32 = t & 31;
+                const long tbase = ((long)hd * (WLX_T_AUDIO_PAD / 32) + tile) * 2048;
+                const int dt = dd >> 4, c0 = dd & 15, gg = (k32 & 15) >> 2, ee = (k32 >> 4) << 2;
+                dst = p.Vt + (long)layer * p.kv_layer_stride_v + (long)item * p.kv_item_stride_v + tbase + (dt * 64 + gg * 16 + c0) * 8 + ee;
+            }
+            if (m0 + 3 < p.M) *reinterpret_cast<f16x4*>(dst) = v;
+            else {                                                  // ragged last rows (M not a multiple of 4): element by element
+                for (int j = 0; j < 4 && m0 + j < p.M; ++j) {
+                    if (p.mode == GEMM_QKV) dst[j] = v[j];
+                    else {
+                        const int tj = t + j, k32j = tj & 31;
+                        const int da = col0 + col, hd = da >> 6, dd = da & 63;
+                        const long tb = ((long)hd * (WLX_T_AUDIO_PAD / 32) + (tj >> 5)) * 2048;
+                        p.Vt[(long)layer * p.kv_layer_stride_v + (long)item * p.kv_item_stride_v + tb +
+                             ((dd >> 4) * 64 + ((k32j & 15) >> 2) * 16 + (dd & 15)) * 8 + (k32j & 3) + ((k32j >> 4) << 2)] = v[j];
+                    }
+                }
+            }
+        }
+    }
+}
+
 template <int WNT, int WMT>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     constexpr int KS = 2;                       // k-tiles (of 32) per LDS stage
@@ -348,7 +446,13 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
         rbuf = (rbuf + 1 == DEPTH) ? 0 : rbuf + 1;
         wbuf = (wbuf + 1 == DEPTH) ? 0 : wbuf + 1;
     }
-    gemm_epilogue<WNT, WMT>(p, acc, nt0, m0, z, c, g);
+    // (no LDS-DMA is in flight any more: the tail of the loop drained it, so __syncthreads() is safe from here on)
+    const bool f16_out = p.mode == GEMM_STORE_F16 || p.mode == GEMM_GELU_F16 || p.mode == GEMM_QKV || p.mode == GEMM_CROSS_KV;
+    if (p.epi_lds && f16_out && (p.rows_per_item & 3) == 0 && (p.mode == GEMM_STORE_F16 || p.mode == GEMM_GELU_F16 || p.d % (32 * WNT) == 0)) {
+        __syncthreads();                                    // everyone is done reading the last stage: the ring becomes the tile
+        gemm_epilogue_lds<WNT, WMT>(p, acc, reinterpret_cast<half_t*>(ring), ntb, mb, wn, wm, z, c, g, tid);
+    } else
+        gemm_epilogue<WNT, WMT>(p, acc, nt0, m0, z, c, g);
 }
 
 // tile shapes of the second form: (WNT, WMT) wave tiles -> workgroup tile (32 WNT) x (32 WMT); ring depth by what fits
@@ -362,6 +466,9 @@ static void gemm2_go(const GemmParams& p0, int zbatch, hipStream_t s) {
     dim3 grid((NT_total + 2 * WNT - 1) / (2 * WNT), (p0.M + 32 * WMT - 1) / (32 * WMT), zbatch);
     GemmParams p = p0;
     p.xcd_a = p.xcd_b = 0;
+    static const bool epi_lds = [] { const char* e = getenv("WLX_GEMM_EPI_LDS"); return !(e && e[0] == '0'); }();   // 0 = direct epilogue (A/B)
+    p.epi_lds = epi_lds ? 1 : 0;
+    if (p.rows_per_item <= 0) p.rows_per_item = 4;          // (modes without items: only its divisibility is looked at)
     static const bool swz_on = [] { const char* e = getenv("WLX_GEMM2_XCD"); return !(e && e[0] == '0'); }();   // 0 = plain map (A/B)
     const int gx = (int)grid.x, gy = (int)grid.y;
     if (swz_on && zbatch == 1 && (gx * gy) % 8 == 0 && gx * gy >= 16) {
