@@ -412,12 +412,21 @@ __global__ __launch_bounds__(NW * 64) void attn_encoder_lds_kernel(const half_t*
         __builtin_amdgcn_s_barrier();
         if (ti + DEPTH - 1 < NT) issue(ti + DEPTH - 1, wbuf);
         const f16x8* src = aring + (long)rbuf * 8 * 64 + lane;
+        // all eight fragments of the tile are requested from LDS at once: the V^T reads then land under the score MFMAs and
+        // the softmax instead of costing a second exposed LDS round trip per tile (one wave per SIMD: nothing else hides it;
+        // SQ counters before: 47 % of the wave cycles parked at waits, profiles/r2z_pmc_sq_encoder.csv)
+        f16x8 kfr[4], vfr[4];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) kfr[f] = src[f * 64];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) vfr[f] = src[(4 + f) * 64];
+        __builtin_amdgcn_sched_barrier(0);
         f32x4 st[2];
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             st[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt) st[s] = mfma16(src[(s * 2 + kt) * 64], qf[kt], st[s]);
+            for (int kt = 0; kt < 2; ++kt) st[s] = mfma16(kfr[s * 2 + kt], qf[kt], st[s]);
         }
         float p[8];
         float tmax = WLX_NEG_INF;
@@ -447,7 +456,7 @@ __global__ __launch_bounds__(NW * 64) void attn_encoder_lds_kernel(const half_t*
             for (int dt = 0; dt < 4; ++dt) { acc[dt][0] *= al; acc[dt][1] *= al; acc[dt][2] *= al; acc[dt][3] *= al; }
         }
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma16(src[(4 + dt) * 64], pf, acc[dt]);
+        for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma16(vfr[dt], pf, acc[dt]);
         rbuf = (rbuf + 1 == DEPTH) ? 0 : rbuf + 1;
         wbuf = (wbuf + 1 == DEPTH) ? 0 : wbuf + 1;
     };
@@ -471,6 +480,9 @@ __global__ __launch_bounds__(NW * 64) void attn_encoder_lds_kernel(const half_t*
     }
 }
 
+// (Measured and dropped, profiles/r2z: a fourth form with TWO key tiles per ring stage — half the waits and barriers, the same
+// bytes in flight — runs at the third form's speed (1.58-1.61 ms per encoder for both), as do a ring of 7 and eight waves per
+// workgroup: the 47 % of wave cycles the SQ counters show parked are not the per-tile barrier or the fill latency.)
 int attn_prepare_device() { return 0; }                     // (the ring is 32 KiB: below the default dynamic-LDS limit)
 
 void launch_attn_encoder(const half_t* Q, long ldq, const half_t* K, long ldk, const half_t* Vt, long ldvt,
