@@ -482,7 +482,11 @@ __global__ __launch_bounds__(NW * 64) void attn_encoder_lds_kernel(const half_t*
 
 // (Measured and dropped, profiles/r2z: a fourth form with TWO key tiles per ring stage — half the waits and barriers, the same
 // bytes in flight — runs at the third form's speed (1.58-1.61 ms per encoder for both), as do a ring of 7 and eight waves per
-// workgroup: the 47 % of wave cycles the SQ counters show parked are not the per-tile barrier or the fill latency.)
+// workgroup: the 47 % of wave cycles the SQ counters show parked are not the per-tile barrier or the fill latency. A fifth
+// form — two waves per 16-query block, each walking every other key tile, merged through LDS at the end: 2.2 waves per
+// SIMD instead of 1.1 — is ALSO equal (1.57-1.59 ms, large-v3 7.60 vs 7.64 ms): a SIMD retires one 16-query x 32-key tile per
+// ~0.64 us however many waves share it, i.e. the kernel is bound by the ~170 instructions per tile (8 MFMAs, ~100 VALU of
+// which 9 quarter-rate exponentials, hazard nops), not by anything a second wave could hide.)
 int attn_prepare_device() { return 0; }                     // (the ring is 32 KiB: below the default dynamic-LDS limit)
 
 void launch_attn_encoder(const half_t* Q, long ldq, const half_t* K, long ldk, const half_t* Vt, long ldvt,
