@@ -498,7 +498,13 @@ static hipError_t gemm2_optin() {      // > 64 KiB of dynamic LDS needs the opt-
 // launches with <= 1 workgroup per CU (1.65 vs 1.63 ms), every LDS fragment read of a stage issued before its first MFMA
 // (sched_barrier; 1.62-1.65 vs 1.61-1.63), 64 x 64 or 64 x 128 tiles for the N = d_model GEMMs (1.71-1.75 / 1.73), four k-tiles per stage
 // with a ring of 3 (half the barriers: 1.74): neither the fill latency, nor the LDS read latency, nor the barrier count of a
-// stage is what its 0.7 us (12 MFMAs = 0.08 us) are spent on.
+// stage is what its 0.7 us (12 MFMAs = 0.08 us) are spent on. Phase-removal probes on this kernel (timing only, encoder-only
+// runs, 1.60 ms baseline): every fill re-reading stage 0's cache-hot lines 1.61 (so not L2 / HBM), NO fills after the prologue
+// 1.33, no MFMAs 1.53. What is left, and scales with co-resident workgroups per CU (36 workgroup-stages per CU take
+// 0.77 us each whether one or two workgroups share the CU), is the CU's LDS port: a stage moves 20 KiB in by LDS-DMA and
+// 40 KiB out through ds_read_b128 (five 1 KiB fragment reads per six MFMAs per wave). Next step for this kernel: weight
+// fragments straight from their packed global image into registers (inline-asm loads with hand-counted vmcnt beside the
+// LDS-DMA ring), activations only through LDS: -40 % LDS traffic per stage.
 static int gemm2_pick(const GemmParams& p, int zbatch) {
     static const int forced = [] { const char* e = getenv("WLX_GEMM2_SHAPE"); return e ? atoi(e) : -1; }();
     const int n_shapes = (int)(sizeof(kGemm2Shapes) / sizeof(kGemm2Shapes[0]));
