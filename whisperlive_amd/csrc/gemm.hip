@@ -505,6 +505,10 @@ static hipError_t gemm2_optin() {      // > 64 KiB of dynamic LDS needs the opt-
 // 40 KiB out through ds_read_b128 (five 1 KiB fragment reads per six MFMAs per wave). Next step for this kernel: weight
 // fragments straight from their packed global image into registers (inline-asm loads with hand-counted vmcnt beside the
 // LDS-DMA ring), activations only through LDS: -40 % LDS traffic per stage.
+// -> Built and measured (a third form: inline-asm global_load_dwordx4 into three rotating register sets, loop unrolled by
+// the ring depth, both queues counted by hand; bit-identical results): 1.586-1.591 ms vs 1.583-1.598 — no change either, so the
+// LDS port is not it; the kernel was dropped again. What the probes leave standing: ~0.45 us of a 0.64 us stage remain with
+// neither fills nor MFMAs, i.e. the per-stage wait + barrier + LDS-read + issue sequence of four lock-stepped waves itself.
 static int gemm2_pick(const GemmParams& p, int zbatch) {
     static const int forced = [] { const char* e = getenv("WLX_GEMM2_SHAPE"); return e ? atoi(e) : -1; }();
     const int n_shapes = (int)(sizeof(kGemm2Shapes) / sizeof(kGemm2Shapes[0]));
