@@ -58,3 +58,93 @@ def err_stats(a, b):
     return dict(max_abs=float(d.max()), mean_abs=float(d.mean()), ref_rms=float(np.sqrt((b ** 2).mean())),
                 rel_rms=float(np.sqrt((d ** 2).mean()) / (np.sqrt((b ** 2).mean()) + 1e-30)),
                 argmax=int(d.argmax()))
+
+
+def peaked_weights(spec: WhisperSpec, seed: int):
+    """Seeded weights whose next-token distributions are PEAKED and whose decodes are not degenerate (VERDICT r2 'weak' #3:
+    plain random weights give near-flat distributions, so a wrong-but-plausible beam hides inside the fp16-vs-fp32 noise
+    and parity has to accept near-ties). Built from ``random_weights`` by rescaling only:
+
+    * decoder final LayerNorm affine x8, tied token embedding x0.5: logits with a standard deviation of ~6 (top-1
+      probabilities of 5-60 %, candidate scores O(1) apart), while the 'repeat the token just fed' term E[tok].E[tok] of a
+      random tied embedding stays inside the spread of the other 51 k logits;
+    * learned decoder positions x25 (std 0.5) and the constant paths of the residual stream removed (decoder out_proj /
+      fc2 / v_proj biases zero, cross-attention output x0.3): the direction of the final hidden state changes from step to
+      step instead of being one constant vector, so the best token differs per step and per hypothesis;
+    * decoder attention queries x4 (self and cross): attention distributions are content-dependent instead of uniform, so a
+      wrong key index / ancestry row / position changes the logits by O(1) instead of O(1/t);
+    * decoder self-attention output and MLP output x2."""
+    from whisperlive_amd.weights import random_weights
+    w = random_weights(spec, seed=seed)
+    w["model.decoder.embed_tokens.weight"] *= np.float32(0.5)
+    w["model.decoder.embed_positions.weight"] *= np.float32(25.0)
+    w["model.decoder.layer_norm.weight"] *= np.float32(8.0)
+    w["model.decoder.layer_norm.bias"] *= np.float32(8.0)
+    for l in range(spec.dec_layers):
+        p = f"model.decoder.layers.{l}."
+        for a in ("self_attn", "encoder_attn"):
+            w[p + a + ".q_proj.weight"] *= np.float32(4.0)
+            w[p + a + ".q_proj.bias"] *= np.float32(4.0)
+            w[p + a + ".out_proj.weight"] *= np.float32(2.0 if a == "self_attn" else 0.3)
+            w[p + a + ".out_proj.bias"] *= np.float32(0.0)
+            w[p + a + ".v_proj.bias"] *= np.float32(0.0)
+        w[p + "fc2.weight"] *= np.float32(2.0)
+        w[p + "fc2.bias"] *= np.float32(0.0)
+    return w
+
+
+class NoisyProvider(NetProvider):
+    """The oracle network with seeded uniform noise of amplitude `amp` added to every logit: a decode whose tokens do
+    not change under noise several times larger than the GPU's measured logit error has no near-ties on its decision
+    path, so the GPU must reproduce it token for token."""
+
+    def __init__(self, model, enc, amp: float, seed: int):
+        super().__init__(model, enc)
+        self.amp, self.rng = np.float32(amp), np.random.default_rng(seed)
+
+    def step(self, tokens, parents):
+        lg = super().step(tokens, parents)
+        return lg + self.amp * self.rng.uniform(-1.0, 1.0, size=lg.shape).astype(np.float32)
+
+
+def decode_is_well_conditioned(model, enc, prompt, opts, ref, amp: float, seeds=(1, 2)) -> bool:
+    """True if the oracle's result `ref` is unchanged when every logit is perturbed by +-amp (two noise seeds)."""
+    for sd in seeds:
+        alt = odec.generate(NoisyProvider(model, enc, amp, sd), list(prompt), opts)
+        if alt.sequences_ids != ref.sequences_ids:
+            return False
+    return True
+
+
+def check_decode(oracle, enc, slot, ids, prompt, what, *, require_exact=True, noise_amp=0.02, enc_items=None, noise_seeds=(1, 2), **kw):
+    """GPU beam decode vs the oracle's. Well-conditioned case (the oracle's result survives +-noise_amp on every logit): the GPU
+    must reproduce every token and the score to 5e-3. Otherwise (a near-tie on the oracle's own decision path): the GPU's
+    sequence must be an equally good hypothesis UNDER THE ORACLE and its reported score the oracle's evaluation of it.
+    require_exact: the case is pinned as well-conditioned (scripts/scan_peaked_seeds.py) — fail if it is not."""
+    opts = odec.GenOptions(ids=ids, **kw)
+    got = slot.generate([prompt], engine_ids(ids), enc_items=enc_items, **kw)[0]
+    ref = odec.generate(NetProvider(oracle, enc), prompt, opts)
+    g, r = got.sequences_ids[0], ref.sequences_ids[0]
+    n = 0
+    while n < min(len(g), len(r)) and g[n] == r[n]:
+        n += 1
+    print(what, "common prefix", n, "of", len(r), "distinct tokens", len(set(r)), "gpu score", got.scores[0], "oracle", ref.scores[0])
+    stable = decode_is_well_conditioned(oracle, enc, prompt, opts, ref, noise_amp, seeds=noise_seeds)
+    if require_exact:
+        assert stable, (what, "pinned case is not well-conditioned: pick another seed (scripts/scan_peaked_seeds.py)")
+    if stable:
+        assert g == r, (what, "first difference at", n, g[max(0, n - 2): n + 3], r[max(0, n - 2): n + 3])
+        assert abs(got.scores[0] - ref.scores[0]) <= 5e-3, (what, got.scores[0], ref.scores[0])
+    else:
+        # a near-tie somewhere on the oracle's own decision path: the GPU's sequence must be an equally good hypothesis
+        # under the oracle, and its reported score must be the oracle's evaluation of the same tokens
+        lg = oracle.decode_logits(enc, np.asarray(list(prompt) + list(g))[None])[0].numpy()
+        cum = 0.0
+        for i, t in enumerate(g):
+            v, lse, _ = odec.process_logits(lg[len(prompt) - 1 + i], list(g[:i]), opts, ids.no_timestamps not in prompt)
+            assert np.isfinite(v[t]), (what, "GPU emitted a token the rules forbid", i, t)
+            cum += float(v[t] - lse)
+        assert abs(got.scores[0] - cum / max(len(g), 1)) <= 5e-3, (what, got.scores[0], cum / max(len(g), 1))
+        assert len(g) == len(r) and cum >= ref.scores[0] * max(len(r), 1) - 5e-2, (what, n, cum, ref.scores[0] * len(r))
+    assert abs(got.no_speech_prob - ref.no_speech_prob) <= 2e-3 + 0.02 * ref.no_speech_prob
+    return n, len(r), stable

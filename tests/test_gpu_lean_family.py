@@ -3,7 +3,7 @@ the Whisper family â€” 512 (base), 768 (small), 1024 (medium), 1280 (large-v3) â
 finishes in seconds. tiny (d_model 384) is not a multiple of 256 and runs the general first-generation GEMV, which is
 what tests/test_gpu_parity.py covers; this module is what pins the kernels bench.py times.
 
-Tolerances as in test_gpu_parity.py: logits rel-rms <= 2e-2 and max-abs <= 6e-2 * rms + 2e-2 against the fp32 oracle on
+Tolerances as at full depth (tests/test_gpu_full_depth.py): logits rel-rms <= 5e-3 and max-abs <= 2e-2 * rms + 1e-2 against the fp32 oracle on
 the same fp16-rounded weights; generated tokens equal up to the first fp16-vs-fp32 near-tie (>= 6 tokens)."""
 import numpy as np
 import pytest
@@ -48,7 +48,7 @@ def fam(request, gpu):
 def _check(got, ref, what):
     st = H.err_stats(got, ref)
     assert np.isfinite(np.asarray(got)).all(), what
-    assert st["rel_rms"] <= 2e-2 and st["max_abs"] <= 6e-2 * st["ref_rms"] + 2e-2, (what, st)
+    assert st["rel_rms"] <= 5e-3 and st["max_abs"] <= 2e-2 * st["ref_rms"] + 1e-2, (what, st)
     return st
 
 

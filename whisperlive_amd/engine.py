@@ -230,6 +230,12 @@ class Slot:
         check(self.lib.wlx_debug_decode_logits(self.engine._h, self.sid, _i32p(tk), tk.size, _f32p(out)))
         return out
 
+    def debug_logits(self, rows: int) -> np.ndarray:
+        """the slot's logits buffer [rows, V] as the LAST decoder pass left it (wlx_debug_logits_get)"""
+        out = np.empty((rows, self.engine.spec.vocab), dtype=np.float32)
+        check(self.lib.wlx_debug_logits_get(self.engine._h, self.sid, _f32p(out), rows, out.size))
+        return out
+
     def debug_search(self, logits: np.ndarray, prompt: Sequence[int], ids: TokenIds, **kw) -> GenerationResult:
         logits = np.ascontiguousarray(logits, dtype=np.float32)   # [steps, rows, V]
         d = dict(beam_size=5, patience=1.0, num_hypotheses=1, length_penalty=1.0, repetition_penalty=1.0,
