@@ -65,7 +65,7 @@ def pmc_traffic(kernel_name: str):
             with open(path, newline="") as f:
                 for row in csv.DictReader(f):
                     if kernel_name in row["kernel"] and row["counter"] == "FETCH_SIZE":
-                        return float(row["mean_per_launch"]) * 1024.0 * 2.0, os.path.relpath(path, ROOT)
+                        return float(row["mean_per_launch"]) * FETCH_KIB_TO_BYTES, os.path.relpath(path, ROOT)
         except (OSError, KeyError, ValueError):
             continue
     return None, None
@@ -134,11 +134,17 @@ def f16_rounded(weights):
             for k, v in weights.items()}
 
 
-def measured_traffic(kernel_name: str, model: str, timeout_s: int = 240):
+FETCH_KIB_TO_BYTES = 1024.0 * 2.0     # FETCH_SIZE is in KiB; on gfx950 it tallies the 128-B requests of wide (16 B per lane)
+                                      # coalesced reads at 64 B (MI355X guide, HBM section) — checked per run, see below
+
+
+def measured_traffic(kernel_name: str, model: str, timeout_s: int = 300, child_args=()):
     """HBM bytes per launch of `kernel_name`, measured BY THIS RUN: a child process of this script (a few decode steps of
     the same workload) under `rocprofv3 --pmc FETCH_SIZE --kernel-trace` — counters in their own pass, as the MI355X guide
-    prescribes — and its counter_collection.csv reduced here. FETCH_SIZE is in KiB and on gfx950 counts half the bytes
-    of wide coalesced reads: x 1024 x 2. (None, reason) when rocprofv3 is missing or the pass fails."""
+    prescribes — and its counter_collection.csv reduced here. Returns (bytes, source, extra): `extra` carries the RAW
+    counter mean (KiB) and a calibration of the KiB -> bytes factor inside the SAME pass: the vocabulary projection
+    streams its V x d fp16 weight image exactly once per launch (tests pin that it reads nothing else of size), so
+    factor = 2 V d / (raw KiB x 1024) must come out at ~2.0 for the x 1024 x 2 conversion to be right on this box."""
     import csv
     import glob
     import shutil
@@ -146,27 +152,40 @@ def measured_traffic(kernel_name: str, model: str, timeout_s: int = 240):
     import tempfile
     rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if rp is None:
-        return None, "rocprofv3 not found"
+        return None, "rocprofv3 not found", {}
     d = tempfile.mkdtemp(prefix="wlx_pmc_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     cmd = [rp, "--pmc", "FETCH_SIZE", "--kernel-trace", "-d", d, "-o", "wlx", "--output-format", "csv", "--",
-           sys.executable, os.path.abspath(__file__), "--pmc-child", "--model", model]
+           sys.executable, os.path.abspath(__file__), "--pmc-child", "--model", model] + list(child_args)
     try:
         proc = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
         tot = n = 0.0
+        per = {}
         for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
             with open(f, newline="") as fh:
                 for r in csv.DictReader(fh):
-                    if r["Counter_Name"] == "FETCH_SIZE" and kernel_name in r["Kernel_Name"]:
+                    if r["Counter_Name"] != "FETCH_SIZE":
+                        continue
+                    a = per.setdefault(r["Kernel_Name"], [0.0, 0])
+                    a[0] += float(r["Counter_Value"]); a[1] += 1
+                    if kernel_name in r["Kernel_Name"]:
                         tot += float(r["Counter_Value"])
                         n += 1
         if not n:
-            return None, f"no FETCH_SIZE rows for {kernel_name} (rocprofv3 rc {proc.returncode}: {proc.stderr[-200:]})"
-        return tot / n * 1024.0 * 2.0, f"rocprofv3 --pmc FETCH_SIZE pass of this run ({int(n)} launches)"
+            return None, f"no FETCH_SIZE rows for {kernel_name} (rocprofv3 rc {proc.returncode}: {proc.stderr[-200:]})", {}
+        extra = {"raw_fetch_size_kib_per_launch": tot / n, "kib_to_bytes_factor_used": FETCH_KIB_TO_BYTES}
+        from whisperlive_amd.specs import get_spec
+        sp = get_spec(model)
+        # calibration: the largest-fetch kernel of the pass is the vocabulary projection (V x d fp16, read once per launch)
+        big = max(per.items(), key=lambda kv: kv[1][0] / kv[1][1])
+        raw_big = big[1][0] / big[1][1]
+        extra["calibration"] = {"kernel": big[0][:80], "raw_kib_per_launch": raw_big, "known_bytes": 2.0 * sp.vocab * sp.d_model,
+                                "bytes_per_raw_kib_over_1024": 2.0 * sp.vocab * sp.d_model / (raw_big * 1024.0)}
+        return tot / n * FETCH_KIB_TO_BYTES, f"rocprofv3 --pmc FETCH_SIZE pass of this run ({int(n)} launches)", extra
     except Exception as e:  # noqa: BLE001 — the headline line must survive a failed counter pass
-        return None, f"{type(e).__name__}: {e}"
+        return None, f"{type(e).__name__}: {e}", {}
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
@@ -291,16 +310,32 @@ def make_bench_transcriber(eng, spec, ids, decode_steps, vad_model=None, max_bat
     return tr
 
 
+def stream_pcm(seconds: float, seed: int = 1234) -> np.ndarray:
+    """The stream leg's audio: `speech_like_pcm` (2.5 s phrases / 1.0 s pauses) with a 3 s noise-only stretch in every 12 s,
+    i.e. longer than the gate's min_silence_duration_ms = 2000 — audio the VAD has to CUT, not only to look at."""
+    from oracle import logmel as olm          # synthetic-input generator only
+    pcm = olm.speech_like_pcm(seconds, seed).copy()
+    t = np.arange(pcm.shape[0]) / 16000.0
+    quiet = (t % 12.0) >= 9.0
+    noise = np.random.default_rng(seed + 7).normal(0.0, 0.003, pcm.shape[0]).astype(np.float32)
+    pcm[quiet] = noise[quiet]
+    return pcm
+
+
 def stream_leg(eng, spec, ids, decode_steps, pcm_fn, clients=1, batch=False, model_name="small.en"):
     """configs[1] / configs[2] through the server shell on the already-built engine (make_bench_transcriber). VAD: the
-    Silero network on the GPU with seeded weights and a +6 output bias, so the gate passes the audio while costing what
-    the real network costs."""
+    Silero network on the GPU (libwlx.so wlx_vad_*) with seeded weights whose probabilities FOLLOW the audio's energy
+    (oracle/silero_vad.py::energy_following_weights — no Silero weight file exists offline): phrases pass, the 3 s
+    noise-only stretches of `stream_pcm` are cut, so speech segmentation, `collect_chunks` and `restore_speech_timestamps`
+    all run with real effect inside the timed path, and the network costs exactly what the real one costs."""
     from oracle import silero_vad as sv          # seeded weight generator only; the network runs in libwlx.so
     from whisperlive_amd import vad
 
-    w = sv.random_weights(3)
-    w["out_b"] = np.asarray([6.0], np.float32)
+    w = sv.energy_following_weights(3)
     vm = vad.SileroHIPModel(w, device=eng.device)
+    probe = pcm_fn(24.0, 4321)
+    spans = vad.get_speech_timestamps(probe, vad.VadOptions(threshold=0.5), model=vm)
+    kept = sum(c["end"] - c["start"] for c in spans) / float(probe.shape[0])
 
     def make():
         return make_bench_transcriber(eng, spec, ids, decode_steps, vad_model=vm, max_batch=max(1, clients if batch else 1))
@@ -314,6 +349,8 @@ def stream_leg(eng, spec, ids, decode_steps, pcm_fn, clients=1, batch=False, mod
     finally:
         BatchInferenceWorker.TEMPERATURES = saved_t
         vm.close()
+    res["vad"] = dict(model="Silero architecture on the GPU, seeded energy-following weights", threshold=0.5,
+                      speech_spans_in_24s_probe=len(spans), audio_kept_fraction=kept)
     res["config"] = (f"configs[{1 if clients == 1 else 2}]: {clients} WebSocket stream{'s' if clients > 1 else ''} -> TranscriptionServer -> "
                      f"ServeClientHIP{' -> BatchInferenceWorker' if batch else ''} -> WhisperModelHIP.transcribe, Whisper-{model_name}, "
                      f"VAD on (Silero on GPU), beam 5, {decode_steps} tokens per window"
@@ -404,8 +441,25 @@ def config5(args, rank, world, local, dist, torch):
         if step_ms is not None:
             out["decode_step"] = {"rows": rows, "graph_replay_ms": step_ms, "algorithmic_bytes": sb,
                                   "hbm_frac_of_peak": sb / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-            out["roofline"] = dict(bound="hbm", kernel="decode step (all launches, 40 rows)", achieved=sb / (step_ms * 1e-3) / 1e9,
-                                   peak=HBM_PEAK_GBS, unit="GB/s", frac=sb / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None)
+            # roofline of the DOMINANT kernel of the 40-row step (HIP-event timed inside the engine, as in the headline run),
+            # its HBM traffic from a live FETCH_SIZE pass of the same batched decode
+            try:
+                prof = slot.debug_profile_step(rows=rows, t=1 + args.decode_steps // 2, iters=10)
+                dom = max(prof, key=lambda k: k["total_us"])
+                roof = dict(bound="hbm", kernel=dom["name"], achieved=dom["bytes_per_launch"] / (dom["avg_us"] * 1e-6) / 1e9,
+                            peak=HBM_PEAK_GBS, unit="GB/s", traffic=None, launches_per_decode_step=dom["launches"],
+                            avg_us=dom["avg_us"], algorithmic_bytes_per_launch=dom["bytes_per_launch"], rows=rows)
+                roof["frac"] = roof["achieved"] / roof["peak"]
+                out["decode_step"]["kernels"] = prof
+                if world == 1 and not args.no_pmc:
+                    note("rocprofv3 FETCH_SIZE pass (batched decode, 8 x 5 rows)")
+                    roof["traffic"], roof["traffic_source"], roof["traffic_detail"] = measured_traffic(
+                        dom["name"], args.model, timeout_s=420, child_args=["--batch", str(MB)])
+                out["roofline"] = roof
+            except Exception as e:  # noqa: BLE001
+                note(f"per-kernel probe at {rows} rows unavailable: {e}")
+                out["roofline"] = dict(bound="hbm", kernel=f"decode step (all launches, {rows} rows)", achieved=sb / (step_ms * 1e-3) / 1e9,
+                                       peak=HBM_PEAK_GBS, unit="GB/s", frac=sb / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None)
     worker.stop()
     tr.close()
     eng.close()
@@ -473,7 +527,7 @@ def main():
     from whisperlive_amd.specs import get_spec
     from whisperlive_amd.weights import random_weights
 
-    if args.config == 5:
+    if args.config == 5 and not args.pmc_child:
         if args.model == "small.en":
             args.model = "large-v3"
         return config5(args, rank, world, local, dist, torch)
@@ -482,12 +536,14 @@ def main():
     eng = HipWhisperEngine(spec, weights, device=local)
     if args.pmc_child:
         # the counter pass of measured_traffic(): a few decode steps of the same workload, nothing else
-        sl = eng.create_slot(1, 5)
+        Bc = max(1, args.batch)
+        sl = eng.create_slot(Bc, 5)
         ids_ = token_ids(spec.vocab)
-        sl.pcm_put(olm.speech_like_pcm(WINDOW_S, seed=1234), 0)
-        T = sl.logmel_resident(0)
-        sl.encode(1, seek=[0], seg=[min(T - 1, 3000)])
-        sl.generate([[ids_["sot"]]], TokenIds(**ids_), beam_size=5, patience=1.0, max_length=1 + 12,
+        for b in range(Bc):
+            sl.pcm_put(olm.speech_like_pcm(WINDOW_S, seed=1234 + b), b)
+        Ts = [sl.logmel_resident(b) for b in range(Bc)]
+        sl.encode(Bc, seek=[0] * Bc, seg=[min(T - 1, 3000) for T in Ts])
+        sl.generate([[ids_["sot"]]] * Bc, TokenIds(**ids_), beam_size=5, patience=1.0, max_length=1 + 12,
                     suppress_tokens=suppress_list(ids_, True))
         sl.close()
         eng.close()
@@ -562,7 +618,10 @@ def main():
         n_tok = len(last.sequences_ids[0])
         xrt = world * S * B * args.steps * WINDOW_S / wall
         # ---- roofline of the dominant kernel, HIP-event timed inside the engine on the slot stream
-        prof = slot.debug_profile_step(rows=5, t=1 + args.decode_steps // 2, iters=20)
+        # one slot's decode step as this run executes it: B windows x 5 beams rows per launch (--streams: S such steps run
+        # concurrently on S slots; the probe is one slot's step alone)
+        prows = 5 * B
+        prof = slot.debug_profile_step(rows=prows, t=1 + args.decode_steps // 2, iters=20)
         dom = max(prof, key=lambda k: k["total_us"])
         roof = dict(bound="hbm", kernel=dom["name"], achieved=dom["bytes_per_launch"] / (dom["avg_us"] * 1e-6) / 1e9,
                     peak=HBM_PEAK_GBS, unit="GB/s", traffic=None,
@@ -571,8 +630,9 @@ def main():
         roof["frac"] = roof["achieved"] / roof["peak"]
         if world == 1 and not args.no_pmc:
             note("rocprofv3 FETCH_SIZE pass")
-            roof["traffic"], roof["traffic_source"] = measured_traffic(dom["name"], args.model)
-            note(f"traffic: {roof['traffic']} ({roof['traffic_source']})")
+            roof["traffic"], roof["traffic_source"], roof["traffic_detail"] = measured_traffic(
+                dom["name"], args.model, child_args=["--batch", str(B)] if B > 1 else ())
+            note(f"traffic: {roof['traffic']} ({roof['traffic_source']}) {roof['traffic_detail'].get('calibration')}")
         if roof["traffic"] is None:
             why = roof.get("traffic_source")
             roof["traffic"], roof["traffic_source"] = pmc_traffic(dom["name"])
@@ -584,8 +644,8 @@ def main():
                                       achieved=big["bytes_per_launch"] / (big["avg_us"] * 1e-6) / 1e9,
                                       frac=big["bytes_per_launch"] / (big["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS)
         step_us = sum(k["total_us"] for k in prof)
-        step_graph_ms = slot.debug_time_decode_step(rows=5, t=1 + args.decode_steps // 2, iters=50)
-        sb = decode_step_bytes(spec, 5, 1 + args.decode_steps // 2)
+        step_graph_ms = slot.debug_time_decode_step(rows=prows, t=1 + args.decode_steps // 2, iters=50)
+        sb = decode_step_bytes(spec, prows, 1 + args.decode_steps // 2) + 2 * spec.dec_layers * 2 * spec.n_audio_ctx * spec.d_model * (B - 1)
         out = {
             "metric": "real-time factor (xRT), Whisper-small 30 s window (p50 chunk latency in p50_chunk_latency_ms)",
             "value": xrt, "unit": "xRT (audio s / wall s)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -597,7 +657,7 @@ def main():
                                    f"{n_tok} generated tokens forced by suppressing EOT), seeded random weights",
                        "streams_per_gpu": S, "batch_per_stream": B, "beam_size": 5, "decode_steps": n_tok, "window_s": WINDOW_S},
             "stage_ms": stage,
-            "decode_step": {"graph_replay_ms": step_graph_ms, "sum_kernel_us": step_us, "algorithmic_bytes": sb,
+            "decode_step": {"rows": prows, "graph_replay_ms": step_graph_ms, "sum_kernel_us": step_us, "algorithmic_bytes": sb,
                             "hbm_frac_of_peak": sb / (step_graph_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                             "kernels": prof},
             "roofline": roof,
@@ -605,7 +665,7 @@ def main():
         if world == 1 and S == 1 and B == 1 and not args.no_stream:
             note("stream leg")
             try:
-                out["stream"] = stream_leg(eng, spec, ids, args.decode_steps, olm.speech_like_pcm, clients=max(1, args.stream_clients),
+                out["stream"] = stream_leg(eng, spec, ids, args.decode_steps, stream_pcm, clients=max(1, args.stream_clients),
                                            batch=args.stream_batch, model_name=args.model)
             except Exception as e:  # noqa: BLE001 — the headline line must survive a failure of this leg
                 out["stream"] = {"error": f"{type(e).__name__}: {e}"}

@@ -64,9 +64,11 @@ typedef struct {
 } wlx_spec;
 
 /* One weight tensor, named with the Hugging Face Whisper state-dict key (e.g.
- * "model.encoder.layers.0.self_attn.q_proj.weight"), fp32, C-contiguous, in host or device
- * memory. The engine copies/repacks it into its own MFMA-fragment layout during create;
- * the caller may free the tensor afterwards. */
+ * "model.encoder.layers.0.self_attn.q_proj.weight"), **float32 only**, C-contiguous, in host or device
+ * memory (there is no dtype field: a half-precision checkpoint must be widened by the caller — the Python binding,
+ * whisperlive_amd/engine.py, does `tensor.to(float32)` for fp16 / bf16 torch tensors, a transient device copy of that ONE
+ * tensor list; the values are unchanged, the engine rounds projection matrices to fp16 itself). The engine copies/repacks
+ * every tensor into its own MFMA-fragment layout during create; the caller may free the tensors afterwards. */
 typedef struct {
     const char* name;
     const void* data;
@@ -172,7 +174,19 @@ int32_t wlx_detect_language(wlx_engine* e, int32_t slot, int32_t batch, int32_t 
 int32_t wlx_timings_get(wlx_engine* e, int32_t slot, wlx_timings* out);
 int32_t wlx_sync(wlx_engine* e, int32_t slot);
 
-/* ---- voice-activity probabilities (Silero VAD, 16 kHz) ------------------------------------------------------------
+/* ---- word timestamps (PRODUCT entry point: transcribe(word_timestamps=True) calls it once per segment group) ---- */
+/* Word alignment — replaces ctranslate2.models.Whisper.align(encoder_output, start_sequence, text_tokens, num_frames,
+ * median_filter_width) (whisper_live/transcriber/transcriber_faster_whisper.py:1657-1663).
+ * tokens = start_sequence (n_sot ids) + [no_timestamps] + text_tokens + [eot]  (n_tokens <= 448) of encoder item `item`;
+ * heads = n_heads (layer, head) pairs (the model's alignment heads). Outputs: the DTW path as parallel arrays
+ * text_indices / time_indices (n_path <= path_cap entries; time in encoder positions of 20 ms) and
+ * text_token_probs[n_tokens - n_sot - 2] = softmax over ids < eot of each text token. */
+int32_t wlx_align(wlx_engine* e, int32_t slot, int32_t item, const int32_t* tokens, int32_t n_tokens, int32_t n_sot,
+                  int32_t num_frames, int32_t median_filter_width, const int32_t* heads, int32_t n_heads, int32_t eot,
+                  int32_t* text_indices, int32_t* time_indices, int32_t path_cap, int32_t* n_path_out,
+                  float* text_token_probs);
+
+/* ---- voice-activity probabilities (Silero VAD, 16 kHz) — PRODUCT entry points: the VAD gate of every use_vad session ----
  * Replaces the model call inside faster_whisper.vad.get_speech_timestamps (onnxruntime, one CPU thread) that the
  * reference makes before every transcription when the client asks for VAD:
  * whisper_live/transcriber/transcriber_faster_whisper.py:830-838 and, per batch item, whisper_live/batch_inference.py:245-248;
@@ -202,7 +216,8 @@ void    wlx_vad_destroy(wlx_vad* v);
 int32_t wlx_vad_probs(wlx_vad* v, const float* pcm, int64_t n, float* probs_out, int32_t cap,
                       int32_t* n_windows_out, float* device_ms_out);
 
-/* ---- test hooks (used only by tests/ and bench.py's roofline leg; not part of the drop-in) ---- */
+/* ==== everything below: TEST / PROFILING hooks (used only by tests/, scripts/ and bench.py's roofline leg; not part of
+ * the drop-in boundary; the product entry points end here) ================================================================= */
 /* next-token logits [rows, vocab] of the last decoder step executed on the slot */
 int32_t wlx_debug_logits_get(wlx_engine* e, int32_t slot, float* out, int32_t rows, int64_t cap_floats);
 /* teacher-forced decoder pass: feed `n` tokens of one sequence (item 0), return logits [n, vocab] */
@@ -212,17 +227,6 @@ int32_t wlx_debug_decode_logits(wlx_engine* e, int32_t slot, const int32_t* toke
 int32_t wlx_debug_search(wlx_engine* e, int32_t slot, const float* logits, int32_t steps,
                          const int32_t* prompt, int32_t prompt_len, const wlx_gen_opts* opts,
                          int32_t* tokens_out, int32_t tokens_stride, int32_t* n_tokens_out, float* scores_out);
-/* Word alignment — replaces ctranslate2.models.Whisper.align(encoder_output, start_sequence, text_tokens, num_frames,
- * median_filter_width) (whisper_live/transcriber/transcriber_faster_whisper.py:1657-1663).
- * tokens = start_sequence (n_sot ids) + [no_timestamps] + text_tokens + [eot]  (n_tokens <= 448) of encoder item `item`;
- * heads = n_heads (layer, head) pairs (the model's alignment heads). Outputs: the DTW path as parallel arrays
- * text_indices / time_indices (n_path <= path_cap entries; time in encoder positions of 20 ms) and
- * text_token_probs[n_tokens - n_sot - 2] = softmax over ids < eot of each text token. */
-int32_t wlx_align(wlx_engine* e, int32_t slot, int32_t item, const int32_t* tokens, int32_t n_tokens, int32_t n_sot,
-                  int32_t num_frames, int32_t median_filter_width, const int32_t* heads, int32_t n_heads, int32_t eot,
-                  int32_t* text_indices, int32_t* time_indices, int32_t path_cap, int32_t* n_path_out,
-                  float* text_token_probs);
-
 /* time `iters` replays of one full decode step (rows x vocab GEMV chain) with HIP events; returns avg ms */
 int32_t wlx_debug_time_decode_step(wlx_engine* e, int32_t slot, int32_t rows, int32_t t, int32_t iters,
                                    float* avg_ms_out);

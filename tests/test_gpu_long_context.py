@@ -182,3 +182,29 @@ def test_45s_chunk_second_window_conditioned_on_first(peaked):
     finally:
         hip.model.generate = gen
         hip.close()
+
+
+def test_word_alignment_with_a_well_separated_optimum(peaked):
+    """`wlx_align` at 12 layers on the peaked weights: the cross-attention of the alignment heads is content-dependent
+    (queries x4), so the DTW optimum is well separated — the oracle's own path keeps >= 99.8 % of its cells under 2 % noise on
+    the alignment matrix — and the STRICT criteria apply with no cost escape (on flat random-weight matrices the
+    overlap assertion of tests/test_gpu_parity.py::test_align_parity is vacuous): >= 95 % identical path cells, the path cost
+    on the oracle's matrix within 1e-3 of the optimum, token probabilities to 2e-3 + 2 %."""
+    from oracle import alignment as oal
+    spec, eng, oracle, slot, enc, _ = peaked
+    ids = H.token_ids_for(spec.vocab)
+    text = np.random.default_rng(3).integers(300, ids.eot - 1, size=40).tolist()
+    heads = [(l, h) for l in range(spec.dec_layers // 2, spec.dec_layers) for h in range(spec.n_heads)][:12]
+    tokens = [ids.sot, ids.no_timestamps] + text + [ids.eot]
+    ti, fi, probs = slot.align(tokens, 1, 3000, heads, ids.eot, median_filter_width=7)
+    rti, rfi, rprobs, matrix = oal.align(oracle, enc, [ids.sot], ids.no_timestamps, text, ids.eot, 3000, heads, 7)
+    np.testing.assert_allclose(probs, rprobs, atol=2e-3, rtol=2e-2)
+    ref_cells = set(zip(rti.tolist(), rfi.tolist()))
+    rng = np.random.default_rng(1)
+    nt, nf = oal.dtw(-(matrix + 0.02 * matrix.std() * rng.standard_normal(matrix.shape).astype(np.float32)))
+    assert len(ref_cells & set(zip(nt.tolist(), nf.tolist()))) / len(ref_cells) >= 0.99, "the case is not well separated"
+    same = len(ref_cells & set(zip(ti.tolist(), fi.tolist()))) / len(ref_cells)
+    cost = lambda a, b: float((-matrix)[a, b].sum())
+    print("peaked align: path overlap", same, "cost", cost(ti, fi), cost(rti, rfi))
+    assert same >= 0.95, same
+    assert cost(ti, fi) <= cost(rti, rfi) + 1e-3 * abs(cost(rti, rfi)) + 1e-3

@@ -325,3 +325,44 @@ def test_wide_batches_decode_in_lean_groups_over_the_same_encoder_output():
     enc8 = m.encode(np.zeros((8, 80, 3000), np.float32))
     m.model.generate(enc8, [[tk.sot]] * 8, beam_size=5)
     assert seen == [(8, None)]                       # fits one launch: no item map needed
+
+
+def test_vad_unavailable_from_a_factory_built_transcriber_downgrades_once(monkeypatch):
+    """a model_factory-built transcriber without Silero weights raised VadUnavailable on EVERY chunk (the server's
+    availability check only runs for transcribers it builds itself): the session must downgrade to use_vad=False once, warn
+    the client, and keep producing text."""
+    import json
+    from unittest.mock import MagicMock
+    from whisperlive_amd import vad
+    from whisperlive_amd.serve_client import ServeClientHIP
+    from whisperlive_amd.types import Segment, TranscriptionInfo
+
+    calls = []
+
+    class Tr:
+        def transcribe(self, audio, **kw):
+            calls.append(kw.get("vad_filter"))
+            if kw.get("vad_filter"):
+                raise vad.VadUnavailable("no weights")
+            seg = Segment(id=1, seek=0, start=0.0, end=1.0, text=" hi", tokens=[1], avg_logprob=-0.1, compression_ratio=1.0,
+                          no_speech_prob=0.0, words=None, temperature=0.0)
+            return [seg], TranscriptionInfo(language="en", language_probability=1.0, duration=1.0, duration_after_vad=1.0,
+                                            transcription_options=None, vad_options=None, all_language_probs=None)
+
+    ws = MagicMock()
+    c = ServeClientHIP.__new__(ServeClientHIP)
+    c.websocket, c.client_uid, c.transcriber, c.use_vad, c.serialize = ws, "u1", Tr(), True, False
+    c.language, c.task, c.initial_prompt, c.vad_parameters, c.hotwords, c.word_timestamps, c.device_index = "en", "transcribe", None, {"threshold": 0.5}, None, False, 0
+    saved = ServeClientHIP.BATCH_WORKER, dict(ServeClientHIP.BATCH_WORKERS)
+    ServeClientHIP.BATCH_WORKER = None
+    ServeClientHIP.BATCH_WORKERS.clear()
+    try:
+        out = c.transcribe_audio(np.zeros(16000, np.float32))
+        assert [s.text for s in out] == [" hi"] and c.use_vad is False and calls == [True, False]
+        out = c.transcribe_audio(np.zeros(16000, np.float32))
+        assert calls == [True, False, False]                                   # no second failure, no second warning
+        msgs = [json.loads(a[0][0]) for a in ws.send.call_args_list]
+        assert [m["status"] for m in msgs if "status" in m] == ["WARNING"]
+    finally:
+        ServeClientHIP.BATCH_WORKER = saved[0]
+        ServeClientHIP.BATCH_WORKERS.update(saved[1])

@@ -73,55 +73,100 @@ class wlx_vad_weights(C.Structure):
                 ("lstm_b_hh", C.POINTER(C.c_float)), ("out_w", C.POINTER(C.c_float)), ("out_b", C.POINTER(C.c_float))]
 
 
+_extra_ok = None
+
+
+def _hipcc() -> str:
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise WlxError("hipcc not found: cannot build libwlx.so (ROCm toolchain required)")
+    return hipcc
+
+
+def _compile(out: Path, defines=(), verbose: bool = False) -> Path:
+    """hipcc --offload-arch=gfx950 of every source into `out`: one object per source (compiled in parallel, cached under
+    csrc/.obj/<variant>/ and rebuilt when the source or any header is newer), linked into a temporary file and renamed
+    (concurrent builders never see a half-written library). HIPCC_EXTRA is a hidden LLVM option: a hipcc that does not know
+    it fails with 'Unknown command line argument' — retry once without it (the AGPR-form build: correct, the encoder
+    attention ~8 % slower) and remember the answer for the other builds of this process."""
+    global _extra_ok
+    from concurrent.futures import ThreadPoolExecutor
+    hipcc = _hipcc()
+    defines = list(defines)
+    hdrs = list(CSRC.glob("*.h")) + [PKG_DIR.parent / "include" / "wlx.h"]
+    hdr_time = max(h.stat().st_mtime for h in hdrs)
+    base = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC"] + [f"-D{d}" for d in defines]
+
+    def objects(extra):
+        tag = "_".join(["base" if extra else "agpr"] + [d.replace("=", "-") for d in defines])
+        odir = CSRC / ".obj" / tag
+        odir.mkdir(parents=True, exist_ok=True)
+
+        def one(src):
+            obj = odir / (src + ".o")
+            sp = CSRC / src
+            if obj.exists() and obj.stat().st_mtime >= max(sp.stat().st_mtime, hdr_time):
+                return obj, None
+            tmp = obj.with_name(obj.name + f".tmp{os.getpid()}")
+            proc = subprocess.run(base + extra + ["-c", str(sp), "-o", str(tmp)], capture_output=True, text=True)
+            if verbose and (proc.stdout or proc.stderr):
+                print(proc.stdout, proc.stderr)
+            if proc.returncode != 0:
+                if tmp.exists():
+                    tmp.unlink()
+                return None, proc
+            os.replace(tmp, obj)
+            return obj, None
+        with ThreadPoolExecutor(max_workers=min(len(SOURCES), os.cpu_count() or 4)) as ex:
+            return list(ex.map(one, SOURCES))
+
+    for extra in ([HIPCC_EXTRA, []] if _extra_ok is not False else [[]]):
+        res = objects(extra)
+        bad = [p for o, p in res if o is None]
+        if not bad:
+            if extra:
+                _extra_ok = True
+            tmp = out.with_name(out.name + f".tmp{os.getpid()}")
+            proc = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(tmp)] + [str(o) for o, _ in res],
+                                  capture_output=True, text=True)
+            if proc.returncode != 0:
+                if tmp.exists():
+                    tmp.unlink()
+                raise WlxError(f"hipcc link failed ({proc.returncode}):\n{proc.stderr[-4000:]}")
+            os.replace(tmp, out)
+            return out
+        err = bad[0].stderr
+        if extra and ("Unknown command line argument" in err or "unknown argument" in err.lower()):
+            _extra_ok = False
+            print(f"[wlx build] this hipcc rejects {' '.join(HIPCC_EXTRA)}: building with MFMA accumulators in AGPR form")
+            continue
+        raise WlxError(f"hipcc failed ({bad[0].returncode}):\n{err[-4000:]}")
+    raise WlxError("hipcc failed")
+
+
+def _fresh(out: Path) -> bool:
+    deps = [CSRC / s for s in SOURCES] + list(CSRC.glob("*.h")) + [PKG_DIR.parent / "include" / "wlx.h"]
+    return out.exists() and all(out.stat().st_mtime >= d.stat().st_mtime for d in deps)
+
+
 def build_trace() -> Path:
     """libwlx_trace.so: the same sources with -DWLX_TRACE (in-kernel timeline marks, profiling only)."""
     out = PKG_DIR / "libwlx_trace.so"
-    srcs = [CSRC / s for s in SOURCES]
-    deps = srcs + list(CSRC.glob("*.h"))
-    if out.exists() and all(out.stat().st_mtime >= d.stat().st_mtime for d in deps):
-        return out
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DWLX_TRACE"] + HIPCC_EXTRA + ["-o", str(out)] + [str(s) for s in srcs]
-    proc = subprocess.run(cmd, capture_output=True, text=True)
-    if proc.returncode != 0:
-        raise WlxError(f"hipcc failed ({proc.returncode}):\n{proc.stderr[-4000:]}")
-    return out
+    return out if _fresh(out) else _compile(out, ["WLX_TRACE"])
 
 
 def build_variant(name: str, defines) -> Path:
     """A/B builds of the same sources with extra -D flags (e.g. libwlx_wfirst.so: -DWLX_X_FIRST=0, the decode GEMVs with
     their weight stream requested BEFORE the activations, the round-1 order); selected at run time with WLX_LIB=<path>."""
     out = PKG_DIR / name
-    srcs = [CSRC / s for s in SOURCES]
-    deps = srcs + list(CSRC.glob("*.h"))
-    if out.exists() and all(out.stat().st_mtime >= d.stat().st_mtime for d in deps):
-        return out
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + HIPCC_EXTRA + [f"-D{d}" for d in defines] + ["-o", str(out)] + [str(s) for s in srcs]
-    proc = subprocess.run(cmd, capture_output=True, text=True)
-    if proc.returncode != 0:
-        raise WlxError(f"hipcc failed ({proc.returncode}):\n{proc.stderr[-4000:]}")
-    return out
+    return out if _fresh(out) else _compile(out, list(defines))
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile every HIP source for gfx950 into whisperlive_amd/libwlx.so (hipcc cross-compiles without a GPU)."""
-    srcs = [CSRC / s for s in SOURCES]
-    deps = srcs + list(CSRC.glob("*.h")) + [PKG_DIR.parent / "include" / "wlx.h"]
-    if not force and DEFAULT_LIB.exists() and all(DEFAULT_LIB.stat().st_mtime >= d.stat().st_mtime for d in deps):
+    if not force and _fresh(DEFAULT_LIB):
         return DEFAULT_LIB
-    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    if not os.path.exists(hipcc):
-        raise WlxError("hipcc not found: cannot build libwlx.so (ROCm toolchain required)")
-    tmp = DEFAULT_LIB.with_suffix(".so.tmp")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"] + HIPCC_EXTRA + ["-o", str(tmp)] + [str(s) for s in srcs]
-    proc = subprocess.run(cmd, capture_output=True, text=True)
-    if verbose or proc.returncode != 0:
-        print(proc.stdout, proc.stderr)
-    if proc.returncode != 0:
-        raise WlxError(f"hipcc failed ({proc.returncode}):\n{proc.stderr[-4000:]}")
-    os.replace(tmp, DEFAULT_LIB)
-    return DEFAULT_LIB
+    return _compile(DEFAULT_LIB, (), verbose)
 
 
 _lib = None

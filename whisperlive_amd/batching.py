@@ -142,7 +142,7 @@ class BatchInferenceWorker:
                 if req.use_vad:
                     params = req.vad_parameters or {}
                     opts = _vad.VadOptions(**params) if isinstance(params, dict) else params
-                    chunks = _vad.get_speech_timestamps(audio, opts, model=tr.__dict__.get("vad_model") if hasattr(tr, "__dict__") else None)
+                    chunks = _vad.get_speech_timestamps(audio, opts, model=tr._vad_model() if hasattr(tr, "_vad_model") else None)
                     if chunks:
                         pieces, _ = _vad.collect_chunks(audio, chunks)
                         audio = np.concatenate(pieces, axis=0) if pieces else audio

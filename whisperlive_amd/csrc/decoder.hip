@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstdio>
+#include <atomic>
 
 namespace wlx {
 
@@ -918,16 +919,28 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
 // larger models: 30 rows x 1280 fp16 = 77 KiB of staged activations) raise the kernel's limit first, once. The first
 // launch of every shape happens OUTSIDE stream capture (engine.hip runs a decoder pass eagerly before it captures one).
 #define WLX_G2_LDS_MAX (152 * 1024)
+// Set when a device refused the raised limit (another GPU generation, a lower per-block LDS limit): gemv2_cfg then keeps
+// every shape that needs more than 64 KiB on the general kernel instead of launching something that cannot run.
+static std::atomic<bool> g_lds_optin_refused{false};
 template <int CH, int LNV, int IN, int OUT, int NTB, int MT, int XS>
 static void g2_launch(dim3 grid, dim3 block, size_t shm, hipStream_t s, const GemvParams& p) {
     if (shm > 64 * 1024) {
-        static bool granted[64] = {};                       // per device: the opt-in is a property of the function ON a device
+        static std::atomic<signed char> granted[64] = {};   // per device: the opt-in is a property of the function ON a device
         int dev = 0;
         (void)hipGetDevice(&dev);
-        if (dev >= 0 && dev < 64 && !granted[dev]) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemv2_kernel<CH, LNV, IN, OUT, NTB, MT, XS>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, WLX_G2_LDS_MAX);
-            granted[dev] = true;
+        if (dev >= 0 && dev < 64 && granted[dev].load(std::memory_order_acquire) == 0) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_gemv2_kernel<CH, LNV, IN, OUT, NTB, MT, XS>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, WLX_G2_LDS_MAX);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                g_lds_optin_refused.store(true);
+                fprintf(stderr, "[wlx] device %d refused %d KiB of dynamic LDS (%s): batched decode projections fall back to the general kernel\n",
+                        dev, WLX_G2_LDS_MAX / 1024, hipGetErrorString(e));
+                // the launch below then fails with the runtime's own error, which the engine's hipGetLastError check reports for
+                // THIS call; later calls take the general kernel (gemv2_cfg)
+            } else {
+                granted[dev].store(1, std::memory_order_release);
+            }
         }
     }
     hipLaunchKernelGGL((dec_gemv2_kernel<CH, LNV, IN, OUT, NTB, MT, XS>), grid, block, shm, s, p);
@@ -1003,6 +1016,7 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     if (p.in_mode == GEMV_IN_F16 && (c.MT > 1 || c.shm + xs_bytes > 64 * 1024)) c.xstage = false;   // fragments from global instead
     if (c.xstage) c.shm += xs_bytes;
     if (c.shm > WLX_G2_LDS_MAX) return c;                              // beyond a CU's LDS (160 KiB, less a margin): older kernel
+    if (c.shm > 64 * 1024 && g_lds_optin_refused.load(std::memory_order_relaxed)) return c;   // the device refused the raised limit once
     c.ok = true;
     return c;
 }

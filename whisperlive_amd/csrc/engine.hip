@@ -1621,23 +1621,27 @@ extern "C" int32_t wlx_debug_profile_step(wlx_engine* e, int32_t slot, int32_t r
     SlotGuard sg_;
     CKR(slot_acquire(e, slot, sg_));
     Slot* s = sg_.s;
-    if (rows < 1 || rows > s->cache_rows || rows > 16 || t < 0 || t >= WLX_T_TEXT || iters < 1 || !out || !n_out || cap < 1)
+    if (rows < 1 || rows > s->cache_rows || rows > 64 || t < 0 || t >= WLX_T_TEXT || iters < 1 || !out || !n_out || cap < 1)
         return fail(WLX_ERR_ARG, "bad arguments");
+    if (rows > 16 && (rows % s->R != 0 || rows / s->R > s->B)) return fail(WLX_ERR_ARG, "more than 16 rows: a multiple of the slot's rows per item");
     if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "decode before encode");
     CK(hipSetDevice(e->device));
     hipStream_t st = s->stream;
-    std::vector<int> tk(rows, 0), ps(rows, t), ca(rows), an(rows), gi(1, 0);
+    // up to 16 rows: one item with `rows` beams; more: rows / R items of R beams each, as a batched decode has them
+    const int tR = rows > 16 ? s->R : rows, tG = rows / tR;
+    std::vector<int> tk(rows, 0), ps(rows, t), ca(rows), an(rows), gi(tG, 0);
+    for (int g = 0; g < tG; ++g) gi[g] = g % std::max(1, s->enc_batch);
     std::vector<short> anc((size_t)rows * WLX_T_TEXT);
     for (int r = 0; r < rows; ++r) { ca[r] = an[r] = r; for (int p = 0; p < WLX_T_TEXT; ++p) anc[(size_t)r * WLX_T_TEXT + p] = (short)r; }
     CKR(set_anc_rows(s, anc, 0, rows));
     CKR(upload_rows(s, tk, ps, ca, an, gi));
     CK(hipMemsetAsync(s->st.done, 0, 4, st));
-    for (int i = 0; i < 2; ++i) decoder_pass(e, s, rows, rows, 1, true, true);   // warm caches / code objects
+    for (int i = 0; i < 2; ++i) decoder_pass(e, s, rows, tR, tG, true, true);   // warm caches / code objects
     CK(hipStreamSynchronize(st));
     Prof prof;
     prof.t = t;
     s->prof = &prof;
-    decoder_pass(e, s, rows, rows, 1, true, true);                               // pass 1: list the launches of one step
+    decoder_pass(e, s, rows, tR, tG, true, true);                               // pass 1: list the launches of one step
     struct Agg { int launches = 0; double bytes = 0, us = 0; };
     std::map<std::string, Agg> agg;
     for (auto& r : prof.recs) { Agg& a = agg[r.name]; a.launches += 1; a.bytes += r.bytes; }
@@ -1650,7 +1654,7 @@ extern "C" int32_t wlx_debug_profile_step(wlx_engine* e, int32_t slot, int32_t r
         prof.only = kv.first;
         hipGraph_t graph; hipGraphExec_t exec;
         if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { rc = WLX_ERR_HIP; break; }
-        decoder_pass(e, s, rows, rows, 1, true, true);
+        decoder_pass(e, s, rows, tR, tG, true, true);
         if (hipStreamEndCapture(st, &graph) != hipSuccess) { rc = WLX_ERR_HIP; break; }
         if (hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(graph); rc = WLX_ERR_HIP; break; }
         (void)hipGraphDestroy(graph);

@@ -25,6 +25,7 @@ from typing import List, Optional
 import numpy as np
 
 from . import metrics as wl_metrics
+from . import vad as _vad
 
 
 class ServeClientBase:
@@ -125,6 +126,12 @@ class ServeClientBase:
                 time.sleep(0.01)
         self.on_transcription_thread_exit()
         logging.info("Exiting speech to text thread")
+
+    def _transcribe_locked(self, input_sample, kw):
+        if self.serialize:
+            with ServeClientHIP.SINGLE_MODEL_LOCK:
+                return self.transcriber.transcribe(input_sample, **kw)
+        return self.transcriber.transcribe(input_sample, **kw)                 # concurrent: own slot / HIP stream
 
     def on_transcription_thread_exit(self):
         """Hook run by the transcription thread as it ends (backends release per-thread resources here)."""
@@ -384,11 +391,21 @@ class ServeClientHIP(ServeClientBase):
         kw = dict(initial_prompt=self.initial_prompt, language=self.language, task=self.task, vad_filter=self.use_vad,
                   vad_parameters=self.vad_parameters if self.use_vad else None, hotwords=self.hotwords,
                   word_timestamps=self.word_timestamps)
-        if self.serialize:
-            with ServeClientHIP.SINGLE_MODEL_LOCK:
-                result, info = self.transcriber.transcribe(input_sample, **kw)
-        else:
-            result, info = self.transcriber.transcribe(input_sample, **kw)     # concurrent: own slot / HIP stream
+        try:
+            result, info = self._transcribe_locked(input_sample, kw)
+        except _vad.VadUnavailable as e:
+            # use_vad reached a transcriber with no Silero weights (a model_factory-built one: the server's own availability
+            # check only covers transcribers it builds itself). Same outcome as there: tell the client ONCE, run ungated —
+            # raising here on every chunk would leave the session alive but silent.
+            logging.warning(f"use_vad requested by {self.client_uid} but unavailable: {e}")
+            self.use_vad = False
+            try:
+                self.websocket.send(json.dumps({"uid": self.client_uid, "status": "WARNING",
+                                                "message": "use_vad ignored: no Silero VAD weights are configured on this server"}))
+            except Exception:  # noqa: BLE001 — a closed socket must not hide the transcript path
+                pass
+            kw.update(vad_filter=False, vad_parameters=None)
+            result, info = self._transcribe_locked(input_sample, kw)
         if self.language is None and info is not None:
             self.set_language(info)
         return result

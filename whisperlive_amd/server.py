@@ -197,7 +197,7 @@ class TranscriptionServer:
                 # the gate must be the reference's detector or nothing: without Silero weights the client is told and
                 # the session runs ungated (WLX_ALLOW_VAD_STANDIN=1 opts into the labelled energy gate instead)
                 try:
-                    _vad.get_default_model()
+                    _vad.get_default_model(device_index)
                 except _vad.VadUnavailable as e:
                     logging.warning(f"use_vad requested by {options['uid']} but unavailable: {e}")
                     websocket.send(json.dumps({"uid": options["uid"], "status": "WARNING",
@@ -367,7 +367,7 @@ class TranscriptionServer:
             raise ValueError("device indices must be >= 0")
         self.model_factory = model_factory
         if vad_weights:
-            _vad.configure(vad_weights, self.devices[0])         # silero_vad.onnx or .npz -> Silero on the GPU
+            _vad.configure(vad_weights, self.devices[0])         # silero_vad.onnx or .npz -> Silero on every GPU that serves a client
         return BackendType(backend)
 
     def run(self, host, port=9090, backend="hip", faster_whisper_custom_model_path=None, whisper_tensorrt_path=None,

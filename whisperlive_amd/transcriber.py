@@ -340,11 +340,16 @@ class WhisperModelHIP:
         self.time_precision = 0.02
         self.max_length = 448
         self.max_batch = max_batch
-        self.vad_model = vad_model          # padded audio -> per-window speech probability; None = vad.get_default_model()
+        self.vad_model = vad_model          # padded audio -> per-window speech probability; None = the process's Silero weights on THIS GPU
         self._tls = threading.local()
         self._slots: List[Slot] = []
         self._slots_lock = threading.Lock()
         self._seed = itertools.count(0x5EED)
+
+    def _vad_model(self):
+        """the gate's probability model: the one given at construction, else the process's Silero weights on this
+        transcriber's own GPU (raises vad.VadUnavailable when none are configured)"""
+        return self.vad_model if self.vad_model is not None else _vad.get_default_model(getattr(self.engine, "device", 0))
 
     # ---- slots: one per calling thread (the reference runs one transcription thread per client)
     def _slot(self) -> Slot:
@@ -466,7 +471,7 @@ class WhisperModelHIP:
                 vad_parameters = VadOptions()
             elif isinstance(vad_parameters, dict):
                 vad_parameters = VadOptions(**vad_parameters)
-            speech_chunks = _vad.get_speech_timestamps(audio, vad_parameters, model=self.vad_model)
+            speech_chunks = _vad.get_speech_timestamps(audio, vad_parameters, model=self._vad_model())
             chunks, _meta = _vad.collect_chunks(audio, speech_chunks)
             audio = np.concatenate(chunks, axis=0)
             duration_after_vad = audio.shape[0] / sr
@@ -768,7 +773,7 @@ class WhisperModelHIP:
             if vad_filter:
                 if isinstance(vad_parameters, dict):
                     vad_parameters = VadOptions(**vad_parameters)
-                chunks, _ = _vad.collect_chunks(audio, _vad.get_speech_timestamps(audio, vad_parameters, model=self.vad_model))
+                chunks, _ = _vad.collect_chunks(audio, _vad.get_speech_timestamps(audio, vad_parameters, model=self._vad_model()))
                 audio = np.concatenate(chunks, axis=0)
             audio = audio[: language_detection_segments * fe.n_samples]
             slot = self._slot()

@@ -149,7 +149,9 @@ class SileroHIPModel:
     # exits without it simply returns the device memory with its context
 
 
-_default_model: Optional[Callable[[np.ndarray], np.ndarray]] = None
+_default_model: Optional[Callable[[np.ndarray], np.ndarray]] = None      # installed explicitly (set_default_model / configure)
+_default_weights = None                                                   # Silero weights of the process (loaded once)
+_device_models: Dict[int, Callable[[np.ndarray], np.ndarray]] = {}       # one SileroHIPModel per GPU (clients shard over GPUs)
 _default_lock = threading.Lock()
 
 
@@ -158,56 +160,71 @@ class VadUnavailable(RuntimeError):
 
 
 def set_default_model(model: Optional[Callable[[np.ndarray], np.ndarray]]):
-    global _default_model
+    global _default_model, _default_weights
     with _default_lock:
         _default_model = model
+        if model is None:
+            _default_weights = None
+            for m in _device_models.values():
+                close = getattr(m, "close", None)
+                if close:
+                    close()
+            _device_models.clear()
 
 
 def configure(weights_path: Optional[str] = None, device: int = 0) -> Callable[[np.ndarray], np.ndarray]:
-    """Install the process-wide VAD model from a weight file: ``.npz`` (names / shapes of SILERO_SHAPES) or the
+    """Install the process-wide VAD weights from a file: ``.npz`` (names / shapes of SILERO_SHAPES) or the
     ``silero_vad.onnx`` the reference downloads (whisper_live/vad.py:112-128) — the latter is converted on the fly by
-    ``whisperlive_amd.silero_export`` (stdlib protobuf walk, no onnx / onnxruntime needed) and runs on the GPU."""
+    ``whisperlive_amd.silero_export`` (stdlib protobuf walk, no onnx / onnxruntime needed). The network runs on the GPU the
+    calling transcriber lives on: ``get_default_model(device)`` builds one SileroHIPModel per device from these weights."""
+    global _default_weights
     if weights_path is None:
-        return get_default_model()
+        return get_default_model(device)
     if weights_path.endswith(".npz"):
         w = load_silero_npz(weights_path)
     else:
         from .silero_export import silero_weights_from_onnx
         w = check_silero_weights(silero_weights_from_onnx(weights_path))
-    model = SileroHIPModel(w, device)
-    set_default_model(model)
-    logging.info("VAD: Silero weights from %s on GPU %d", weights_path, device)
-    return model
+    with _default_lock:
+        _default_weights = w
+    logging.info("VAD: Silero weights from %s", weights_path)
+    return get_default_model(device)
 
 
-def get_default_model() -> Callable[[np.ndarray], np.ndarray]:
-    """WLX_SILERO_VAD_NPZ / WLX_SILERO_VAD_ONNX name the weights (the ONNX file is the one the reference downloads).
-    Without them ``use_vad`` FAILS (VadUnavailable) unless WLX_ALLOW_VAD_STANDIN=1 opts into the labelled energy gate —
-    a default deployment must not silently gate audio with something that is not the reference's detector."""
-    global _default_model
+def get_default_model(device: Optional[int] = None) -> Callable[[np.ndarray], np.ndarray]:
+    """The VAD model for a transcriber on GPU `device` (None: WLX_VAD_DEVICE or 0). WLX_SILERO_VAD_NPZ /
+    WLX_SILERO_VAD_ONNX name the weights (the ONNX file is the one the reference downloads). Without them ``use_vad`` FAILS
+    (VadUnavailable) unless WLX_ALLOW_VAD_STANDIN=1 opts into the labelled energy gate — a default deployment must not
+    silently gate audio with something that is not the reference's detector."""
+    global _default_model, _default_weights
     with _default_lock:
         if _default_model is not None:
             return _default_model
-        npz = os.environ.get("WLX_SILERO_VAD_NPZ")
-        path = os.environ.get("WLX_SILERO_VAD_ONNX")
-        dev = int(os.environ.get("WLX_VAD_DEVICE", "0"))
-        if npz and os.path.isfile(npz):
-            _default_model = SileroHIPModel(load_silero_npz(npz), dev)
-            logging.info("VAD: Silero (HIP) from %s", npz)
-        elif path and os.path.isfile(path):
-            from .silero_export import silero_weights_from_onnx
-            _default_model = SileroHIPModel(check_silero_weights(silero_weights_from_onnx(path)), dev)
-            logging.info("VAD: Silero (HIP) from %s", path)
-        elif os.environ.get("WLX_ALLOW_VAD_STANDIN") == "1":
-            logging.warning("VAD: WLX_ALLOW_VAD_STANDIN=1 — using the energy-gate stand-in, which is NOT the reference's "
-                            "speech detector (set WLX_SILERO_VAD_ONNX / WLX_SILERO_VAD_NPZ or pass --vad_weights)")
-            _default_model = EnergyGateModel()
-        else:
-            raise VadUnavailable(
-                "use_vad needs Silero VAD weights: set WLX_SILERO_VAD_ONNX (the silero_vad.onnx the reference downloads) or "
-                "WLX_SILERO_VAD_NPZ, pass --vad_weights to the server, or opt into the energy-gate stand-in with "
-                "WLX_ALLOW_VAD_STANDIN=1")
-        return _default_model
+        dev = int(os.environ.get("WLX_VAD_DEVICE", "0")) if device is None else int(device)
+        if dev in _device_models:
+            return _device_models[dev]
+        if _default_weights is None:
+            npz = os.environ.get("WLX_SILERO_VAD_NPZ")
+            path = os.environ.get("WLX_SILERO_VAD_ONNX")
+            if npz and os.path.isfile(npz):
+                _default_weights = load_silero_npz(npz)
+                logging.info("VAD: Silero (HIP) from %s", npz)
+            elif path and os.path.isfile(path):
+                from .silero_export import silero_weights_from_onnx
+                _default_weights = check_silero_weights(silero_weights_from_onnx(path))
+                logging.info("VAD: Silero (HIP) from %s", path)
+            elif os.environ.get("WLX_ALLOW_VAD_STANDIN") == "1":
+                logging.warning("VAD: WLX_ALLOW_VAD_STANDIN=1 — using the energy-gate stand-in, which is NOT the reference's "
+                                "speech detector (set WLX_SILERO_VAD_ONNX / WLX_SILERO_VAD_NPZ or pass --vad_weights)")
+                _default_model = EnergyGateModel()
+                return _default_model
+            else:
+                raise VadUnavailable(
+                    "use_vad needs Silero VAD weights: set WLX_SILERO_VAD_ONNX (the silero_vad.onnx the reference downloads) or "
+                    "WLX_SILERO_VAD_NPZ, pass --vad_weights to the server, or opt into the energy-gate stand-in with "
+                    "WLX_ALLOW_VAD_STANDIN=1")
+        _device_models[dev] = SileroHIPModel(_default_weights, dev)
+        return _device_models[dev]
 
 
 def speech_segments_from_probs(probs: Sequence[float], n_samples: int, opt: VadOptions, sampling_rate: int = 16000
