@@ -178,8 +178,10 @@ def measured_traffic(kernel_name: str, model: str, timeout_s: int = 300, child_a
         extra = {"raw_fetch_size_kib_per_launch": tot / n, "kib_to_bytes_factor_used": FETCH_KIB_TO_BYTES}
         from whisperlive_amd.specs import get_spec
         sp = get_spec(model)
-        # calibration: the largest-fetch kernel of the pass is the vocabulary projection (V x d fp16, read once per launch)
-        big = max(per.items(), key=lambda kv: kv[1][0] / kv[1][1])
+        # calibration: the largest-fetch DECODE projection of the pass is the vocabulary projection (V x d fp16, read once per
+        # launch; the other dec_gemv2 launches stream 1-13 MB)
+        gem = {k: v for k, v in per.items() if "dec_gemv2_kernel" in k} or per
+        big = max(gem.items(), key=lambda kv: kv[1][0] / kv[1][1])
         raw_big = big[1][0] / big[1][1]
         extra["calibration"] = {"kernel": big[0][:80], "raw_kib_per_launch": raw_big, "known_bytes": 2.0 * sp.vocab * sp.d_model,
                                 "bytes_per_raw_kib_over_1024": 2.0 * sp.vocab * sp.d_model / (raw_big * 1024.0)}

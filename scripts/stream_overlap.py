@@ -18,6 +18,11 @@ with open(path, newline="") as f:
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Queue_Id"]), int(r["Stream_Id"]), int(r["Thread_Id"]), nm))
 rows.sort()
 print(f"{len(rows)} dispatches, span {(rows[-1][1] - rows[0][0]) / 1e6:.2f} ms")
+if decode_only:
+    # steady state only: the middle of the decode dispatches (set-up, warm-up and the tail are left out)
+    lo, hi = rows[int(len(rows) * 0.45)][0], rows[int(len(rows) * 0.95)][0]
+    rows = [r for r in rows if lo <= r[0] <= hi]
+    print(f"steady-state window: {len(rows)} dispatches, {(hi - lo) / 1e6:.2f} ms")
 byq = defaultdict(list)
 for s, e, q, st, th, nm in rows:
     byq[q].append((s, e, st, th))
@@ -26,7 +31,7 @@ for q, v in sorted(byq.items()):
     threads = Counter(x[3] for x in v)
     busy = sum(e - s for s, e, _, _ in v)
     switches = sum(1 for a, b in zip(v, v[1:]) if a[2] != b[2])
-    print(f"queue {q}: {len(v)} dispatches, busy {busy / 1e6:.2f} ms, streams {dict(streams)}, host threads {len(threads)}, "
+    print(f"queue {q}: {len(v)} dispatches, busy {busy / 1e6:.2f} ms, streams {dict(streams)}, host threads {len(threads)} {dict(threads)}, "
           f"stream switches between consecutive dispatches {switches}")
 # concurrency histogram
 ev = []

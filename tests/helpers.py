@@ -117,10 +117,15 @@ def decode_is_well_conditioned(model, enc, prompt, opts, ref, amp: float, seeds=
 
 
 def check_decode(oracle, enc, slot, ids, prompt, what, *, require_exact=True, noise_amp=0.02, enc_items=None, noise_seeds=(1, 2), **kw):
-    """GPU beam decode vs the oracle's. Well-conditioned case (the oracle's result survives +-noise_amp on every logit): the GPU
-    must reproduce every token and the score to 5e-3. Otherwise (a near-tie on the oracle's own decision path): the GPU's
-    sequence must be an equally good hypothesis UNDER THE ORACLE and its reported score the oracle's evaluation of it.
-    require_exact: the case is pinned as well-conditioned (scripts/scan_peaked_seeds.py) — fail if it is not."""
+    """GPU beam decode vs the oracle's.
+    * tokens identical -> pass (the GPU's reported score must equal the oracle's to 5e-3).
+    * tokens differ, require_exact (a case PINNED as well-conditioned by scripts/scan_peaked_seeds.py: the oracle's own result
+      survives +-0.02 of noise on every logit, far above any BLAS summation-order difference between hosts) -> fail. No
+      near-tie escape.
+    * tokens differ, not pinned: the noise test runs now. A well-conditioned case fails; otherwise (a near-tie on the oracle's
+      own decision path) the GPU's sequence must be an equally good hypothesis UNDER THE ORACLE (within 5e-2 of the oracle's
+      best cumulative score — on peaked weights alternatives are O(1) apart) and its reported score the oracle's evaluation
+      of the same tokens."""
     opts = odec.GenOptions(ids=ids, **kw)
     got = slot.generate([prompt], engine_ids(ids), enc_items=enc_items, **kw)[0]
     ref = odec.generate(NetProvider(oracle, enc), prompt, opts)
@@ -129,15 +134,13 @@ def check_decode(oracle, enc, slot, ids, prompt, what, *, require_exact=True, no
     while n < min(len(g), len(r)) and g[n] == r[n]:
         n += 1
     print(what, "common prefix", n, "of", len(r), "distinct tokens", len(set(r)), "gpu score", got.scores[0], "oracle", ref.scores[0])
-    stable = decode_is_well_conditioned(oracle, enc, prompt, opts, ref, noise_amp, seeds=noise_seeds)
-    if require_exact:
-        assert stable, (what, "pinned case is not well-conditioned: pick another seed (scripts/scan_peaked_seeds.py)")
-    if stable:
-        assert g == r, (what, "first difference at", n, g[max(0, n - 2): n + 3], r[max(0, n - 2): n + 3])
+    exact = g == r
+    if exact:
         assert abs(got.scores[0] - ref.scores[0]) <= 5e-3, (what, got.scores[0], ref.scores[0])
     else:
-        # a near-tie somewhere on the oracle's own decision path: the GPU's sequence must be an equally good hypothesis
-        # under the oracle, and its reported score must be the oracle's evaluation of the same tokens
+        diff = (what, "first difference at", n, g[max(0, n - 2): n + 3], r[max(0, n - 2): n + 3])
+        assert not require_exact, diff
+        assert not decode_is_well_conditioned(oracle, enc, prompt, opts, ref, noise_amp, seeds=noise_seeds), diff
         lg = oracle.decode_logits(enc, np.asarray(list(prompt) + list(g))[None])[0].numpy()
         cum = 0.0
         for i, t in enumerate(g):
@@ -147,4 +150,4 @@ def check_decode(oracle, enc, slot, ids, prompt, what, *, require_exact=True, no
         assert abs(got.scores[0] - cum / max(len(g), 1)) <= 5e-3, (what, got.scores[0], cum / max(len(g), 1))
         assert len(g) == len(r) and cum >= ref.scores[0] * max(len(r), 1) - 5e-2, (what, n, cum, ref.scores[0] * len(r))
     assert abs(got.no_speech_prob - ref.no_speech_prob) <= 2e-3 + 0.02 * ref.no_speech_prob
-    return n, len(r), stable
+    return n, len(r), exact

@@ -28,8 +28,8 @@ pytestmark = [pytest.mark.gpu, pytest.mark.timeout(1200)]
 
 LOGIT_REL_RMS = 5e-3
 NOISE_AMP = 0.02
-PEAKED_SEED = 0
-PINNED_WELL_CONDITIONED = False       # set once scripts/scan_peaked_seeds.py large-v3 has found a seed
+PEAKED_SEED = 4                      # scripts/scan_peaked_seeds.py large-v3: clip 1, [sot], 64 steps is well-conditioned at +-0.02
+PINNED_WELL_CONDITIONED = True
 N_ITEMS = 8
 
 
@@ -104,14 +104,13 @@ def test_eight_items_batched_beam5_equal_singles_and_oracle(lv3):
     for i in (0, 3, 7):
         ref = odec.generate(H.NetProvider(oracle, encs[i]), [ids.sot], opts)
         g, r = res[i].sequences_ids[0], ref.sequences_ids[0]
-        stable = H.decode_is_well_conditioned(oracle, encs[i], [ids.sot], opts, ref, NOISE_AMP, seeds=(1,))
-        print("large-v3 batched item", i, "common prefix", _prefix(g, r), "of", len(r), "well-conditioned", stable,
-              "gpu score", res[i].scores[0], "oracle", ref.scores[0])
-        if stable:
-            assert g == r, (i, _prefix(g, r), g, r)
+        print("large-v3 batched item", i, "common prefix", _prefix(g, r), "of", len(r), "gpu score", res[i].scores[0], "oracle", ref.scores[0])
+        if g == r:
             assert abs(res[i].scores[0] - ref.scores[0]) <= 5e-3
             exact += 1
         else:
+            # only a near-tie on the oracle's own decision path excuses a difference (the noise test runs only now)
+            assert not H.decode_is_well_conditioned(oracle, encs[i], [ids.sot], opts, ref, NOISE_AMP, seeds=(1,)), (i, _prefix(g, r), g, r)
             lgt = oracle.decode_logits(encs[i], np.asarray([ids.sot] + list(g))[None])[0].numpy()
             cum = 0.0
             for k, t in enumerate(g):
@@ -121,7 +120,7 @@ def test_eight_items_batched_beam5_equal_singles_and_oracle(lv3):
             assert abs(res[i].scores[0] - cum / max(len(g), 1)) <= 5e-3
             assert cum >= ref.scores[0] * max(len(r), 1) - 5e-2
         assert abs(res[i].no_speech_prob - ref.no_speech_prob) <= 2e-3 + 0.02 * ref.no_speech_prob
-    assert exact >= 1, "at least one of the three oracle-checked items must be a well-conditioned, token-exact case"
+    assert exact >= 2, "at least two of the three oracle-checked items must be token-exact"
 
 
 def test_single_clip_beam5_64_steps_token_exact(lv3):

@@ -2,6 +2,7 @@
 // (one HIP stream + all scratch per concurrent stream), and the host orchestration of
 // log-mel -> encoder -> prefill -> hipGraph-replayed decode steps.
 #include "engine.h"
+#include <atomic>
 #include <limits>
 #include <algorithm>
 #include <cmath>
@@ -448,6 +449,45 @@ static int slot_grow_audio(Engine* e, Slot* s, size_t n_samples) {
     return WLX_OK;
 }
 
+// A slot's stream gets a HARDWARE QUEUE OF ITS OWN. HIP multiplexes ordinary streams round robin over GPU_MAX_HW_QUEUES = 4
+// hardware queues (the null stream and this library's utility stream take two of them), so with four concurrent clients two
+// slots shared one queue and their decode chains serialised: 4 streams ran at 1826 xRT. A stream created through
+// hipExtStreamCreateWithCUMask owns its queue (the CU mask is a property of the queue) — here with EVERY CU enabled, so
+// nothing is restricted: 2734 xRT for the same four streams, single stream unchanged (profiles/r3b_streams4_*.json,
+// profiles/r3b_streams4_dedicated_queues_overlap.txt). Raising GPU_MAX_HW_QUEUES instead is NOT an option: 5, 6 and 8 run the
+// same workload at 610-640 xRT. WLX_SLOT_CU_MASK=off restores ordinary streams; =stride4 / contig4 give slot k a quarter of
+// the CUs (every 4th CU: a decode step is as fast on 64 CUs spread over all XCDs as on 256 — 373 us — but the encoder is not).
+static int create_slot_stream(int device, hipStream_t* out) {
+    static const char* cu_mode = getenv("WLX_SLOT_CU_MASK");
+    static std::atomic<int> slot_seq{0};
+    const std::string m = cu_mode ? cu_mode : "full";
+    if (m == "prio_high" || m == "prio_alt") {
+        // (A/B) priority streams draw their hardware queues from a per-priority pool, separate from the normal-priority pool
+        // the null and utility streams live in, and — unlike the CU-mask constructor — take the non-blocking flag
+        int lo = 0, hi = 0;
+        CK(hipDeviceGetStreamPriorityRange(&lo, &hi));          // numerically lower = higher priority
+        const int k = slot_seq.fetch_add(1);
+        const int pr = (m == "prio_alt" && (k & 1)) ? lo : hi;
+        if (hipStreamCreateWithPriority(out, hipStreamNonBlocking, pr) == hipSuccess) return WLX_OK;
+        (void)hipGetLastError();
+    } else if (m != "off") {
+        hipDeviceProp_t prop;
+        CK(hipGetDeviceProperties(&prop, device));
+        const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+        const int k = slot_seq.fetch_add(1);
+        std::vector<uint32_t> mask(words, 0u);
+        const int parts = (m == "contig2") ? 2 : ((m == "stride4" || m == "contig4") ? 4 : 1);
+        for (int cu = 0; cu < ncu; ++cu) {
+            const bool mine = (m == "stride4") ? (cu % parts == k % parts) : (cu * parts / ncu == k % parts);
+            if (mine) mask[cu >> 5] |= 1u << (cu & 31);
+        }
+        if (hipExtStreamCreateWithCUMask(out, (uint32_t)words, mask.data()) == hipSuccess) return WLX_OK;
+        (void)hipGetLastError();           // not supported here: an ordinary stream (shared queues) is still correct
+    }
+    CK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
+    return WLX_OK;
+}
+
 extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max_rows_per_item, int32_t* slot_out) {
     if (!e || !slot_out) return fail(WLX_ERR_ARG, "null argument");
     if (max_batch < 1 || max_batch > 64) return fail(WLX_ERR_ARG, "max_batch out of range");
@@ -461,7 +501,7 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
     s->nframes.assign(B, 0);
     s->npcm.assign(B, 0);
     int rc = [&]() -> int {
-        CK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        CKR(create_slot_stream(e->device, &s->stream));
         CK(hipEventCreate(&s->ev0)); CK(hipEventCreate(&s->ev1));
         CK(hipEventCreateWithFlags(&s->ev_poll0, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&s->ev_poll1, hipEventDisableTiming));
@@ -984,7 +1024,7 @@ static int get_step_graph(Engine* e, Slot* s, int rows, int R, int groups, bool 
         // it and moves on to the next chunk, whisper_live/backend/base.py:134-137), the next one captures afresh.
         (void)hipGetLastError();
         hipStream_t ns = nullptr;
-        if (hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) == hipSuccess) {
+        if (create_slot_stream(e->device, &ns) == WLX_OK) {
             (void)hipStreamDestroy(s->stream);
             s->stream = ns;
         }
