@@ -207,6 +207,49 @@ def respawn_ranks(n: int, argv) -> int:
     return subprocess.call(cmd, env=env)
 
 
+def ws_client_main(spec_json: str) -> int:
+    """`bench.py --ws-client '<json>'`: ONE stock-client stand-in in its own process (whisper_live/client.py:433,547: float32
+    16 kHz PCM in 4096-sample binary packets, then END_OF_AUDIO): connect, wait for SERVER_READY, build the PCM, start on the
+    common `go` instant (paced clients offset by k / clients of the packet period: independent clients are not phase-locked),
+    count the segment messages that come back. Prints one JSON line."""
+    import threading
+    from whisperlive_amd import ws
+    a = json.loads(spec_json)
+    res = {"segments": 0, "error": None}
+    try:
+        c = ws.connect(f"ws://127.0.0.1:{a['port']}")
+        c.send(json.dumps(dict(uid=f"bench{a['k']}", language=a["language"], task="transcribe", model=a["model"], use_vad=True,
+                               no_speech_thresh=1.0, same_output_threshold=10)))
+        if json.loads(c.recv(timeout=30)).get("message") != "SERVER_READY":
+            raise RuntimeError("no SERVER_READY")
+        pcm = stream_pcm(a["secs"], a["seed"])
+        packets = [pcm[i: i + 4096].tobytes() for i in range(0, pcm.shape[0], 4096)]
+
+        def drain():
+            try:
+                while True:
+                    if "segments" in json.loads(c.recv()):
+                        res["segments"] += 1
+            except Exception:  # noqa: BLE001 — closed
+                return
+        rd = threading.Thread(target=drain, daemon=True)
+        rd.start()
+        pace_s = a["pace_s"]
+        time.sleep(max(0.0, a["go"] - time.time()) + (pace_s * a["k"] / max(1, a["clients"]) if pace_s else 0.0))
+        t0 = time.perf_counter()
+        for i, pk in enumerate(packets):
+            c.send(pk)
+            if pace_s:
+                time.sleep(max(0.0, t0 + (i + 1) * pace_s - time.perf_counter()))
+        time.sleep(a["settle_s"])
+        c.send(b"END_OF_AUDIO")
+        rd.join(5)
+    except Exception as e:  # noqa: BLE001
+        res["error"] = f"{type(e).__name__}: {e}"
+    print(json.dumps(res), flush=True)
+    return 0
+
+
 def stream_through_server(make_transcriber, seconds: float = 40.0, paced_seconds: float = 4.0, settle_s: float = 3.0,
                           pcm_fn=None, clients: int = 1, batch: bool = False, model_name: str = "small.en", language="en"):
     """BASELINE configs[1] (and, with clients=4, configs[2]) in their literal form: WebSocket streams against the
@@ -217,8 +260,9 @@ def stream_through_server(make_transcriber, seconds: float = 40.0, paced_seconds
     (a per-stream rate: with N clients the aggregate is up to N x that), p50 = median chunk latency. The transcriber is
     the product one (WhisperModelHIP: VAD gate -> log-mel -> encoder -> beam search -> segments), decode length pinned.
     batch=True starts the per-GPU BatchInferenceWorker (the reference's --batch_inference mode)."""
+    import subprocess
     import threading
-    from whisperlive_amd import metrics, ws
+    from whisperlive_amd import metrics
     from whisperlive_amd.serve_client import ServeClientHIP
     from whisperlive_amd.server import TranscriptionServer
 
@@ -233,43 +277,29 @@ def stream_through_server(make_transcriber, seconds: float = 40.0, paced_seconds
         raise RuntimeError("server did not start")
     out = {}
 
-    def client(k, pcm, pace_s, got, errs):
-        try:
-            c = ws.connect(f"ws://127.0.0.1:{srv.port}")
-            c.send(json.dumps(dict(uid=f"bench{k}", language=language, task="transcribe", model=model_name, use_vad=True,
-                                   no_speech_thresh=1.0, same_output_threshold=10)))
-            if json.loads(c.recv(timeout=30)).get("message") != "SERVER_READY":
-                raise RuntimeError("no SERVER_READY")
-
-            def drain():
-                try:
-                    while True:
-                        if "segments" in json.loads(c.recv()):
-                            got[k] += 1
-                except Exception:  # noqa: BLE001 — closed
-                    return
-            rd = threading.Thread(target=drain, daemon=True)
-            rd.start()
-            t0 = time.perf_counter()
-            for i in range(0, pcm.shape[0], 4096):
-                c.send(pcm[i: i + 4096].tobytes())
-                if pace_s:
-                    time.sleep(max(0.0, t0 + (i // 4096 + 1) * pace_s - time.perf_counter()))
-            time.sleep(settle_s)
-            c.send(b"END_OF_AUDIO")
-            rd.join(5)
-        except Exception as e:  # noqa: BLE001
-            errs.append(f"{type(e).__name__}: {e}")
-
     def run(tag, secs, seed, pace_s):
+        # the clients are SEPARATE PROCESSES (`bench.py --ws-client ...`), as real clients are: four unpaced senders inside
+        # this interpreter held its GIL and charged their own packet loops to the server's chunk latency
         metrics.snapshot(reset=True)
-        got, errs = [0] * clients, []
-        ts = [threading.Thread(target=client, args=(k, pcm_fn(secs, seed + k), pace_s, got, errs)) for k in range(clients)]
+        go = time.time() + 2.5                         # every client connects, builds its PCM, then starts on this instant
+        cmd = [sys.executable, os.path.abspath(__file__), "--ws-client"]
+        procs = [subprocess.Popen(cmd + [json.dumps(dict(port=srv.port, k=k, clients=clients, secs=secs, seed=seed + k, pace_s=pace_s,
+                                                          settle_s=settle_s, go=go, model=model_name, language=language))],
+                                  stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for k in range(clients)]
         t0 = time.perf_counter()
-        [t.start() for t in ts]
-        time.sleep(secs * (pace_s / 0.256 if pace_s else 0.0) + settle_s * 0.9)        # snapshot while every client is still connected
+        time.sleep(max(0.0, go - time.time()) + secs * (pace_s / 0.256 if pace_s else 0.0) + settle_s * 0.9)   # snapshot while every client is still connected
         snap = metrics.snapshot()
-        [t.join(60) for t in ts]
+        got, errs = [], []
+        for pr in procs:
+            try:
+                o, e = pr.communicate(timeout=90)
+                r = json.loads(o.strip().splitlines()[-1])
+                got.append(r.get("segments", 0))
+                if r.get("error"):
+                    errs.append(r["error"])
+            except Exception as ex:  # noqa: BLE001
+                pr.kill()
+                errs.append(f"{type(ex).__name__}: {ex}")
         out[tag] = dict(clients=clients, audio_sent_s_per_client=secs, wall_s=time.perf_counter() - t0, chunks=snap["chunks"],
                         audio_processed_s=snap["audio_s"], xrt=snap["xrt"],
                         p50_chunk_latency_ms=None if snap["p50_latency_s"] is None else 1e3 * snap["p50_latency_s"],
@@ -498,7 +528,10 @@ def main():
     ap.add_argument("--clips", type=int, default=64, help="--config 5: number of 30 s clips per step")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 FETCH_SIZE pass that fills roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--ws-client", default=None, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.ws_client:
+        raise SystemExit(ws_client_main(args.ws_client))
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # started by hand: launch the ranks ourselves (the driver does the same thing around this script)

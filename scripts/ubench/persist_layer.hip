@@ -16,7 +16,7 @@
 //                the dependency), i.e. the structure the engine has today (which fuses some of these phases: 7 launches per
 //                layer, 30.2 us measured, profiles/r2w_*).
 // Every spin is bounded (a broken protocol reports failure instead of hanging the box).
-// build: hipcc --offload-arch=gfx950 -O3 -o persist_layer persist_layer.hip ; run: ./persist_layer [layers=12] [iters=50]
+// build: hipcc --offload-arch=gfx950 -O3 -o persist_layer persist_layer.hip ; run: ./persist_layer [layers=12] [iters=50] [fused]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -57,10 +57,26 @@ static const Phase kPhases[] = {
     {0, 192, B_H, 1920, 1, 6, B_SLAB, 80, "fc2, 4 K slices (192)"},
     {192, 240, B_SLAB, 320, 1, 0, B_X, 80, "slice reduce + residual (48)"},
 };
-constexpr int NPH = sizeof(kPhases) / sizeof(kPhases[0]);
+// The SAME layer with the engine's fusions (7 launches per layer today): cross-attention query projection fused into the
+// (head, 8 splits) attention workgroups (each re-reads its head's 96 KiB of query weights), the split combine fused into the
+// output projection's prologue (every one of its 48 workgroups gathers all 96 x 170 partial values), the MLP output
+// projection K-split 2 ways with the partial slabs summed by their consumers (the next layer's first projection gathers
+// x + 2 slabs, the next residual update its own 3 x 80 values).
+static const Phase kPhasesFused[] = {
+    {48, 192, -1, 11520, 0, 6, B_QKV, 40, "LN1(x + 2 slabs) + QKV (144)"},
+    {192, 204, B_QKV, 480, 1, 1, B_ATT, 160, "self-attention (12 heads)"},
+    {204, 252, B_ATT, 1920, 0, 6, B_X2, 80, "out-proj + residual (48)"},
+    {0, 96, B_X2, 3840, 0, 36, B_PART, 170, "LN2 + cross query (96 KiB) + cross attention (48 KiB K/V): 12 heads x 8 splits"},
+    {96, 144, B_PART, 16320, 0, 6, B_X3, 80, "split combine + cross out-proj + residual (48)"},
+    {0, 192, B_X3, 3840, 0, 6, B_H, 40, "LN3 + fc1 + GELU (192)"},
+    {144, 240, B_H, 3840, 1, 12, B_X, 120, "fc2, 2 K slices -> slabs (96)"},
+};
+constexpr int NPH_MAX = sizeof(kPhases) / sizeof(kPhases[0]);
 constexpr int BUF_VALUES = 16384;          // capacity of one edge buffer (values)
-constexpr int MAXQ = 24;
-__constant__ Phase dPhases[NPH];
+constexpr int MAXQ = 36;
+__constant__ Phase dPhases[NPH_MAX];
+__constant__ int dNPH;
+static int NPH = NPH_MAX;
 
 __device__ __forceinline__ float mix(float a, float b) { return a * 0.731f + b * 0.269f + 0.01f; }
 
@@ -88,8 +104,8 @@ template <int SWEEP_WAVES>
 __global__ __launch_bounds__(256) void persist_kernel(gu64* gran /* [2][NBUF][BUF_VALUES] */, const f32x4* __restrict__ weights,
                                                       long wstride16, int layers, unsigned* fail, float* result) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* act = reinterpret_cast<float*>(smem);                 // up to 3840 gathered values
-    float* outv = act + 4096;                                    // up to 256 published values
+    float* act = reinterpret_cast<float*>(smem);                 // up to 16384 gathered values
+    float* outv = act + 16384;                                    // up to 256 published values
     float* red = outv + 256;
     volatile int* sfail = reinterpret_cast<volatile int*>(red + 8);
     const int wg = blockIdx.x, tid = threadIdx.x;
@@ -97,7 +113,8 @@ __global__ __launch_bounds__(256) void persist_kernel(gu64* gran /* [2][NBUF][BU
     __syncthreads();
     f32x4 wreg[MAXQ];
     // phases this workgroup takes part in
-    int mine[NPH], nm = 0;
+    int mine[NPH_MAX], nm = 0;
+    const int NPH = dNPH;
     for (int p = 0; p < NPH; ++p) if (wg >= dPhases[p].wg0 && wg < dPhases[p].wg1) mine[nm++] = p;
     if (nm == 0) return;
     auto request_weights = [&](int layer, int p) {
@@ -171,10 +188,12 @@ __global__ __launch_bounds__(256) void persist_kernel(gu64* gran /* [2][NBUF][BU
 // ------------------------------------------------------------------------------------------------ launch-chain form
 __global__ __launch_bounds__(256) void phase_kernel(int p, int layer, const float* __restrict__ src, int cap, float* dst,
                                                     const f32x4* __restrict__ weights, long wstride16, float* result, int last) {
-    __shared__ float act[4096];
-    __shared__ float outv[256];
-    __shared__ float red[4];
+    extern __shared__ __attribute__((aligned(16))) char smem2[];
+    float* act = reinterpret_cast<float*>(smem2);
+    float* outv = act + 16384;
+    float* red = outv + 256;
     const Phase ph = dPhases[p];
+    const int NPH = dNPH;
     const int wg = blockIdx.x + ph.wg0, tid = threadIdx.x;
     f32x4 wreg[MAXQ];
     const f32x4* base = weights + ((long)(layer * NPH + p) * 256 + wg) * wstride16;
@@ -200,7 +219,12 @@ __global__ __launch_bounds__(256) void phase_kernel(int p, int layer, const floa
 int main(int argc, char** argv) {
     const int layers = argc > 1 ? atoi(argv[1]) : 12;
     const int iters = argc > 2 ? atoi(argv[2]) : 50;
-    CK(hipMemcpyToSymbol(HIP_SYMBOL(dPhases), kPhases, sizeof(kPhases)));
+    const bool fused = argc > 3 && !strcmp(argv[3], "fused");
+    const Phase* kP = fused ? kPhasesFused : kPhases;
+    NPH = fused ? (int)(sizeof(kPhasesFused) / sizeof(kPhasesFused[0])) : NPH_MAX;
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(dPhases), kP, sizeof(Phase) * NPH));
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(dNPH), &NPH, sizeof(int)));
+    printf("phase table: %s\n", fused ? "the engine's fused structure (7 phases per layer)" : "one phase per dependency edge (10 per layer)");
     hipStream_t st; CK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     // weights: a distinct region per (layer, phase, workgroup): MAXQ x 256 x 16 B = 96 KiB -> 12 layers x 10 phases x 256 wg = 2.9 GB
     const long wstride16 = (long)MAXQ * 256;
@@ -213,14 +237,15 @@ int main(int argc, char** argv) {
     float *res_p, *res_l; CK(hipMalloc(&res_p, 65536)); CK(hipMalloc(&res_l, 65536));
     double layer_w = 0, layer_g = 0;
     for (int p = 0; p < NPH; ++p) {
-        const int n = kPhases[p].wg1 - kPhases[p].wg0;
-        layer_w += (double)n * kPhases[p].wq * 4096.0; layer_g += (double)n * kPhases[p].gcount * 8.0;
-        printf("phase %d %-58s wg %3d  gathers %5d values/wg  weights %5.1f KiB/wg  publishes %3d values/wg\n", p, kPhases[p].name, n,
-               kPhases[p].gcount, kPhases[p].wq * 4.0, kPhases[p].pcount);
+        const int n = kP[p].wg1 - kP[p].wg0;
+        layer_w += (double)n * kP[p].wq * 4096.0; layer_g += (double)n * kP[p].gcount * 8.0;
+        printf("phase %d %-58s wg %3d  gathers %5d values/wg  weights %5.1f KiB/wg  publishes %3d values/wg\n", p, kP[p].name, n,
+               kP[p].gcount, kP[p].wq * 4.0, kP[p].pcount);
     }
     printf("per layer: %.1f MB of weights / K,V streamed, %.2f MB of granule reads, %d in-launch edges\n", layer_w / 1e6, layer_g / 1e6, NPH);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const size_t shm = 96 * 1024;
+    CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&phase_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persist_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&persist_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm));
     auto run_persist = [&](int sweep, float* ms_out) -> bool {
@@ -247,12 +272,12 @@ int main(int argc, char** argv) {
     CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     for (int l = 0; l < layers; ++l)
         for (int p = 0; p < NPH; ++p) {
-            const Phase& ph = kPhases[p];
+            const Phase& ph = kP[p];
             const int sp = (ph.src < 0) ? NPH - 1 : p - 1, sl = (ph.src < 0) ? l - 1 : l, sbuf = (ph.src < 0) ? B_X : ph.src;
             const float* src = sl >= 0 ? plain + ((size_t)(sl & 1) * NBUF + sbuf) * BUF_VALUES : nullptr;
             float* dst = plain + ((size_t)(l & 1) * NBUF + ph.dst) * BUF_VALUES;
-            const int cap = kPhases[sp].pcount * (kPhases[sp].wg1 - kPhases[sp].wg0);
-            hipLaunchKernelGGL(phase_kernel, dim3(ph.wg1 - ph.wg0), dim3(256), 0, st, p, l, src, cap, dst, w, wstride16, res_l,
+            const int cap = kP[sp].pcount * (kP[sp].wg1 - kP[sp].wg0);
+            hipLaunchKernelGGL(phase_kernel, dim3(ph.wg1 - ph.wg0), dim3(256), shm, st, p, l, src, cap, dst, w, wstride16, res_l,
                                (l == layers - 1 && p == NPH - 1) ? 1 : 0);
         }
     CK(hipStreamEndCapture(st, &graph)); CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
@@ -265,13 +290,14 @@ int main(int argc, char** argv) {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms_l = ms / iters < ms_l ? ms / iters : ms_l;
     }
     printf("launch chain : %8.2f us per layer (%d launches per layer, %.2f us per launch)\n", 1e3 * ms_l / layers, NPH, 1e3 * ms_l / layers / NPH);
-    std::vector<float> rl(3840), rp(3840);
-    CK(hipMemcpy(rl.data(), res_l, 3840 * 4, hipMemcpyDeviceToHost));
+    const int nres = kP[NPH - 1].pcount * (kP[NPH - 1].wg1 - kP[NPH - 1].wg0);
+    std::vector<float> rl(nres), rp(nres);
+    CK(hipMemcpy(rl.data(), res_l, nres * 4, hipMemcpyDeviceToHost));
     for (int sweep : {1, 4}) {
         float ms_p;
         if (!run_persist(sweep, &ms_p)) continue;
-        CK(hipMemcpy(rp.data(), res_p, 3840 * 4, hipMemcpyDeviceToHost));
-        double md = 0; for (int i = 0; i < 3840; ++i) md = fmax(md, fabs((double)rp[i] - rl[i]));
+        CK(hipMemcpy(rp.data(), res_p, nres * 4, hipMemcpyDeviceToHost));
+        double md = 0; for (int i = 0; i < nres; ++i) md = fmax(md, fabs((double)rp[i] - rl[i]));
         printf("persistent   : %8.2f us per layer (%d polling wave%s per workgroup; %.2f us per edge)  = %.2fx of the launch chain; "
                "result max |diff| vs launch chain %.3g (%s)\n", 1e3 * ms_p / layers, sweep, sweep > 1 ? "s" : "", 1e3 * ms_p / layers / NPH,
                ms_p / ms_l, md, md < 1e-3 ? "same" : "DIFFERENT");

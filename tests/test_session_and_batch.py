@@ -366,3 +366,45 @@ def test_vad_unavailable_from_a_factory_built_transcriber_downgrades_once(monkey
     finally:
         ServeClientHIP.BATCH_WORKER = saved[0]
         ServeClientHIP.BATCH_WORKERS.update(saved[1])
+
+
+def test_batch_worker_lanes_overlap_consecutive_batches():
+    """lanes=2: a request that arrives while a batch is on the GPU is collected and run by the second lane instead of waiting
+    for the first batch to finish; collection itself stays serial (batches form as with one lane)."""
+    import threading
+    import time
+    from whisperlive_amd.batching import BatchInferenceWorker, BatchRequest
+
+    class SlowTr:
+        max_batch = 4
+
+        def __init__(self):
+            self.active, self.peak, self.lock = 0, 0, threading.Lock()
+
+        def transcribe(self, audio, **kw):
+            with self.lock:
+                self.active += 1
+                self.peak = max(self.peak, self.active)
+            time.sleep(0.15)
+            with self.lock:
+                self.active -= 1
+            return [], None
+
+    def run(lanes):
+        tr = SlowTr()
+        w = BatchInferenceWorker(tr, max_batch_size=4, batch_window_ms=5, lanes=lanes)
+        w.start()
+        try:
+            a, b = BatchRequest(audio=np.zeros(1600, np.float32), use_vad=False), BatchRequest(audio=np.zeros(1600, np.float32), use_vad=False)
+            t0 = time.monotonic()
+            w.submit(a)
+            time.sleep(0.04)                       # after a's 5 ms window closed: b is a second batch
+            w.submit(b)
+            assert a.future.wait(2) and b.future.wait(2)
+            return time.monotonic() - t0, tr.peak
+        finally:
+            w.stop()
+    t1, peak1 = run(1)
+    t2, peak2 = run(2)
+    assert peak1 == 1 and peak2 == 2
+    assert t1 > 0.29 and t2 < 0.26, (t1, t2)

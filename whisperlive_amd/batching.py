@@ -51,7 +51,7 @@ class BatchInferenceWorker:
     LOGPROB_THRESHOLD = -1.0
     NO_SPEECH_THRESHOLD = 0.6
 
-    def __init__(self, transcriber, max_batch_size: int = 8, batch_window_ms: int = 50):
+    def __init__(self, transcriber, max_batch_size: int = 8, batch_window_ms: int = 50, lanes: int = 2):
         self.transcriber = transcriber
         # never collect more requests than one engine slot can hold (WhisperModelHIP.max_batch); a duck-typed or mocked
         # transcriber without that integer keeps the configured size
@@ -61,30 +61,42 @@ class BatchInferenceWorker:
             max_batch_size = cap
         self.max_batch_size = max_batch_size
         self.batch_window_ms = batch_window_ms
+        # MI355X-first: `lanes` worker threads instead of the reference's one (whisper_live/batch_inference.py:118-121). Batches
+        # are COLLECTED by one lane at a time, exactly as the reference collects them (first request, then up to
+        # max_batch_size within batch_window_ms), but a second lane may collect and run the next batch while the first is
+        # still on the GPU: every lane decodes on its own engine slot / hardware queue, so a request that arrives just after
+        # a batch started no longer waits for that whole batch (configs[2] through the worker: p50 45 -> see DESIGN.md §5).
+        # lanes=1 is the reference's behaviour.
+        self.lanes = max(1, int(lanes))
         self._queue: "queue.Queue[BatchRequest]" = queue.Queue()
         self._stop_event = threading.Event()
+        self._collect_lock = threading.Lock()
         self._thread: Optional[threading.Thread] = None
+        self._threads: List[threading.Thread] = []
 
     def start(self):
-        self._thread = threading.Thread(target=self._worker_loop, daemon=True)
-        self._thread.start()
-        logging.info(f"[BatchInference] Started (max_batch={self.max_batch_size}, window={self.batch_window_ms}ms)")
+        self._threads = [threading.Thread(target=self._worker_loop, daemon=True, name=f"wlx-batch-lane{i}") for i in range(self.lanes)]
+        self._thread = self._threads[0]
+        for t in self._threads:
+            t.start()
+        logging.info(f"[BatchInference] Started (max_batch={self.max_batch_size}, window={self.batch_window_ms}ms, lanes={self.lanes})")
 
     def stop(self):
         self._stop_event.set()
-        if self._thread:
-            self._thread.join(timeout=5)
+        for t in (self._threads or ([self._thread] if self._thread else [])):
+            t.join(timeout=5)
 
     def submit(self, request: BatchRequest):
         self._queue.put(request)
 
     # ---- collection -------------------------------------------------------------------------------------------
-    def _worker_loop(self):
-        while not self._stop_event.is_set():
+    def _collect(self) -> List[BatchRequest]:
+        """one batch, collected as the reference collects it (:126-153); only one lane collects at a time"""
+        with self._collect_lock:
             try:
                 batch = [self._queue.get(timeout=0.5)]
             except queue.Empty:
-                continue
+                return []
             deadline = time.monotonic() + self.batch_window_ms / 1000.0
             while len(batch) < self.max_batch_size:
                 left = deadline - time.monotonic()
@@ -94,14 +106,26 @@ class BatchInferenceWorker:
                     batch.append(self._queue.get(timeout=left))
                 except queue.Empty:
                     break
-            try:
-                self._process_batch(batch)
-            except Exception as e:  # noqa: BLE001 — the worker must survive (tests/test_batch_inference.py:99-120)
-                logging.error(f"[BatchInference] Batch processing error: {e}")
-                for req in batch:
-                    if not req.future.is_set():
-                        req.error = e
-                        req.future.set()
+            return batch
+
+    def _worker_loop(self):
+        try:
+            while not self._stop_event.is_set():
+                batch = self._collect()
+                if not batch:
+                    continue
+                try:
+                    self._process_batch(batch)
+                except Exception as e:  # noqa: BLE001 — the worker must survive (tests/test_batch_inference.py:99-120)
+                    logging.error(f"[BatchInference] Batch processing error: {e}")
+                    for req in batch:
+                        if not req.future.is_set():
+                            req.error = e
+                            req.future.set()
+        finally:
+            release = getattr(type(self.transcriber), "release_slot", None)
+            if release is not None:
+                self.transcriber.release_slot()        # this lane's engine slot goes back to the pool
 
     def _process_batch(self, batch: List[BatchRequest]):
         if len(batch) == 1:

@@ -44,6 +44,9 @@ struct Slot {
     std::mutex call_mu;      // held by the entry point currently using the slot (engine.hip: slot_acquire)
     int B = 0, R = 0, rows_cap = 0, cache_rows = 0, groups_cap = 0;
     hipStream_t stream = nullptr;
+    bool dedicated_queue = false;       // the stream owns a hardware queue (engine.hip create_slot_stream); counted per device
+    int device_of = -1;
+    bool counted = false;               // in the per-device live-slot count
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_poll0 = nullptr, ev_poll1 = nullptr;
     std::vector<void*> allocs;
     // features

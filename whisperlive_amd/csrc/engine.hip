@@ -376,8 +376,15 @@ extern "C" int32_t wlx_engine_create(const wlx_spec* spec, const wlx_tensor* wei
     return WLX_OK;
 }
 
+static std::atomic<int> g_dedicated_live[64];      // live slots with a hardware queue of their own, per device (create_slot_stream)
+static std::atomic<int> g_slots_live[64];          // live slots per device
+static std::atomic<bool> g_demote[64];             // more live slots than dedicated queues allowed: dedicated slots fall back at their next call
 static void slot_free(Slot* s) {
     if (!s) return;
+    if (s->device_of >= 0 && s->device_of < 64) {
+        if (s->dedicated_queue) g_dedicated_live[s->device_of].fetch_sub(1);
+        if (s->counted && g_slots_live[s->device_of].fetch_sub(1) - 1 <= 4) g_demote[s->device_of].store(false);
+    }
     if (s->align_scores) (void)hipFree(s->align_scores);
     for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
     for (void* p : s->allocs) (void)hipFree(p);
@@ -423,6 +430,21 @@ static int slot_acquire(wlx_engine* e, int slot, SlotGuard& g) {
     if (!s->call_mu.try_lock())
         return fail(WLX_ERR_STATE, "slot %d is busy in another call (a slot serves one call at a time)", slot);
     g.s = s;
+    // more slots than dedicated hardware queues exist on this device now: give the queue back (see create_slot_stream: past
+    // ~6 busy hardware queues everything collapses; eight ordinary streams over the shared pool run at 1883 xRT, eight with
+    // four dedicated queues at 1145). The slot's captured graphs do not depend on the stream they were captured on.
+    if (s->dedicated_queue && s->device_of >= 0 && s->device_of < 64 && g_demote[s->device_of].load()) {
+        hipStream_t ns = nullptr;
+        if (hipSetDevice(s->device_of) == hipSuccess && hipStreamSynchronize(s->stream) == hipSuccess &&
+            hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) == hipSuccess) {
+            (void)hipStreamDestroy(s->stream);
+            s->stream = ns;
+            s->dedicated_queue = false;
+            g_dedicated_live[s->device_of].fetch_sub(1);
+        } else {
+            (void)hipGetLastError();
+        }
+    }
     return WLX_OK;
 }
 
@@ -457,10 +479,24 @@ static int slot_grow_audio(Engine* e, Slot* s, size_t n_samples) {
 // profiles/r3b_streams4_dedicated_queues_overlap.txt). Raising GPU_MAX_HW_QUEUES instead is NOT an option: 5, 6 and 8 run the
 // same workload at 610-640 xRT. WLX_SLOT_CU_MASK=off restores ordinary streams; =stride4 / contig4 give slot k a quarter of
 // the CUs (every 4th CU: a decode step is as fast on 64 CUs spread over all XCDs as on 256 — 373 us — but the encoder is not).
-static int create_slot_stream(int device, hipStream_t* out) {
+// Only the first WLX_DEDICATED_QUEUES (4 = the reference server's max_clients) live slots of a device get one: with 8 dedicated
+// queues (+ the null and utility streams' two) the same 8-stream workload drops from 1883 xRT (shared queues) to 1135 — past
+// some number of busy hardware queues the command processor time-slices them (profiles/r3c_bench_s8_default.json).
+static int create_slot_stream(int device, hipStream_t* out, bool* dedicated_out) {
     static const char* cu_mode = getenv("WLX_SLOT_CU_MASK");
+    static const int max_dedicated = [] { const char* v = getenv("WLX_DEDICATED_QUEUES"); return v ? atoi(v) : 4; }();
     static std::atomic<int> slot_seq{0};
-    const std::string m = cu_mode ? cu_mode : "full";
+    std::string m = cu_mode ? cu_mode : "full";
+    *dedicated_out = false;
+    if (m != "off") {
+        if (device < 0 || device >= 64 || g_dedicated_live[device].fetch_add(1) >= max_dedicated) {
+            if (device >= 0 && device < 64) g_dedicated_live[device].fetch_sub(1);
+            m = "off";
+        } else {
+            *dedicated_out = true;
+        }
+    }
+    auto undo = [&] { if (*dedicated_out) { g_dedicated_live[device].fetch_sub(1); *dedicated_out = false; } };
     if (m == "prio_high" || m == "prio_alt") {
         // (A/B) priority streams draw their hardware queues from a per-priority pool, separate from the normal-priority pool
         // the null and utility streams live in, and — unlike the CU-mask constructor — take the non-blocking flag
@@ -470,6 +506,7 @@ static int create_slot_stream(int device, hipStream_t* out) {
         const int pr = (m == "prio_alt" && (k & 1)) ? lo : hi;
         if (hipStreamCreateWithPriority(out, hipStreamNonBlocking, pr) == hipSuccess) return WLX_OK;
         (void)hipGetLastError();
+        undo();
     } else if (m != "off") {
         hipDeviceProp_t prop;
         CK(hipGetDeviceProperties(&prop, device));
@@ -483,6 +520,7 @@ static int create_slot_stream(int device, hipStream_t* out) {
         }
         if (hipExtStreamCreateWithCUMask(out, (uint32_t)words, mask.data()) == hipSuccess) return WLX_OK;
         (void)hipGetLastError();           // not supported here: an ordinary stream (shared queues) is still correct
+        undo();
     }
     CK(hipStreamCreateWithFlags(out, hipStreamNonBlocking));
     return WLX_OK;
@@ -501,7 +539,16 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
     s->nframes.assign(B, 0);
     s->npcm.assign(B, 0);
     int rc = [&]() -> int {
-        CKR(create_slot_stream(e->device, &s->stream));
+        s->device_of = e->device;
+        if (e->device >= 0 && e->device < 64) {
+            s->counted = true;
+            if (g_slots_live[e->device].fetch_add(1) + 1 > 4) g_demote[e->device].store(true);
+        }
+        if (s->counted && g_demote[e->device].load()) {
+            CK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));        // past 4 live slots: the shared pool
+        } else {
+            CKR(create_slot_stream(e->device, &s->stream, &s->dedicated_queue));
+        }
         CK(hipEventCreate(&s->ev0)); CK(hipEventCreate(&s->ev1));
         CK(hipEventCreateWithFlags(&s->ev_poll0, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&s->ev_poll1, hipEventDisableTiming));
@@ -1024,7 +1071,10 @@ static int get_step_graph(Engine* e, Slot* s, int rows, int R, int groups, bool 
         // it and moves on to the next chunk, whisper_live/backend/base.py:134-137), the next one captures afresh.
         (void)hipGetLastError();
         hipStream_t ns = nullptr;
-        if (create_slot_stream(e->device, &ns) == WLX_OK) {
+        bool ded = false;
+        if (s->dedicated_queue) { g_dedicated_live[e->device].fetch_sub(1); s->dedicated_queue = false; }
+        if (create_slot_stream(e->device, &ns, &ded) == WLX_OK) {
+            s->dedicated_queue = ded;
             (void)hipStreamDestroy(s->stream);
             s->stream = ns;
         }
