@@ -697,6 +697,23 @@ def main():
                             "kernels": prof},
             "roofline": roof,
         }
+        if S == 1 and B == 1:
+            # every window after the first of a stream is CONDITIONED on up to 223 previous tokens
+            # (transcriber_faster_whisper.py:1480-1513): the same window with the reference's full prompt [sot_prev] + 223 + [sot]
+            prev = np.random.default_rng(5).integers(0, ids["eot"], size=223).tolist()
+            cprompt = [ids["timestamp_begin"] - 4] + prev + [ids["sot"]]
+            ckw = dict(gen_kw, max_length=len(cprompt) + args.decode_steps)
+            ct = []
+            for i in range(2 + 5):
+                tc0 = time.perf_counter()
+                Tc = slot.logmel_resident(0)
+                slot.encode(1, seek=[0], seg=[min(Tc - 1, 3000)])
+                slot.generate([cprompt], eids, **ckw)
+                if i >= 2:
+                    ct.append(time.perf_counter() - tc0)
+            out["conditioned_window"] = dict(prompt_tokens=len(cprompt), decode_steps=args.decode_steps, ms_per_window=1e3 * float(np.median(ct)),
+                                             xrt=WINDOW_S / float(np.median(ct)), generate_ms=slot.timings()["generate_ms"],
+                                             note="the headline window with the reference's full 225-token conditioning prompt: prompt prefill + the same 64 steps at positions 225..288")
         if world == 1 and S == 1 and B == 1 and not args.no_stream:
             note("stream leg")
             try:

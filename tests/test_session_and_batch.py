@@ -243,7 +243,8 @@ def test_hip_backend_goes_through_the_batch_worker():
     m = _model()
     tk = Tokenizer(m.hf_tokenizer, False)
     m.engine.default_tokens = [tk.timestamp_begin] + tk.encode(" batched") + [tk.timestamp_begin + 40]
-    w = BatchInferenceWorker(m, max_batch_size=4, batch_window_ms=150); w.start()
+    # wait_when_idle=True: the reference's collection (always wait out the window), so the three requests form ONE batch
+    w = BatchInferenceWorker(m, max_batch_size=4, batch_window_ms=150, wait_when_idle=True); w.start()
     ServeClientHIP.BATCH_WORKER = w
     try:
         cs = [ServeClientHIP(MagicMock(), client_uid=f"c{i}", model="small.en", transcriber=m, start_thread=False, use_vad=False)
@@ -408,3 +409,43 @@ def test_batch_worker_lanes_overlap_consecutive_batches():
     t2, peak2 = run(2)
     assert peak1 == 1 and peak2 == 2
     assert t1 > 0.29 and t2 < 0.26, (t1, t2)
+
+
+def test_batch_worker_starts_at_once_when_idle_and_batches_while_busy():
+    """The collection window only pays while the GPU is busy: an idle worker takes the first request immediately (plus
+    whatever is already queued); requests that arrive while a batch runs are collected over the window and batched."""
+    import threading
+    import time
+    from whisperlive_amd.batching import BatchInferenceWorker, BatchRequest
+
+    sizes, lock = [], threading.Lock()
+
+    class W(BatchInferenceWorker):
+        def _process_batch(self, batch):
+            with lock:
+                sizes.append(len(batch))
+            time.sleep(0.12)
+            for r in batch:
+                r.result = []
+                r.future.set()
+
+    mk = lambda: BatchRequest(audio=np.zeros(1600, np.float32), use_vad=False)
+    w = W(MagicMock(max_batch=4), max_batch_size=4, batch_window_ms=60, lanes=2)
+    w.start()
+    try:
+        a = mk(); t0 = time.monotonic(); w.submit(a)
+        time.sleep(0.03)                                    # a runs alone, at once (no 60 ms wait)
+        b, c = mk(), mk(); w.submit(b); time.sleep(0.02); w.submit(c)      # busy: the second lane waits out its window -> {b, c}
+        assert a.future.wait(1) and b.future.wait(1) and c.future.wait(1)
+        assert time.monotonic() - t0 < 0.30
+        assert sizes == [1, 2], sizes
+    finally:
+        w.stop()
+    sizes.clear()
+    w = W(MagicMock(max_batch=4), max_batch_size=4, batch_window_ms=60, lanes=1, wait_when_idle=True)   # the reference's collection
+    w.start()
+    try:
+        a, b = mk(), mk(); w.submit(a); time.sleep(0.02); w.submit(b)
+        assert a.future.wait(1) and b.future.wait(1) and sizes == [2]
+    finally:
+        w.stop()

@@ -51,7 +51,8 @@ class BatchInferenceWorker:
     LOGPROB_THRESHOLD = -1.0
     NO_SPEECH_THRESHOLD = 0.6
 
-    def __init__(self, transcriber, max_batch_size: int = 8, batch_window_ms: int = 50, lanes: int = 2):
+    def __init__(self, transcriber, max_batch_size: int = 8, batch_window_ms: int = 50, lanes: int = 2,
+                 wait_when_idle: bool = False):
         self.transcriber = transcriber
         # never collect more requests than one engine slot can hold (WhisperModelHIP.max_batch); a duck-typed or mocked
         # transcriber without that integer keeps the configured size
@@ -68,6 +69,13 @@ class BatchInferenceWorker:
         # a batch started no longer waits for that whole batch (configs[2] through the worker: p50 45 -> see DESIGN.md §5).
         # lanes=1 is the reference's behaviour.
         self.lanes = max(1, int(lanes))
+        # The collection window exists to let more requests join a batch — which only pays while the GPU is busy with an
+        # earlier batch (rows that join a decode are almost free, a batch that waits behind another is not). With every lane
+        # idle the first request of a batch therefore starts at once unless more requests are ALREADY queued; the reference
+        # always waits out its window (:140-153; wait_when_idle=True restores that).
+        self.wait_when_idle = bool(wait_when_idle)
+        self._busy = 0
+        self._busy_lock = threading.Lock()
         self._queue: "queue.Queue[BatchRequest]" = queue.Queue()
         self._stop_event = threading.Event()
         self._collect_lock = threading.Lock()
@@ -97,8 +105,19 @@ class BatchInferenceWorker:
                 batch = [self._queue.get(timeout=0.5)]
             except queue.Empty:
                 return []
-            deadline = time.monotonic() + self.batch_window_ms / 1000.0
+            with self._busy_lock:
+                idle = self._busy == 0
+            window = self.batch_window_ms / 1000.0
+            if idle and not self.wait_when_idle:
+                window = 0.0                          # nothing on the GPU: take what is already queued, wait for nothing
+            deadline = time.monotonic() + window
             while len(batch) < self.max_batch_size:
+                if window == 0.0:
+                    try:
+                        batch.append(self._queue.get_nowait())
+                        continue
+                    except queue.Empty:
+                        break
                 left = deadline - time.monotonic()
                 if left <= 0:
                     break
@@ -106,6 +125,8 @@ class BatchInferenceWorker:
                     batch.append(self._queue.get(timeout=left))
                 except queue.Empty:
                     break
+            with self._busy_lock:
+                self._busy += 1                       # counted before the next lane may start collecting
             return batch
 
     def _worker_loop(self):
@@ -122,6 +143,9 @@ class BatchInferenceWorker:
                         if not req.future.is_set():
                             req.error = e
                             req.future.set()
+                finally:
+                    with self._busy_lock:
+                        self._busy -= 1
         finally:
             release = getattr(type(self.transcriber), "release_slot", None)
             if release is not None:

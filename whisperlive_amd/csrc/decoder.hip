@@ -440,7 +440,23 @@ __device__ __forceinline__ void stage_rows_f16(const half_t* __restrict__ X, lon
 template <int CH, int LNV, int IN, int OUT, int NTB, int MT, int XS>
 // (<= 8 waves wherever the kernel holds more than one row tile of fragments: 256 VGPRs per lane — at 16 waves the
 // two- and three-tile residual projections spilled, 36-180 bytes of scratch per lane)
-__global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1) ? 512 : 1024) void dec_gemv2_kernel(GemvParams p) {
+__global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1) ? 512 : 1024) void dec_gemv2_kernel(GemvParams p_in) {
+    // Row chunks (prompt prefill, round 3): a pass over up to 448 rows runs every projection as ONE launch whose grid.z walks
+    // chunks of 48 rows (three MFMA row tiles, the widest this kernel holds); a chunk is this kernel on rebased row pointers.
+    // Decode steps launch with Mtot = 0 and skip the block (a scalar branch).
+    GemvParams p = p_in;
+    if (p_in.Mtot > 0) {
+        const int r0 = (int)blockIdx.z * 48;
+        p.M = (p_in.Mtot - r0 < 48) ? p_in.Mtot - r0 : 48;
+        if (p.X) p.X += (long)r0 * p.ldx;
+        if (p.Xh) p.Xh += (long)r0 * p.ldxh;
+        if (p.Yh) p.Yh += (long)r0 * p.ldyh;
+        if (p.Y) p.Y += (long)r0 * p.ldy;
+        if (p.Xres) p.Xres += (long)r0 * p.ldxres;
+        if (p.slab) p.slab += (long)r0 * ((IN == GEMV_IN_LN) ? p.ldx : p.ldxres);
+        if (p.row_cache) p.row_cache += r0;
+        if (p.row_pos) p.row_pos += r0;
+    }
     static_assert(XS == GEMV_X_PLAIN || IN == GEMV_IN_LN || (IN == GEMV_IN_F16 && OUT == GEMV_OUT_RESID && NTB == 1),
                   "slab / embedding sources: LayerNorm prologue or residual epilogue only");
     static_assert(OUT != GEMV_OUT_SLAB || (IN == GEMV_IN_F16 && NTB == 1), "K-split form: fp16 rows in");
@@ -1012,6 +1028,13 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     c.MT = (p.M + 15) / 16;
     c.shm = sizeof(float) * (size_t)c.nw * c.NTB * c.MT * 256;
     const size_t xs_bytes = (size_t)p.M * (KTf * 32 + 8) * sizeof(half_t);    // fp16 activation rows
+    // two tiles per workgroup are an optimisation, not a requirement: where their reduction buffer plus the staged rows pass
+    // a CU's LDS (large-v3's first MLP projection at 41..48 rows: 49 + 124 KiB) one tile per workgroup still runs lean —
+    // this shape used to fall back to the first-generation kernel (48-row prompt-prefill chunks of large-v3)
+    if (c.NTB == 2 && p.out_mode == GEMV_OUT_GELU_F16 && c.shm + xs_bytes > WLX_G2_LDS_MAX) {
+        c.NTB = 1;
+        c.shm = sizeof(float) * (size_t)c.nw * c.NTB * c.MT * 256;
+    }
     c.xstage = true;
     if (p.in_mode == GEMV_IN_F16 && (c.MT > 1 || c.shm + xs_bytes > 64 * 1024)) c.xstage = false;   // fragments from global instead
     if (c.xstage) c.shm += xs_bytes;
@@ -1070,7 +1093,7 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
       snprintf(nm[q], 48, "gemv2<%d,%d,%d> N%d K%d", p.in_mode, p.out_mode, p.xsrc, p.N, p.K); p.trc = trace_next(nm[q]); }
 #endif
     const int NT_total = (p.N + 15) / 16;
-    dim3 grid((NT_total + c.NTB - 1) / c.NTB, p.out_mode == GEMV_OUT_SLAB ? p.KT / p.KTS : 1), block(c.nw * 64);
+    dim3 grid((NT_total + c.NTB - 1) / c.NTB, p.out_mode == GEMV_OUT_SLAB ? p.KT / p.KTS : 1, p.Mtot > 0 ? (p.Mtot + 47) / 48 : 1), block(c.nw * 64);
     if (p.in_mode == GEMV_IN_XATTN) {      // helper waves for the combine: one thread per (row, head, 4-float group), <= 1024
         const int want = (p.M * p.H * 8 + 63) / 64;
         block.x = 64 * std::max(c.nw, std::min(c.MT > 1 ? 8 : 16, want));
@@ -1119,12 +1142,19 @@ static bool gemv2_ok(const GemvParams& p, Gemv2Cfg* out) {
     if (out) *out = c;
     return true;
 }
-bool dec_gemv_is_lean(const GemvParams& p) { return gemv2_ok(p, nullptr); }
+// more than 48 rows (prompt prefill): the lean kernel in row chunks of 48 (grid.z), configured for a full chunk
+static GemvParams gemv_chunked(const GemvParams& p) {
+    GemvParams q = p;
+    if (p.M > 48 && p.Mtot == 0 && p.in_mode != GEMV_IN_XATTN && p.xsrc != GEMV_X_EMBED) { q.Mtot = p.M; q.M = 48; }
+    return q;
+}
+bool dec_gemv_is_lean(const GemvParams& p) { return gemv2_ok(gemv_chunked(p), nullptr); }
 
 int dec_gemv_slab_split(int M, int K, int N) {
     static const int ks_env = [] { const char* e = getenv("WLX_FC2_KS"); return e ? atoi(e) : WLX_FC2_KS; }();
     if (ks_env != WLX_FC2_KS || WLX_FC2_KS < 2) return 0;                     // (the slab count is a compile-time constant of the consumers)
-    if (g_decode_v1 || M < 1 || M > 48 || K % 32 || (K / 32) % WLX_FC2_KS || K < 2048) return 0;
+    if (M > 48) M = 48;                                                       // row chunks (prompt prefill): decided for a full chunk
+    if (g_decode_v1 || M < 1 || K % 32 || (K / 32) % WLX_FC2_KS || K < 2048) return 0;
     GemvParams p{};
     p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_SLAB; p.M = M; p.K = K; p.KT = K / 32; p.N = N; p.KTS = p.KT / WLX_FC2_KS;
     static const float dummy_bias = 0.f;
@@ -1134,8 +1164,9 @@ int dec_gemv_slab_split(int M, int K, int N) {
     return WLX_FC2_KS;
 }
 
-const char* dec_gemv_kernel_name(const GemvParams& p) {
+const char* dec_gemv_kernel_name(const GemvParams& p_any) {
     static thread_local char buf[64];
+    const GemvParams p = gemv_chunked(p_any);
     const int MT = (p.M + 15) / 16;
     Gemv2Cfg c2;
     if (gemv2_ok(p, &c2)) {
@@ -1155,9 +1186,11 @@ static void gemv_dispatch_in(const GemvParams& p, dim3 grid, dim3 block, size_t 
     }
 }
 
-void launch_dec_gemv(const GemvParams& p0, hipStream_t s) {
+void launch_dec_gemv(const GemvParams& p_any, hipStream_t s) {
     Gemv2Cfg c2;
-    if (gemv2_ok(p0, &c2) && gemv2_launch(p0, c2, s)) return;
+    const GemvParams pc = gemv_chunked(p_any);
+    if (gemv2_ok(pc, &c2) && gemv2_launch(pc, c2, s)) return;
+    const GemvParams& p0 = p_any;
     const GemvParams& p = p0;
     const int MT = (p.M + 15) / 16;
     const int NT_total = (p.N + 15) / 16;

@@ -70,6 +70,14 @@ struct Slot {
     float *part_ml = nullptr, *logits = nullptr;
     long ldl = 0;
     int *d_token = nullptr, *d_pos = nullptr, *d_cache = nullptr, *d_ancrow = nullptr, *d_group_item = nullptr;
+    // the decoder pass's working set (scratch rows + row tables): `step` = the decode steps and chunked passes (rows_cap = 64
+    // rows, the members above), `pf` = the one-pass prompt prefill (up to 448 rows: engine.hip prefill_tokens)
+    struct DecBufs {
+        float* xd; half_t *qd, *attnd, *hd; float* slab; int slab_rows; half_t* part_o; float* part_ml;
+        int *d_token, *d_pos, *d_cache, *d_ancrow, *d_group_item;
+    };
+    DecBufs pf{};
+    bool pf_ok = false;                 // every projection of this model runs on the lean kernel in row chunks (decided at creation)
     short* d_anc = nullptr; int* d_intok = nullptr;
     bool anc_ident = false;                          // the uploaded row tables have ancrow[r] == r (decode steps; upload_rows)
     SearchState st{};

@@ -580,6 +580,24 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         CKR(dalloc(s->allocs, &s->slab, (size_t)WLX_FC2_KS * 48 * d));
         CKR(dalloc(s->allocs, &s->part_o, (size_t)s->groups_cap * e->H * WLX_XSPLIT * 16 * 64));
         CKR(dalloc(s->allocs, &s->part_ml, (size_t)s->groups_cap * e->H * WLX_XSPLIT * 16 * 2));
+        {   // the one-pass prompt prefill's working set: up to WLX_T_TEXT rows (engine.hip prefill_tokens)
+            const size_t PR = WLX_T_TEXT, PG = (WLX_T_TEXT + 15) / 16;
+            Slot::DecBufs& b = s->pf;
+            b.slab_rows = (int)PR;
+            CKR(dalloc(s->allocs, &b.xd, PR * d)); CKR(dalloc(s->allocs, &b.qd, PR * d)); CKR(dalloc(s->allocs, &b.attnd, PR * d));
+            CKR(dalloc(s->allocs, &b.hd, PR * F)); CKR(dalloc(s->allocs, &b.slab, (size_t)WLX_FC2_KS * PR * d));
+            CKR(dalloc(s->allocs, &b.part_o, PG * e->H * WLX_XSPLIT * 16 * 64));
+            CKR(dalloc(s->allocs, &b.part_ml, PG * e->H * WLX_XSPLIT * 16 * 2));
+            CKR(dalloc(s->allocs, &b.d_token, PR)); CKR(dalloc(s->allocs, &b.d_pos, PR)); CKR(dalloc(s->allocs, &b.d_cache, PR));
+            CKR(dalloc(s->allocs, &b.d_ancrow, PR)); CKR(dalloc(s->allocs, &b.d_group_item, PG));
+            // usable when every projection of this model takes the lean kernel in row chunks (d_model a multiple of 256, ...)
+            GemvParams q{};
+            static const float dummy_bias = 0.f;
+            q.M = 96; q.bias = &dummy_bias; q.xsrc = GEMV_X_PLAIN;
+            auto lean = [&](int in, int out, int N, int K) { q.in_mode = in; q.out_mode = out; q.N = N; q.K = K; q.KT = K / 32; return dec_gemv_is_lean(q); };
+            s->pf_ok = lean(GEMV_IN_LN, GEMV_OUT_QKV, 3 * d, d) && lean(GEMV_IN_F16, GEMV_OUT_RESID, d, d) && lean(GEMV_IN_LN, GEMV_OUT_F16, d, d) &&
+                       lean(GEMV_IN_LN, GEMV_OUT_GELU_F16, F, d) && lean(GEMV_IN_F16, GEMV_OUT_RESID, d, F);
+        }
         s->ldl = ((sp.vocab + 15) / 16) * 16;
         CKR(dalloc(s->allocs, &s->logits, (size_t)RC * s->ldl));
         CKR(dalloc(s->allocs, &s->d_token, (size_t)RC));
@@ -861,29 +879,39 @@ static void pgemv(Slot* s, const GemvParams& p) {
 // ------------------------------------------------------------------------------------------------
 // decoder pass: embed -> L x {self-attn block, cross-attn block, MLP} -> (final LN + vocab projection)
 // Row tables / ancestry must already be on the device. `rows` live rows in `groups` groups of R rows.
-static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool with_logits, bool check_done) {
+static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool with_logits, bool check_done, const Slot::DecBufs* alt = nullptr) {
     const wlx_spec& sp = e->spec;
     const int d = sp.d_model, F = sp.ffn, H = e->H;
+    // the working set: the slot's own (decode steps, chunked passes) or the prompt-prefill set (alt); everything else
+    // (stream, KV caches, cross K/V, ancestry, profiler hook) is the slot's
+    struct View {
+        Slot* base; float* xd; half_t *qd, *attnd, *hd; float* slab; long slab_rows; half_t* part_o; float* part_ml;
+        int *d_token, *d_pos, *d_cache, *d_ancrow, *d_group_item;
+        Slot* operator->() const { return base; }
+    } s{s_, alt ? alt->xd : s_->xd, alt ? alt->qd : s_->qd, alt ? alt->attnd : s_->attnd, alt ? alt->hd : s_->hd,
+        alt ? alt->slab : s_->slab, alt ? (long)alt->slab_rows : 48L, alt ? alt->part_o : s_->part_o, alt ? alt->part_ml : s_->part_ml,
+        alt ? alt->d_token : s_->d_token, alt ? alt->d_pos : s_->d_pos, alt ? alt->d_cache : s_->d_cache,
+        alt ? alt->d_ancrow : s_->d_ancrow, alt ? alt->d_group_item : s_->d_group_item};
     hipStream_t st = s->stream;
     // The decoder pass only rewrites scratch and re-appends the same K/V at the same position when it runs once
     // more after the search has raised `done` (the host runs at most one step ahead), so the second-generation
     // kernels do not test the flag: the test was a dependent scalar load at the head of ~100 launches per step.
     const int* done = (check_done && g_decode_v1) ? s->st.done : nullptr;
-    RowTables rt{s->d_token, s->d_pos, s->d_cache, s->d_ancrow, s->d_anc, s->d_intok};
+    RowTables rt{s.d_token, s.d_pos, s.d_cache, s.d_ancrow, s->d_anc, s->d_intok};
     const long crs = (long)WLX_T_TEXT * d;
     // ---- the parameter sets of one layer (the first projection's residual source is filled in below)
     auto qkv_params = [&](int l, int xsrc) {
         const DecLayerW& w = e->dec[l];
         GemvParams p{};
         p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_QKV; p.M = rows; p.K = d; p.KT = d / 32; p.N = 3 * d;
-        p.Wp = w.Wqkv; p.bias = w.bqkv; p.X = s->xd; p.ldx = d; p.gamma = w.ln1_g; p.beta = w.ln1_b;
-        p.Yh = s->qd; p.ldyh = d; p.d = d; p.qscale = 0.125f;
+        p.Wp = w.Wqkv; p.bias = w.bqkv; p.X = s.xd; p.ldx = d; p.gamma = w.ln1_g; p.beta = w.ln1_b;
+        p.Yh = s.qd; p.ldyh = d; p.d = d; p.qscale = 0.125f;
         p.Kc = s->kc + (size_t)l * s->cache_rows * crs; p.Vc = s->vc + (size_t)l * s->cache_rows * crs; p.cache_row_stride = crs;
-        p.row_cache = s->d_cache; p.row_pos = s->d_pos; p.done = done;
-        p.xsrc = xsrc; p.slab = s->slab; p.slab_stride = (long)48 * d;
+        p.row_cache = s.d_cache; p.row_pos = s.d_pos; p.done = done;
+        p.xsrc = xsrc; p.slab = s.slab; p.slab_stride = s.slab_rows * d;
         if (xsrc == GEMV_X_EMBED) {
-            p.tok_emb = e->tok_emb16; p.pos_emb = e->dec_pos; p.emb_token = s->d_token; p.intok = s->d_intok;
-            p.Xres = s->xd; p.ldxres = d;
+            p.tok_emb = e->tok_emb16; p.pos_emb = e->dec_pos; p.emb_token = s.d_token; p.intok = s->d_intok;
+            p.Xres = s.xd; p.ldxres = d;
         }
         return p;
     };
@@ -891,16 +919,16 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
         const DecLayerW& w = e->dec[l];
         GemvParams p{};
         p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
-        p.Wp = w.Wo; p.bias = w.bo; p.Xh = s->attnd; p.ldxh = d; p.Xres = s->xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
-        p.xsrc = xsrc; p.slab = s->slab; p.slab_stride = (long)48 * d;
+        p.Wp = w.Wo; p.bias = w.bo; p.Xh = s.attnd; p.ldxh = d; p.Xres = s.xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
+        p.xsrc = xsrc; p.slab = s.slab; p.slab_stride = s.slab_rows * d;
         return p;
     };
     auto vocab_params = [&](int xsrc) {
         GemvParams p{};
         p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_F32; p.M = rows; p.K = d; p.KT = d / 32; p.N = sp.vocab;
-        p.Wp = e->Wvocab; p.bias = nullptr; p.X = s->xd; p.ldx = d; p.gamma = e->dec_ln_g; p.beta = e->dec_ln_b;
+        p.Wp = e->Wvocab; p.bias = nullptr; p.X = s.xd; p.ldx = d; p.gamma = e->dec_ln_g; p.beta = e->dec_ln_b;
         p.Y = s->logits; p.ldy = s->ldl; p.qscale = 1.f; p.done = done;
-        p.xsrc = xsrc; p.slab = s->slab; p.slab_stride = (long)48 * d;
+        p.xsrc = xsrc; p.slab = s.slab; p.slab_stride = s.slab_rows * d;
         return p;
     };
     // ---- what this pass may use (decided once, from the shapes only — never from what a profiling filter lets through):
@@ -911,16 +939,16 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
     if (KS && !(dec_gemv_is_lean(qkv_params(0, GEMV_X_SLABS)) && dec_gemv_is_lean(oproj_params(0, GEMV_X_SLABS)))) KS = 0;
     const bool fold_embed = !no_fold && rows <= 48 && dec_gemv_is_lean(qkv_params(0, GEMV_X_EMBED));
     if (!fold_embed)
-        plaunch(s, "dec_embed_kernel", (double)rows * d * (2 + 4), [&] { launch_dec_embed(e->tok_emb16, e->dec_pos, d, rt, rows, s->xd, done, st); });
+        plaunch(s.base, "dec_embed_kernel", (double)rows * d * (2 + 4), [&] { launch_dec_embed(e->tok_emb16, e->dec_pos, d, rt, rows, s.xd, done, st); });
     bool slabs_pending = false;             // the residual stream is xd + slabs until the next residual update writes the sum back
     for (int l = 0; l < sp.dec_layers; ++l) {
         const DecLayerW& w = e->dec[l];
         half_t* kc = s->kc + (size_t)l * s->cache_rows * crs;
         half_t* vc = s->vc + (size_t)l * s->cache_rows * crs;
         // LN1 + QKV, K/V appended to the self-attention cache
-        pgemv(s, qkv_params(l, (l == 0 && fold_embed) ? GEMV_X_EMBED : (slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN)));
-        plaunch(s, "dec_self_attn2_kernel", 4.0 * rows * d * (s->prof ? s->prof->t + 1 : 1), [&] { launch_dec_self_attn(s->qd, d, kc, vc, crs, d, H, rt, rows, s->attnd, d, done, s->anc_ident, st); });
-        pgemv(s, oproj_params(l, slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN));
+        pgemv(s.base, qkv_params(l, (l == 0 && fold_embed) ? GEMV_X_EMBED : (slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN)));
+        plaunch(s.base, "dec_self_attn2_kernel", 4.0 * rows * d * (s->prof ? s->prof->t + 1 : 1), [&] { launch_dec_self_attn(s.qd, d, kc, vc, crs, d, H, rt, rows, s.attnd, d, done, s->anc_ident, st); });
+        pgemv(s.base, oproj_params(l, slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN));
         slabs_pending = false;
         GemvParams p{};
         // LN2 + cross-attention query + cross-attention partials: one fused launch when the shape allows and nobody needs
@@ -929,56 +957,56 @@ static void decoder_pass(Engine* e, Slot* s, int rows, int R, int groups, bool w
         const half_t* cvl = s->cvt + (size_t)l * s->B * d * WLX_T_AUDIO_PAD;
         const bool fused = !s->align && dec_cq_cross_attn_eligible(d, H, R);
         if (fused)
-            plaunch(s, "dec_cq_cross_attn_kernel", 2.0 * d * d + 4.0 * groups * WLX_T_AUDIO * d, [&] {
-                launch_dec_cq_cross_attn(s->xd, d, w.ln2_g, w.ln2_b, w.Wcq, w.bcq, 0.125f, d, ckl, cvl, (long)WLX_T_AUDIO_PAD * d, H, R,
-                                         groups, rows, s->d_group_item, s->part_o, s->part_ml, st);
+            plaunch(s.base, "dec_cq_cross_attn_kernel", 2.0 * d * d + 4.0 * groups * WLX_T_AUDIO * d, [&] {
+                launch_dec_cq_cross_attn(s.xd, d, w.ln2_g, w.ln2_b, w.Wcq, w.bcq, 0.125f, d, ckl, cvl, (long)WLX_T_AUDIO_PAD * d, H, R,
+                                         groups, rows, s.d_group_item, s.part_o, s.part_ml, st);
             });
         if (!fused) {
             p = GemvParams{};
             p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_F16; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
-            p.Wp = w.Wcq; p.bias = w.bcq; p.X = s->xd; p.ldx = d; p.gamma = w.ln2_g; p.beta = w.ln2_b;
-            p.Yh = s->qd; p.ldyh = d; p.qscale = 0.125f; p.done = done;
-            pgemv(s, p);
+            p.Wp = w.Wcq; p.bias = w.bcq; p.X = s.xd; p.ldx = d; p.gamma = w.ln2_g; p.beta = w.ln2_b;
+            p.Yh = s.qd; p.ldyh = d; p.qscale = 0.125f; p.done = done;
+            pgemv(s.base, p);
             if (s->align) {     // word alignment: raw q.k of this layer's alignment heads for the rows of this chunk
                 const Slot::AlignCapture& a = *s->align;
                 for (int hi = 0; hi < a.n_heads; ++hi)
                     if (a.heads[2 * hi] == l)
-                        launch_dec_align_scores(s->qd, d, s->ck + ((size_t)l * s->B + a.item) * WLX_T_AUDIO_PAD * d, a.heads[2 * hi + 1], rows,
+                        launch_dec_align_scores(s.qd, d, s->ck + ((size_t)l * s->B + a.item) * WLX_T_AUDIO_PAD * d, a.heads[2 * hi + 1], rows,
                                                 a.scores + ((size_t)hi * a.n_tok + a.row0) * WLX_T_AUDIO_PAD, st);
             }
-            plaunch(s, "dec_cross_attn_kernel", 4.0 * groups * WLX_T_AUDIO * d, [&] {
-                launch_dec_cross_attn(s->qd, d, ckl, cvl, (long)WLX_T_AUDIO_PAD * d, H, R, groups, rows, s->d_group_item, s->part_o, s->part_ml, st);
+            plaunch(s.base, "dec_cross_attn_kernel", 4.0 * groups * WLX_T_AUDIO * d, [&] {
+                launch_dec_cross_attn(s.qd, d, ckl, cvl, (long)WLX_T_AUDIO_PAD * d, H, R, groups, rows, s.d_group_item, s.part_o, s.part_ml, st);
             });
         }
         p = GemvParams{};
         p.in_mode = GEMV_IN_XATTN; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
-        p.Wp = w.Wco; p.bias = w.bco; p.part_o = s->part_o; p.part_ml = s->part_ml; p.H = H; p.R = R;
-        p.Xres = s->xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
+        p.Wp = w.Wco; p.bias = w.bco; p.part_o = s.part_o; p.part_ml = s.part_ml; p.H = H; p.R = R;
+        p.Xres = s.xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
         static const bool no_sep = [] { const char* v = getenv("WLX_XATTN_SEPARATE"); return v && v[0] == '0'; }();   // (A/B)
         if (rows > 16 && !no_sep) {
             // batched rows: the split combine once, in its own launch, then a plain fp16-rows-in projection (decoder.hip)
-            plaunch(s, "dec_xattn_combine_kernel", 0.0, [&] { launch_dec_xattn_combine(s->part_o, s->part_ml, rows, H, R, s->attnd, d, st); });
-            p.in_mode = GEMV_IN_F16; p.Xh = s->attnd; p.ldxh = d;
+            plaunch(s.base, "dec_xattn_combine_kernel", 0.0, [&] { launch_dec_xattn_combine(s.part_o, s.part_ml, rows, H, R, s.attnd, d, st); });
+            p.in_mode = GEMV_IN_F16; p.Xh = s.attnd; p.ldxh = d;
         }
-        pgemv(s, p);
+        pgemv(s.base, p);
         // LN3 + MLP
         p = GemvParams{};
         p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_GELU_F16; p.M = rows; p.K = d; p.KT = d / 32; p.N = F;
-        p.Wp = w.W1; p.bias = w.b1; p.X = s->xd; p.ldx = d; p.gamma = w.ln3_g; p.beta = w.ln3_b;
-        p.Yh = s->hd; p.ldyh = F; p.qscale = 1.f; p.done = done;
-        pgemv(s, p);
+        p.Wp = w.W1; p.bias = w.b1; p.X = s.xd; p.ldx = d; p.gamma = w.ln3_g; p.beta = w.ln3_b;
+        p.Yh = s.hd; p.ldyh = F; p.qscale = 1.f; p.done = done;
+        pgemv(s.base, p);
         p = GemvParams{};
         p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = F; p.KT = F / 32; p.N = d;
-        p.Wp = w.W2; p.bias = w.b2; p.Xh = s->hd; p.ldxh = F; p.Xres = s->xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
+        p.Wp = w.W2; p.bias = w.b2; p.Xh = s.hd; p.ldxh = F; p.Xres = s.xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
         // the last layer keeps the single launch: its consumer would be the vocabulary projection, thousands of workgroups
         // that would each sum the slabs (measured: +2.2 us there against 1.2 us saved here, profiles/r2f_*)
         if (KS && l + 1 < sp.dec_layers) {
-            p.out_mode = GEMV_OUT_SLAB; p.KTS = p.KT / KS; p.slab = s->slab; p.slab_stride = (long)48 * d;
+            p.out_mode = GEMV_OUT_SLAB; p.KTS = p.KT / KS; p.slab = s.slab; p.slab_stride = s.slab_rows * d;
             slabs_pending = true;
         }
-        pgemv(s, p);
+        pgemv(s.base, p);
     }
-    if (with_logits) pgemv(s, vocab_params(GEMV_X_PLAIN));
+    if (with_logits) pgemv(s.base, vocab_params(GEMV_X_PLAIN));
 }
 
 // upload row tables for a pass: token/pos/cache/ancrow [rows], group_item [groups]
@@ -1005,11 +1033,51 @@ static int upload_rows(Slot* s, const std::vector<int>& token, const std::vector
 }
 
 // prefill `n` tokens of one sequence (audio item `item`, KV-cache row `crow`) starting at position pos0,
-// in chunks of <= 64 rows; if logits_out != null the vocabulary projection runs and rows are copied out.
+// in chunks of <= 48 rows (below); if logits_out != null the vocabulary projection runs and rows are copied out.
 static int prefill_tokens(Engine* e, Slot* s, int item, int crow, const int* tokens, int pos0, int n,
                           float* logits_host, int nsp_index, int nsp_token, float* nsp_out) {
-    for (int c0 = 0; c0 < n; c0 += 64) {
-        const int rows = std::min(64, n - c0);
+    // ONE pass over the whole prompt (round 3): every window after the first carries up to 224 prompt tokens
+    // (transcriber_faster_whisper.py:1480-1513) and the chunked form below costs a full ~87-launch decoder pass per 48 rows —
+    // 4.6 ms for 224 tokens on Whisper-small, 18 ms on large-v3 (profiles/r3f_prefill_time.txt), 16-19 % of a window. Here
+    // the pass runs ONCE over all rows: each projection is one launch of the lean kernel whose grid.z walks 48-row chunks
+    // (the weight tiles are re-read from L2 by the chunks), attention and combine launches take the rows as they are.
+    // Logits are only needed at the <|startoftranscript|> row (no_speech_prob); callers that want every row's logits
+    // (debug hook) keep the chunked form.
+    const bool one_pass = [] { const char* v = getenv("WLX_PREFILL_ONE_PASS"); return !(v && v[0] == '0'); }();   // (read per call: the A/B test toggles it)
+    if (one_pass && s->pf_ok && !logits_host && !s->align && !s->prof && n > 48 && n <= WLX_T_TEXT && !g_decode_v1) {
+        const int rows = n, groups = (rows + 15) / 16;
+        if ((size_t)(4 * rows + groups) > s->h_stage_ints - 8) return fail(WLX_ERR_ARG, "prompt too long");
+        CK(hipStreamSynchronize(s->stream));                       // the shared staging may still feed an earlier pass's copies
+        int* h = s->h_stage;
+        for (int i = 0; i < rows; ++i) { h[i] = tokens[i]; h[rows + i] = pos0 + i; h[2 * rows + i] = crow; h[3 * rows + i] = crow; }
+        for (int g = 0; g < groups; ++g) h[4 * rows + g] = item;
+        const Slot::DecBufs& b = s->pf;
+        CK(hipMemcpyAsync(b.d_token, h, rows * 4, hipMemcpyHostToDevice, s->stream));
+        CK(hipMemcpyAsync(b.d_pos, h + rows, rows * 4, hipMemcpyHostToDevice, s->stream));
+        CK(hipMemcpyAsync(b.d_cache, h + 2 * rows, rows * 4, hipMemcpyHostToDevice, s->stream));
+        CK(hipMemcpyAsync(b.d_ancrow, h + 3 * rows, rows * 4, hipMemcpyHostToDevice, s->stream));
+        CK(hipMemcpyAsync(b.d_group_item, h + 4 * rows, groups * 4, hipMemcpyHostToDevice, s->stream));
+        s->anc_ident = false;                                       // every row reads its history through the prompt's cache row
+        decoder_pass(e, s, rows, 16, groups, false, false, &b);
+        CK(hipGetLastError());
+        if (nsp_index >= 0 && nsp_index < rows) {
+            const int d = e->spec.d_model;
+            GemvParams p{};
+            p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_F32; p.M = 1; p.K = d; p.KT = d / 32; p.N = e->spec.vocab;
+            p.Wp = e->Wvocab; p.bias = nullptr; p.X = b.xd + (size_t)nsp_index * d; p.ldx = d; p.gamma = e->dec_ln_g; p.beta = e->dec_ln_b;
+            p.Y = s->logits; p.ldy = s->ldl; p.qscale = 1.f; p.xsrc = GEMV_X_PLAIN;
+            launch_dec_gemv(p, s->stream);
+            launch_token_prob(s->logits, s->ldl, e->spec.vocab, 1, nsp_token, s->d_tokprob, s->stream);
+            CK(hipMemcpyAsync(nsp_out, s->d_tokprob, 4, hipMemcpyDeviceToDevice, s->stream));
+            CK(hipGetLastError());
+        }
+        return WLX_OK;
+    }
+    // chunk size: 48 rows = three 16-row MFMA tiles = the widest pass the LEAN projections take (64 would fall back to the
+    // first-generation general kernel at every projection of every chunk); WLX_PREFILL_ROWS=64 restores the old chunks (A/B)
+    static const int chunk = [] { const char* v = getenv("WLX_PREFILL_ROWS"); const int c = v ? atoi(v) : 48; return (c >= 16 && c <= 64) ? c : 48; }();
+    for (int c0 = 0; c0 < n; c0 += chunk) {
+        const int rows = std::min(chunk, n - c0);
         const int groups = (rows + 15) / 16;
         std::vector<int> tk(rows), ps(rows), ca(rows, crow), an(rows, crow), gi(groups, item);
         for (int i = 0; i < rows; ++i) { tk[i] = tokens[c0 + i]; ps[i] = pos0 + c0 + i; }
