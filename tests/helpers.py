@@ -135,8 +135,10 @@ def check_decode(oracle, enc, slot, ids, prompt, what, *, require_exact=True, no
         n += 1
     print(what, "common prefix", n, "of", len(r), "distinct tokens", len(set(r)), "gpu score", got.scores[0], "oracle", ref.scores[0])
     exact = g == r
+    # scores are sum(log p) / len^length_penalty: the 5e-3 bound is per token, so it scales with len^(1 - length_penalty)
+    tol = 5e-3 * max(1.0, float(max(len(r), 1)) ** (1.0 - float(kw.get("length_penalty", 1.0))))
     if exact:
-        assert abs(got.scores[0] - ref.scores[0]) <= 5e-3, (what, got.scores[0], ref.scores[0])
+        assert abs(got.scores[0] - ref.scores[0]) <= tol, (what, got.scores[0], ref.scores[0])
     else:
         diff = (what, "first difference at", n, g[max(0, n - 2): n + 3], r[max(0, n - 2): n + 3])
         assert not require_exact, diff
@@ -147,7 +149,8 @@ def check_decode(oracle, enc, slot, ids, prompt, what, *, require_exact=True, no
             v, lse, _ = odec.process_logits(lg[len(prompt) - 1 + i], list(g[:i]), opts, ids.no_timestamps not in prompt)
             assert np.isfinite(v[t]), (what, "GPU emitted a token the rules forbid", i, t)
             cum += float(v[t] - lse)
-        assert abs(got.scores[0] - cum / max(len(g), 1)) <= 5e-3, (what, got.scores[0], cum / max(len(g), 1))
+        denom = float(max(len(g), 1)) ** float(kw.get("length_penalty", 1.0))
+        assert abs(got.scores[0] - cum / denom) <= tol, (what, got.scores[0], cum / denom)
         assert len(g) == len(r) and cum >= ref.scores[0] * max(len(r), 1) - 5e-2, (what, n, cum, ref.scores[0] * len(r))
     assert abs(got.no_speech_prob - ref.no_speech_prob) <= 2e-3 + 0.02 * ref.no_speech_prob
     return n, len(r), exact

@@ -1222,24 +1222,38 @@ void launch_dec_gemv(const GemvParams& p_any, hipStream_t s) {
 // IDENT: the rows read their history through their OWN ancestry row (every decode step; prefill rows share one): the
 // ancestry row address then needs no table lookup, so the first block's cache-row lookup is requested at once, next to
 // the scalar loads of the row's position, instead of behind them — one dependent trip less (of three) per launch.
+// Round 3: SA_NW waves per (row, head). A wave walks every SA_NW-th block of 64 positions and the waves' (m, l, o) are merged
+// through LDS in a fixed order. With one wave the blocks of a long history were a serial chain of dependent round trips
+// (ancestry -> K / V -> softmax): a step at positions 225..288 (a window conditioned on the reference's full prompt) cost
+// 6.4 us per layer here against 2.9 us at t = 32. Histories of <= 64 positions run exactly as before on wave 0 — the other
+// waves leave at once, and ended waves do not count at the barrier.
+#ifndef SA_NW
+#define SA_NW 4          // -DSA_NW=1 (whisperlive_amd/_lib.py build_variant) = the one-wave form, for A/B
+#endif
 template <bool IDENT>
-__global__ __launch_bounds__(64) void dec_self_attn2_kernel(const half_t* __restrict__ q, long ldq,
-                                                            const half_t* __restrict__ Kc,
-                                                            const half_t* __restrict__ Vc, long crs, int d,
-                                                            const int* __restrict__ pos,
-                                                            const int* __restrict__ ancrow,
-                                                            const short* __restrict__ anc,
-                                                            half_t* __restrict__ out, long ldo WLX_TR_PARAM) {
-    __shared__ float prob[64];
-    __shared__ int crow[64];
-    __shared__ float part[8][64];
-    const int lane = threadIdx.x;
+__global__ __launch_bounds__(64 * SA_NW) void dec_self_attn2_kernel(const half_t* __restrict__ q, long ldq,
+                                                                    const half_t* __restrict__ Kc,
+                                                                    const half_t* __restrict__ Vc, long crs, int d,
+                                                                    const int* __restrict__ pos,
+                                                                    const int* __restrict__ ancrow,
+                                                                    const short* __restrict__ anc,
+                                                                    half_t* __restrict__ out, long ldo WLX_TR_PARAM) {
+    __shared__ float prob_s[SA_NW][64];
+    __shared__ int crow_s[SA_NW][64];
+    __shared__ float part_s[SA_NW][8][64];
+    __shared__ float ml_s[SA_NW][2];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = blockIdx.x, h = blockIdx.y;
     WLX_TR_BEGIN();
+    const int len = pos[r] + 1;
+    const int nblk = (len + 63) >> 6;
+    if (w >= nblk) return;                                  // (wave 0 always stays: len >= 1)
+    float* prob = prob_s[w];
+    int* crow = crow_s[w];
     const short* ar = anc + (long)(IDENT ? r : ancrow[r]) * WLX_T_TEXT;
     int cr0 = 0;
     if constexpr (IDENT) cr0 = ar[lane];                    // block 0's cache rows (lane < 448: always inside the row)
-    const int len = pos[r] + 1;
     f16x8 qv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) qv[i] = ld_f16x8(q + (long)r * ldq + h * WLX_HEAD_DIM + i * 8);
@@ -1250,7 +1264,7 @@ __global__ __launch_bounds__(64) void dec_self_attn2_kernel(const half_t* __rest
     float mrun = WLX_NEG_INF, lrun = 0.f;
     WLX_TR_MARK(1);
 #pragma unroll 1
-    for (int p0 = 0; p0 < len; p0 += 64) {
+    for (int p0 = w * 64; p0 < len; p0 += 64 * SA_NW) {
         const int p = p0 + lane;
         const bool ok = p < len;
         int cr;
@@ -1294,12 +1308,31 @@ __global__ __launch_bounds__(64) void dec_self_attn2_kernel(const half_t* __rest
     }
     WLX_TR_MARK(2);
     // sum the 8 position groups: part[pg][dim]; lane d then owns output dim d
-    *reinterpret_cast<float4*>(&part[pg][dc * 8]) = make_float4(o[0], o[1], o[2], o[3]);
-    *reinterpret_cast<float4*>(&part[pg][dc * 8 + 4]) = make_float4(o[4], o[5], o[6], o[7]);
+    *reinterpret_cast<float4*>(&part_s[w][pg][dc * 8]) = make_float4(o[0], o[1], o[2], o[3]);
+    *reinterpret_cast<float4*>(&part_s[w][pg][dc * 8 + 4]) = make_float4(o[4], o[5], o[6], o[7]);
     float acc = 0.f;
 #pragma unroll
-    for (int g8 = 0; g8 < 8; ++g8) acc += part[g8][lane];
-    out[(long)r * ldo + hoff + lane] = (half_t)(acc / lrun);
+    for (int g8 = 0; g8 < 8; ++g8) acc += part_s[w][g8][lane];
+    if (nblk == 1) {                                        // one block: wave 0 alone, as before
+        out[(long)r * ldo + hoff + lane] = (half_t)(acc / lrun);
+    } else {
+        // merge the waves' partial (m, l, o) in wave order: o = sum_w o_w e^(m_w - m), l = sum_w l_w e^(m_w - m)
+        part_s[w][0][lane] = acc;                           // (this wave's own row of part_s: read above by the same lanes' wave only)
+        if (lane == 0) { ml_s[w][0] = mrun; ml_s[w][1] = lrun; }
+        __syncthreads();                                    // the waves that left at the top do not count
+        if (w == 0) {
+            const int nw = nblk < SA_NW ? nblk : SA_NW;
+            float m = ml_s[0][0];
+            for (int k = 1; k < nw; ++k) m = fmaxf(m, ml_s[k][0]);
+            float L = 0.f, O = 0.f;
+            for (int k = 0; k < nw; ++k) {
+                const float f = __expf(ml_s[k][0] - m);
+                L += ml_s[k][1] * f;
+                O += part_s[k][0][lane] * f;
+            }
+            out[(long)r * ldo + hoff + lane] = (half_t)(O / L);
+        }
+    }
     WLX_TR_MARK(3);
     WLX_TR_END(trc);
 }
@@ -1309,10 +1342,10 @@ void launch_dec_self_attn(const half_t* q, long ldq, const half_t* Kc, const hal
     (void)done;   // a step that runs after the search raised `done` only rewrites scratch (engine.hip decoder_pass)
     static const bool no_ident = [] { const char* e = getenv("WLX_SELF_ATTN_IDENT"); return e && e[0] == '0'; }();   // (A/B)
     if (ident_ancestry && !no_ident)
-        hipLaunchKernelGGL(dec_self_attn2_kernel<true>, dim3(rows, H), dim3(64), 0, s, q, ldq, Kc, Vc, crs, d, rt.pos,
+        hipLaunchKernelGGL(dec_self_attn2_kernel<true>, dim3(rows, H), dim3(64 * SA_NW), 0, s, q, ldq, Kc, Vc, crs, d, rt.pos,
                            rt.ancrow, rt.anc, out, ldo WLX_TR_ARG("self_attn"));
     else
-        hipLaunchKernelGGL(dec_self_attn2_kernel<false>, dim3(rows, H), dim3(64), 0, s, q, ldq, Kc, Vc, crs, d, rt.pos,
+        hipLaunchKernelGGL(dec_self_attn2_kernel<false>, dim3(rows, H), dim3(64 * SA_NW), 0, s, q, ldq, Kc, Vc, crs, d, rt.pos,
                            rt.ancrow, rt.anc, out, ldo WLX_TR_ARG("self_attn"));
 }
 
