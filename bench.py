@@ -410,7 +410,7 @@ def config5(args, rank, world, local, dist, torch):
     MB = 8
     tr = make_bench_transcriber(eng, spec, ids, args.decode_steps, vad_model=None, max_batch=MB)
     BatchInferenceWorker.TEMPERATURES = (0.0,)
-    worker = BatchInferenceWorker(tr, max_batch_size=MB, batch_window_ms=50)
+    worker = BatchInferenceWorker(tr, max_batch_size=MB, batch_window_ms=50, lanes=max(1, args.lanes))
     worker.start()
     n = args.clips
     lo, hi = sh.shard_range(n, rank, world)
@@ -462,10 +462,10 @@ def config5(args, rank, world, local, dist, torch):
             "vs_baseline": None, "dtype": "f16 (MFMA operands; f32 accumulate, f32 residual stream, f32 log-mel)", "data": "synthetic",
             "config": {"workload": f"configs[4]: batch_inference.py batched mode, Whisper-{args.model} shapes, {n} clips x 30 s "
                                    f"(seeds 2000..{2000 + n - 1}), contiguous blocks over {world} GPU(s), per-GPU "
-                                   f"BatchInferenceWorker(max_batch_size={MB}) -> per-item log-mel + one batched encode + one batched "
+                                   f"BatchInferenceWorker(max_batch_size={MB}, lanes={max(1, args.lanes)}) -> per-item log-mel + one batched encode + one batched "
                                    f"beam-5 decode of {args.decode_steps} tokens per batch -> one all_gather of 2 KiB records; "
                                    f"seeded random weights",
-                       "clips": n, "clips_per_gpu": hi - lo, "max_batch_size": MB, "beam_size": 5, "decode_steps": args.decode_steps,
+                       "clips": n, "clips_per_gpu": hi - lo, "max_batch_size": MB, "worker_lanes": max(1, args.lanes), "beam_size": 5, "decode_steps": args.decode_steps,
                        "window_s": WINDOW_S},
             "tokens_per_clip": {"min": min(n_tok), "max": max(n_tok)},
             "p50_step_ms": 1000.0 * float(np.median(lat)),
@@ -526,6 +526,7 @@ def main():
                          "30 s clips, Whisper-large-v3 shapes, one BatchInferenceWorker(max_batch_size=8) per GPU, clips "
                          "sharded in contiguous blocks, ONE all_gather of 2 KiB result records over RCCL")
     ap.add_argument("--clips", type=int, default=64, help="--config 5: number of 30 s clips per step")
+    ap.add_argument("--lanes", type=int, default=4, help="--config 5: lanes of the BatchInferenceWorker (1 = the reference's single worker thread, 2 = the library default; measured 1086 / 1513 / 1618 / 1708 xRT at 1 / 2 / 3 / 4 lanes, profiles/r3k_*, r3d_*)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 FETCH_SIZE pass that fills roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--ws-client", default=None, help=argparse.SUPPRESS)

@@ -955,7 +955,9 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
         // the query rows (word alignment captures them), else projection and attention separately
         const half_t* ckl = s->ck + (size_t)l * s->B * WLX_T_AUDIO_PAD * d;
         const half_t* cvl = s->cvt + (size_t)l * s->B * d * WLX_T_AUDIO_PAD;
-        const bool fused = !s->align && dec_cq_cross_attn_eligible(d, H, R);
+        // (not for the one-pass prompt prefill: with 14+ groups every (split, head, group) workgroup re-reads its head's 96 KiB of
+        // query weights — 224 tokens: 1.49 ms fused, 1.32 ms as projection + attention, profiles/r3l_prefill_fused_cq.txt)
+        const bool fused = !s->align && rows <= 48 && dec_cq_cross_attn_eligible(d, H, R);
         if (fused)
             plaunch(s.base, "dec_cq_cross_attn_kernel", 2.0 * d * d + 4.0 * groups * WLX_T_AUDIO * d, [&] {
                 launch_dec_cq_cross_attn(s.xd, d, w.ln2_g, w.ln2_b, w.Wcq, w.bcq, 0.125f, d, ckl, cvl, (long)WLX_T_AUDIO_PAD * d, H, R,
