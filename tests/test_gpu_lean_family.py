@@ -157,3 +157,43 @@ def test_search_on_injected_logits_full_vocabulary(fam, seed, beam):
     got = slot.debug_search(lg, prompt, H.engine_ids(ids), **kw)
     assert got.sequences_ids == ref.sequences_ids, (got.sequences_ids, ref.sequences_ids)
     np.testing.assert_allclose(got.scores, ref.scores, rtol=1e-3, atol=1e-3)
+
+
+def test_twelve_items_batched_equal_singles(fam):
+    """60 beam rows in one decode — more than the 48 rows one launch of the lean kernels holds: every projection runs as two
+    row chunks (48 + 12) in grid.z (round 3; until then 49..64 rows fell back to the first-generation kernel) — == each clip
+    decoded alone; and 60 teacher-forced rows in one pass against the oracle."""
+    name, spec, eng, oracle, slot, enc = fam
+    ids = H.token_ids_for(spec.vocab)
+    kw = dict(beam_size=5, max_length=1 + 8, suppress_tokens=H.default_suppress(ids))
+    clips = [olm.speech_like_pcm(2.0 + 0.25 * i, seed=120 + i) for i in range(12)]
+    singles = []
+    for c in clips:
+        T = slot.logmel(c); slot.encode(1, seek=[0], seg=[T - 1])
+        singles.append(slot.generate([[ids.sot]], H.engine_ids(ids), **kw)[0])
+    sb = eng.create_slot(12, 5)
+    try:
+        Ts = [sb.logmel(c, item=i) for i, c in enumerate(clips)]
+        sb.encode(12, seek=[0] * 12, seg=[t - 1 for t in Ts])
+        res = sb.generate([[ids.sot]] * 12, H.engine_ids(ids), **kw)
+        for i in range(12):
+            assert res[i].sequences_ids == singles[i].sequences_ids, (name, i)
+            assert abs(res[i].scores[0] - singles[i].scores[0]) < 1e-3
+    finally:
+        sb.close()
+    # restore the fixture's encoder state (item 0 of the shared slot) and check 60 rows in ONE teacher-forced pass
+    pcm = olm.speech_like_pcm(5.0, seed=21)
+    T = slot.logmel(pcm); slot.encode(1, seek=[0], seg=[T - 1])
+    import os
+    old = os.environ.get("WLX_PREFILL_ROWS")
+    os.environ["WLX_PREFILL_ROWS"] = "64"                 # the debug hook's pass takes up to 64 rows per chunk: 60 rows = one pass
+    try:
+        toks = np.random.default_rng(60).integers(0, spec.vocab, size=60)
+        got = slot.debug_decode_logits(toks)
+    finally:
+        if old is None:
+            os.environ.pop("WLX_PREFILL_ROWS")
+        else:
+            os.environ["WLX_PREFILL_ROWS"] = old
+    ref = oracle.decode_logits(enc, toks[None])[0].numpy()
+    print(name, 60, _check(got, ref, f"{name} logits n=60"))

@@ -936,6 +936,7 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
     // layer 0's first projection under the same condition. WLX_NO_EMBED_FOLD=1 keeps the embedding launch (A/B).
     static const bool no_fold = [] { const char* v = getenv("WLX_NO_EMBED_FOLD"); return v && v[0] == '1'; }();
     int KS = dec_gemv_slab_split(rows, F, d);
+    if (rows > s.slab_rows) KS = 0;         // the partial-sum slabs of this working set hold slab_rows rows (steps: 48; 49..64 batched rows keep the single launch)
     if (KS && !(dec_gemv_is_lean(qkv_params(0, GEMV_X_SLABS)) && dec_gemv_is_lean(oproj_params(0, GEMV_X_SLABS)))) KS = 0;
     const bool fold_embed = !no_fold && rows <= 48 && dec_gemv_is_lean(qkv_params(0, GEMV_X_EMBED));
     if (!fold_embed)
@@ -1075,9 +1076,9 @@ static int prefill_tokens(Engine* e, Slot* s, int item, int crow, const int* tok
         }
         return WLX_OK;
     }
-    // chunk size: 48 rows = three 16-row MFMA tiles = the widest pass the LEAN projections take (64 would fall back to the
-    // first-generation general kernel at every projection of every chunk); WLX_PREFILL_ROWS=64 restores the old chunks (A/B)
-    static const int chunk = [] { const char* v = getenv("WLX_PREFILL_ROWS"); const int c = v ? atoi(v) : 48; return (c >= 16 && c <= 64) ? c : 48; }();
+    // chunk size: 48 rows = three 16-row MFMA tiles = one launch of the lean projections per chunk (a 64-row chunk runs them as
+    // two row chunks in grid.z); WLX_PREFILL_ROWS=16..64 (A/B, tests)
+    const int chunk = [] { const char* v = getenv("WLX_PREFILL_ROWS"); const int c = v ? atoi(v) : 48; return (c >= 16 && c <= 64) ? c : 48; }();   // (read per call: tests toggle it)
     for (int c0 = 0; c0 < n; c0 += chunk) {
         const int rows = std::min(chunk, n - c0);
         const int groups = (rows + 15) / 16;
