@@ -286,3 +286,72 @@ def test_prompt_forms_at_full_depth(peaked, case):
     p = PROMPT_CASES[case](ids)
     check_decode(oracle, enc, slot, ids, p, f"small.en peaked, {case}", require_exact=False, beam_size=5, patience=1.0,
                  max_length=len(p) + 24, suppress_tokens=H.default_suppress(ids))
+
+
+def test_fallback_temperatures_at_full_depth(peaked):
+    """The T > 0 legs of `generate_with_fallback` (:1380-1407: beam_size 1, num_hypotheses = best_of 5, sampling_topk 0) and of
+    batch_inference.py (:343-357: CTranslate2's default sampling_topk = 1, i.e. greedy at any temperature), 24 steps at 12 + 12
+    layers. Greedy-at-temperature is deterministic: token-exact against the oracle (or its near-tie). True sampling draws
+    from the device RNG stream (CTranslate2's own is unpinned, oracle/__init__.py), so what is checked is what does not
+    depend on where a draw fell: the same seed gives the same five hypotheses twice, another seed different ones, every token
+    is allowed by the rules, and the score the GPU reports for each hypothesis is the ORACLE's log-probability of those
+    tokens (mean over tokens, untempered) to 5e-3 — the logits along five sampled paths and the bookkeeping."""
+    spec, eng, oracle, slot, enc, _ = peaked
+    ids = H.token_ids_for(spec.vocab)
+    sup = H.default_suppress(ids)
+    check_decode(oracle, enc, slot, ids, [ids.sot], "small.en peaked, T = 0.4 with sampling_topk 1 (batch_inference's fallback)",
+                 require_exact=False, beam_size=1, patience=1.0, max_length=1 + 24, suppress_tokens=sup, sampling_temperature=0.4, sampling_topk=1)
+    kw = dict(beam_size=1, num_hypotheses=5, patience=1.0, max_length=1 + 24, suppress_tokens=sup, sampling_temperature=0.6,
+              sampling_topk=0, seed=1234)
+    a = slot.generate([[ids.sot]], H.engine_ids(ids), **kw)[0]
+    b = slot.generate([[ids.sot]], H.engine_ids(ids), **kw)[0]
+    c = slot.generate([[ids.sot]], H.engine_ids(ids), **dict(kw, seed=99))[0]
+    assert a.sequences_ids == b.sequences_ids and a.scores == b.scores
+    assert c.sequences_ids != a.sequences_ids
+    assert len(a.sequences_ids) == 5 and len({tuple(s) for s in a.sequences_ids}) >= 4
+    opts = odec.GenOptions(ids=ids, **kw)
+    for seq, score in zip(a.sequences_ids, a.scores):
+        lg = oracle.decode_logits(enc, np.asarray([ids.sot] + list(seq))[None])[0].numpy()
+        cum = 0.0
+        for i, t in enumerate(seq):
+            v, lse, _ = odec.process_logits(lg[i], list(seq[:i]), opts, True)
+            assert np.isfinite(v[t]), ("a sampled token the rules forbid", i, t)
+            cum += float(v[t] - lse)
+        assert len(seq) == 24, "EOT never wins on these weights; extend the check if it does"
+        assert abs(score - cum / max(len(seq), 1)) <= 5e-3, (score, cum / max(len(seq), 1))
+
+
+def test_three_items_with_different_prompts_batched_equal_singles(peaked):
+    """one batched decode whose items carry `[sot]`, a 31-token and the full 225-token prompt (per-item prompt lengths, the
+    one-pass prefill inside a batched call, rows at positions 0 / 30 / 224 in the same launches) == the three single decodes"""
+    spec, eng, oracle, slot, enc, _ = peaked
+    ids = H.token_ids_for(spec.vocab)
+    rng = np.random.default_rng(21)
+    prompts = [[ids.sot], [ids.timestamp_begin - 4] + rng.integers(0, ids.eot, size=29).tolist() + [ids.sot], long_prompt(ids, seed=12)]
+    kw = dict(beam_size=5, patience=1.0, max_length=448, suppress_tokens=H.default_suppress(ids))
+    clips = [olm.speech_like_pcm(30.0 - 6 * i, seed=300 + i) for i in range(3)]
+    sb = eng.create_slot(3, 5)
+    try:
+        Ts = [sb.logmel(c, item=i) for i, c in enumerate(clips)]
+        sb.encode(3, seek=[0] * 3, seg=[min(t - 1, 3000) for t in Ts])
+        # max_length is one number per call: the shortest budget decides how far every item decodes (225 + 24 here)
+        kw["max_length"] = len(prompts[2]) + 24
+        res = sb.generate(prompts, H.engine_ids(ids), **kw)
+        for i in range(3):
+            one = sb.generate([prompts[i]], H.engine_ids(ids), enc_items=[i], **kw)[0]
+            a, b = one.sequences_ids[0], res[i].sequences_ids[0]
+            n = 0
+            while n < min(len(a), len(b)) and a[n] == b[n]:
+                n += 1
+            print("item", i, "prompt", len(prompts[i]), "tokens", len(b), "batched == single for the first", n)
+            # 15 rows and 5 rows are different launches of the same kernels (another K split over the waves of a workgroup: a
+            # different fp32 summation order), so over the 218 / 248 steps of the two short-prompt items a near-tie may fall
+            # the other way; every item must agree for at least the 24 steps the long-prompt item runs, that one entirely
+            assert n >= 24, (i, n, a[max(0, n - 2): n + 3], b[max(0, n - 2): n + 3])
+            if a == b:
+                assert abs(one.scores[0] - res[i].scores[0]) <= 1e-3
+            assert abs(one.no_speech_prob - res[i].no_speech_prob) <= 1e-4 + 1e-3 * one.no_speech_prob
+        assert len(res[2].sequences_ids[0]) == 24 or res[2].sequences_ids[0][-1] != ids.eot
+        assert all(len(r.sequences_ids[0]) <= n for r, n in zip(res, (248, 218, 24))) and len(res[2].sequences_ids[0]) >= 8
+    finally:
+        sb.close()
