@@ -355,3 +355,47 @@ def test_three_items_with_different_prompts_batched_equal_singles(peaked):
         assert all(len(r.sequences_ids[0]) <= n for r, n in zip(res, (248, 218, 24))) and len(res[2].sequences_ids[0]) >= 8
     finally:
         sb.close()
+
+
+def test_batched_items_with_short_prompts_share_one_prefill_pass(peaked, monkeypatch):
+    """batch_inference's batches of multilingual requests: every item carries `[sot, lang, task]` (+ a prefix / previous text), a
+    few rows each. Their prompt rows run in ONE decoder pass (item b = row group b) instead of one pass per item; the result must
+    equal the per-item form (WLX_PREFILL_JOINT=0 is read at library load, so the reference here is each item decoded alone) —
+    tokens, scores, and no_speech_prob, which is read from the prefill logits at each item's <|startoftranscript|> row."""
+    spec, eng, oracle, slot, enc, _ = peaked
+    ids = H.token_ids_for(spec.vocab)
+    lang, task = ids.sot + 1, ids.timestamp_begin - 5
+    prompts = [[ids.sot, lang, task], [ids.sot, lang, task, 1100, 1200], [ids.sot],
+               [ids.timestamp_begin - 4, 71, 72, 73, 74, 75, ids.sot, lang + 3, task]]
+    clips = [olm.speech_like_pcm(30.0 - 5 * i, seed=400 + i) for i in range(4)]
+    sb = eng.create_slot(4, 5)
+    try:
+        Ts = [sb.logmel(c, item=i) for i, c in enumerate(clips)]
+        sb.encode(4, seek=[0] * 4, seg=[min(t - 1, 3000) for t in Ts])
+        kw = dict(beam_size=5, patience=1.0, max_length=max(len(p) for p in prompts) + 20, suppress_tokens=H.default_suppress(ids))
+        res = sb.generate(prompts, H.engine_ids(ids), **kw)
+        for i, p in enumerate(prompts):
+            one = sb.generate([p], H.engine_ids(ids), enc_items=[i], **kw)[0]
+            a, b = one.sequences_ids[0], res[i].sequences_ids[0]
+            n = 0
+            while n < min(len(a), len(b)) and a[n] == b[n]:
+                n += 1
+            print("item", i, "prompt", len(p), "batched == single for the first", n, "of", len(a), "no_speech", one.no_speech_prob, res[i].no_speech_prob)
+            assert n >= 16, (i, n, a[:n + 2], b[:n + 2])
+            if a == b:      # (another pass shape for the prompt rows: another fp32 association, a few fp16 roundings of cached K / V apart)
+                assert abs(one.scores[0] - res[i].scores[0]) <= 3e-3
+            assert abs(one.no_speech_prob - res[i].no_speech_prob) <= 1e-5 + 2e-2 * one.no_speech_prob
+        # and one of them against the oracle (its own encoder output)
+        feats = sb.features(1)
+        enc1 = oracle.encode(olm.pad_or_trim(feats[:, : Ts[1] - 1])[None])
+        ref = odec.generate(H.NetProvider(oracle, enc1), prompts[1], odec.GenOptions(ids=ids, **kw))
+        g, r = res[1].sequences_ids[0], ref.sequences_ids[0]
+        n = 0
+        while n < min(len(g), len(r)) and g[n] == r[n]:
+            n += 1
+        print("item 1 vs oracle: common prefix", n, "of", len(r), res[1].scores[0], ref.scores[0], res[1].no_speech_prob, ref.no_speech_prob)
+        assert n >= 12 and abs(res[1].no_speech_prob - ref.no_speech_prob) <= 2e-3 + 0.02 * ref.no_speech_prob
+        if g == r:
+            assert abs(res[1].scores[0] - ref.scores[0]) <= 5e-3
+    finally:
+        sb.close()

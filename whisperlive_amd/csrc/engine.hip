@@ -1294,14 +1294,62 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
     CK(hipMemcpyAsync(s->d_anc, h_anc, (size_t)rows * WLX_T_TEXT * sizeof(short), hipMemcpyHostToDevice, st));
     // ---- prefill prompt[0 .. plen-2]; no_speech_prob is read at the sot position
     if (!injected_logits) {
+        std::vector<int> sot_at(batch, -1);
+        int longest = 0, with_prompt = 0;
         for (int b = 0; b < batch; ++b) {
             const int32_t* pr = prompts + (size_t)b * pstride;
-            int sot_idx = -1;
-            for (int i = 0; i < pl[b]; ++i) if (pr[i] == o->ids.sot) sot_idx = i;
-            if (sot_idx == pl[b] - 1) { for (int r = 0; r < (sampling ? R : 1); ++r) nsp[b * R + r] = (r == 0) ? 1 : 0; }
-            if (pl[b] > 1)
-                CKR(prefill_tokens(e, s, enc_items ? enc_items[b] : b, b * R, pr, 0, pl[b] - 1, nullptr, (sot_idx >= 0 && sot_idx < pl[b] - 1) ? sot_idx : -1,
-                                   o->ids.no_speech, S.no_speech + b));
+            for (int i = 0; i < pl[b]; ++i) if (pr[i] == o->ids.sot) sot_at[b] = i;
+            if (sot_at[b] == pl[b] - 1) { for (int r = 0; r < (sampling ? R : 1); ++r) nsp[b * R + r] = (r == 0) ? 1 : 0; }
+            longest = std::max(longest, pl[b] - 1);
+            with_prompt += pl[b] > 1 ? 1 : 0;
+        }
+        // Batched calls with short prompts (the multilingual start sequence `[sot, lang, task]` (+ prefix) of every item of a
+        // batch_inference batch): ALL items' prompt rows in ONE decoder pass — item b is row group b (16 rows, the unused ones
+        // repeat the item's last prompt row: the same K / V written to the same cache position again) — instead of one full
+        // pass per item, each of which streams every decoder weight (large-v3: 1.3 ms per item, 8 items per batch).
+        static const bool joint = [] { const char* v = getenv("WLX_PREFILL_JOINT"); return !(v && v[0] == '0'); }();
+        if (joint && batch > 1 && with_prompt > 1 && longest <= 16 && s->pf_ok && !s->align && !s->prof && !g_decode_v1 && 16 * batch <= WLX_T_TEXT) {
+            const int prow = 16 * batch;
+            if ((size_t)(4 * prow + batch) > s->h_stage_ints - 8) return fail(WLX_ERR_ARG, "batch too large");
+            CK(hipStreamSynchronize(st));                        // the shared staging may still feed an earlier pass's copies
+            int* h = s->h_stage;
+            for (int b = 0; b < batch; ++b) {
+                const int32_t* pr = prompts + (size_t)b * pstride;
+                const int np_ = pl[b] - 1;                          // prompt rows of this item (0: a lone start token — the group idles on row 0's token at position 0... of a valid cache row)
+                for (int i = 0; i < 16; ++i) {
+                    const int j = np_ > 0 ? std::min(i, np_ - 1) : 0;
+                    h[b * 16 + i] = pr[j]; h[prow + b * 16 + i] = j; h[2 * prow + b * 16 + i] = b * R; h[3 * prow + b * 16 + i] = b * R;
+                }
+                h[4 * prow + b] = enc_items ? enc_items[b] : b;
+            }
+            const Slot::DecBufs& pb = s->pf;
+            CK(hipMemcpyAsync(pb.d_token, h, prow * 4, hipMemcpyHostToDevice, st));
+            CK(hipMemcpyAsync(pb.d_pos, h + prow, prow * 4, hipMemcpyHostToDevice, st));
+            CK(hipMemcpyAsync(pb.d_cache, h + 2 * prow, prow * 4, hipMemcpyHostToDevice, st));
+            CK(hipMemcpyAsync(pb.d_ancrow, h + 3 * prow, prow * 4, hipMemcpyHostToDevice, st));
+            CK(hipMemcpyAsync(pb.d_group_item, h + 4 * prow, batch * 4, hipMemcpyHostToDevice, st));
+            s->anc_ident = false;
+            decoder_pass(e, s, prow, 16, batch, false, false, &pb);
+            CK(hipGetLastError());
+            const int d = e->spec.d_model;
+            for (int b = 0; b < batch; ++b) {
+                if (!(sot_at[b] >= 0 && sot_at[b] < pl[b] - 1)) continue;
+                GemvParams p{};
+                p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_F32; p.M = 1; p.K = d; p.KT = d / 32; p.N = V;
+                p.Wp = e->Wvocab; p.bias = nullptr; p.X = pb.xd + (size_t)(b * 16 + sot_at[b]) * d; p.ldx = d; p.gamma = e->dec_ln_g; p.beta = e->dec_ln_b;
+                p.Y = s->logits; p.ldy = s->ldl; p.qscale = 1.f; p.xsrc = GEMV_X_PLAIN;
+                launch_dec_gemv(p, st);
+                launch_token_prob(s->logits, s->ldl, V, 1, o->ids.no_speech, s->d_tokprob, st);
+                CK(hipMemcpyAsync(S.no_speech + b, s->d_tokprob, 4, hipMemcpyDeviceToDevice, st));
+            }
+            CK(hipGetLastError());
+        } else {
+            for (int b = 0; b < batch; ++b) {
+                const int32_t* pr = prompts + (size_t)b * pstride;
+                if (pl[b] > 1)
+                    CKR(prefill_tokens(e, s, enc_items ? enc_items[b] : b, b * R, pr, 0, pl[b] - 1, nullptr, (sot_at[b] >= 0 && sot_at[b] < pl[b] - 1) ? sot_at[b] : -1,
+                                       o->ids.no_speech, S.no_speech + b));
+            }
         }
     }
     // ---- decode rows
