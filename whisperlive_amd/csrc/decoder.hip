@@ -1246,14 +1246,17 @@ __global__ __launch_bounds__(64 * SA_NW) void dec_self_attn2_kernel(const half_t
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = blockIdx.x, h = blockIdx.y;
     WLX_TR_BEGIN();
+    // the cache rows of this wave's FIRST block, requested together with the row's position, before anything depends on either
+    // (w * 64 + lane < 64 SA_NW <= 448: always inside the ancestry row, whatever the history length turns out to be) — without it
+    // the waves of the later blocks paid a second dependent round trip (position -> ancestry -> K / V)
+    const short* ar = anc + (long)(IDENT ? r : ancrow[r]) * WLX_T_TEXT;
+    int cr0 = 0;
+    if constexpr (IDENT) cr0 = ar[w * 64 + lane];
     const int len = pos[r] + 1;
     const int nblk = (len + 63) >> 6;
     if (w >= nblk) return;                                  // (wave 0 always stays: len >= 1)
     float* prob = prob_s[w];
     int* crow = crow_s[w];
-    const short* ar = anc + (long)(IDENT ? r : ancrow[r]) * WLX_T_TEXT;
-    int cr0 = 0;
-    if constexpr (IDENT) cr0 = ar[lane];                    // block 0's cache rows (lane < 448: always inside the row)
     f16x8 qv[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) qv[i] = ld_f16x8(q + (long)r * ldq + h * WLX_HEAD_DIM + i * 8);
@@ -1268,7 +1271,7 @@ __global__ __launch_bounds__(64 * SA_NW) void dec_self_attn2_kernel(const half_t
         const int p = p0 + lane;
         const bool ok = p < len;
         int cr;
-        if (IDENT && p0 == 0) cr = ok ? cr0 : __builtin_amdgcn_readlane(cr0, 0);      // (a masked lane: any valid row — position 0's)
+        if (IDENT && p0 == w * 64) cr = ok ? cr0 : __builtin_amdgcn_readlane(cr0, 0);  // (a masked lane: any valid row — the block's first position's)
         else cr = ar[ok ? p : len - 1];
         crow[lane] = cr;
         // K row of position p (lane = position); the LDS write above is visible to this same wave after the wait below
