@@ -463,7 +463,7 @@ def test_cli_maps_flags_onto_run(monkeypatch):
                   "--api_key", "k", "--metrics_port", "9100"])
     assert seen == dict(host="0.0.0.0", port=9191, backend="faster_whisper", faster_whisper_custom_model_path="/models/x",
                         single_model=True, max_clients=7, max_connection_time=99, batch_enabled=True, batch_max_size=6,
-                        batch_window_ms=12, raw_pcm_input=True, metrics_port=9100, api_key="k", devices=[0, 2, 3], vad_weights=None)
+                        batch_window_ms=12, batch_lanes=2, raw_pcm_input=True, metrics_port=9100, api_key="k", devices=[0, 2, 3], vad_weights=None)
     seen.clear()
     srv_mod.main(["--vad_weights", "/models/silero_vad.onnx"])
     assert seen["vad_weights"] == "/models/silero_vad.onnx"
