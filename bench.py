@@ -407,7 +407,7 @@ def config5(args, rank, world, local, dist, torch):
     spec = get_spec(args.model)
     eng = HipWhisperEngine(spec, random_weights(spec, seed=0), device=local)
     ids = token_ids(spec.vocab)
-    MB = 8
+    MB = max(1, min(12, args.max_batch))
     tr = make_bench_transcriber(eng, spec, ids, args.decode_steps, vad_model=None, max_batch=MB)
     BatchInferenceWorker.TEMPERATURES = (0.0,)
     worker = BatchInferenceWorker(tr, max_batch_size=MB, batch_window_ms=50, lanes=max(1, args.lanes))
@@ -526,6 +526,7 @@ def main():
                          "30 s clips, Whisper-large-v3 shapes, one BatchInferenceWorker(max_batch_size=8) per GPU, clips "
                          "sharded in contiguous blocks, ONE all_gather of 2 KiB result records over RCCL")
     ap.add_argument("--clips", type=int, default=64, help="--config 5: number of 30 s clips per step")
+    ap.add_argument("--max-batch", type=int, default=8, help="--config 5: max_batch_size of the BatchInferenceWorker (8 = the reference's default, batch_inference.py:100; up to 12 = 60 decoder rows)")
     ap.add_argument("--lanes", type=int, default=4, help="--config 5: lanes of the BatchInferenceWorker (1 = the reference's single worker thread, 2 = the library default; measured 1086 / 1513 / 1618 / 1708 xRT at 1 / 2 / 3 / 4 lanes, profiles/r3k_*, r3d_*)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 FETCH_SIZE pass that fills roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
