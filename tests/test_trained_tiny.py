@@ -12,7 +12,6 @@ i.e. word error rate 0 — the form the reference's only result-level test has (
 import json
 import os
 
-import numpy as np
 import pytest
 
 from tests import helpers as H
