@@ -109,10 +109,10 @@ def test_223_token_prompt_decode_to_max_length_448(peaked):
     n, total, exact = check_decode(oracle, enc, slot, ids, p, "small.en peaked 223-token prompt to max_length", require_exact=False,
                                     beam_size=5, patience=1.0, max_length=448, suppress_tokens=sorted(H.default_suppress(ids) + [ids.eot]))
     assert total == 448 - len(p)
-    # (not a pinned case: over 223 steps the oracle's own result flips under +-0.02 of logit noise, so a different rounding
-    # of the prompt prefill may legitimately pick the other branch of a near-tie — seen at step 24 with the 48-row prefill
-    # chunks, cumulative scores -0.76135 vs -0.76125; check_decode held the GPU's sequence to the near-tie standard above)
-    assert n >= 8, n
+    # (the oracle's own result flips under +-0.02 of logit noise somewhere in these 223 steps, so check_decode holds a diverging
+    # GPU sequence to the near-tie standard above; measured on MI355X in rounds 3 and 4: 223 / 223 tokens. A regression that
+    # diverges early must not hide behind the near-tie rule: at least 200 tokens of common prefix.)
+    assert exact or n >= 200, n
 
 
 def test_flat_weights_long_prompt_near_tie_standard(gpu):

@@ -475,7 +475,10 @@ def test_cli_maps_flags_onto_run(monkeypatch):
 def test_batch_inference_with_concurrent_clients_uses_slots_as_wide_as_the_batches(running_server, monkeypatch):
     """--batch_inference with several clients submitting inside one batch window: the shared
     transcriber the server creates must own slots as wide as the worker's batches, or every batch of >= 2 fails with
-    'batch N exceeds the slot's max_batch 1' and the sessions retry forever."""
+    'batch N exceeds the slot's max_batch 1' and the sessions retry forever.
+    Deterministic: the worker collects as the reference does (wait_when_idle=True: always wait out the
+    window, whisper_live/batch_inference.py:140-153) with a window far longer than the test and max_batch_size equal to the
+    number of clients, so the batch closes exactly when the third request arrives — no race between socket sends and lanes."""
     from tests.fakes import FakeEngine
     from whisperlive_amd.tokenizer import synthetic_tokenizer
     from whisperlive_amd.transcriber import WhisperModelHIP
@@ -489,25 +492,26 @@ def test_batch_inference_with_concurrent_clients_uses_slots_as_wide_as_the_batch
         return WhisperModelHIP("fake", engine=eng, hf_tokenizer=synthetic_tokenizer(eng.spec.vocab), max_batch=max_batch)
 
     monkeypatch.setattr(ServeClientHIP, "create_model", staticmethod(create_model))
-    srv = running_server(batch_enabled=True, batch_max_size=4, batch_window_ms=400, max_clients=4, model_factory=None)
+    srv = running_server(batch_enabled=True, batch_max_size=3, batch_window_ms=20000, max_clients=4, model_factory=None)
     conns = []
     for i in range(3):
         c = ws.connect(f"ws://127.0.0.1:{srv.port}")
         c.send(json.dumps(dict(OPTS, uid=f"b{i}")))
         assert _recv_json(c)["message"] == "SERVER_READY"
         conns.append(c)
-    assert made == [4]                                           # one shared transcriber, slots 4 items wide
+    assert made == [3]                                           # one shared transcriber, slots as wide as the batches
     worker = ServeClientHIP.BATCH_WORKERS[0]
-    assert worker.max_batch_size == 4
+    assert worker.max_batch_size == 3
+    worker.wait_when_idle = True                                 # (read after the first request of a batch is taken)
     pcm = (0.1 * np.sin(np.arange(2 * 16000) * 0.05)).astype(np.float32)
-    for c in conns:                                              # all three land inside one 400 ms batch window
+    for c in conns:
         c.send(pcm.tobytes())
     for i, c in enumerate(conns):
         msg = _recv_json(c)
         assert msg["uid"] == f"b{i}" and msg["segments"], msg
         c.close()
-    batched = [c for s in eng.slots for c in s.calls if c[0] == "encode" and c[1] >= 2]
-    assert batched, [c for s in eng.slots for c in s.calls if c[0] == "encode"]   # at least one true multi-item encode
+    encodes = [c[1] for s in eng.slots for c in s.calls if c[0] == "encode"]
+    assert encodes and encodes[0] == 3, encodes                  # the first encode of the run is the three clients' batch
     assert metrics.snapshot()["errors"].get("transcription", 0) == 0
 
 

@@ -412,40 +412,70 @@ def test_batch_worker_lanes_overlap_consecutive_batches():
 
 
 def test_batch_worker_starts_at_once_when_idle_and_batches_while_busy():
-    """The collection window only pays while the GPU is busy: an idle worker takes the first request immediately (plus
-    whatever is already queued); requests that arrive while a batch runs are collected over the window and batched."""
+    """The collection window only pays while the GPU is busy (the default, wait_when_idle=False): an idle worker takes a lone
+    request at once; requests that arrive while a lane is busy are collected over the window and batched. Deterministic: the
+    busy lane is HELD by an event, the window is far longer than the test and the batch closes on max_batch_size."""
     import threading
     import time
     from whisperlive_amd.batching import BatchInferenceWorker, BatchRequest
 
     sizes, lock = [], threading.Lock()
+    started = [threading.Event(), threading.Event()]
+    release = threading.Event()
 
     class W(BatchInferenceWorker):
         def _process_batch(self, batch):
             with lock:
                 sizes.append(len(batch))
-            time.sleep(0.12)
+                k = len(sizes) - 1
+            if k < len(started):
+                started[k].set()
+            assert release.wait(10)
             for r in batch:
                 r.result = []
                 r.future.set()
 
     mk = lambda: BatchRequest(audio=np.zeros(1600, np.float32), use_vad=False)
-    w = W(MagicMock(max_batch=4), max_batch_size=4, batch_window_ms=60, lanes=2)
+    w = W(MagicMock(max_batch=2), max_batch_size=2, batch_window_ms=20000, lanes=2)
     w.start()
     try:
         a = mk(); t0 = time.monotonic(); w.submit(a)
-        time.sleep(0.03)                                    # a runs alone, at once (no 60 ms wait)
-        b, c = mk(), mk(); w.submit(b); time.sleep(0.02); w.submit(c)      # busy: the second lane waits out its window -> {b, c}
-        assert a.future.wait(1) and b.future.wait(1) and c.future.wait(1)
-        assert time.monotonic() - t0 < 0.30
-        assert sizes == [1, 2], sizes
+        assert started[0].wait(5)                           # a runs alone, at once — not after the 20 s window
+        assert time.monotonic() - t0 < 2.0 and sizes == [1]
+        b, c = mk(), mk(); w.submit(b); w.submit(c)         # lane 0 is held busy: lane 1 collects over its window -> {b, c}
+        assert started[1].wait(5) and sizes == [1, 2], sizes
+        release.set()
+        assert a.future.wait(5) and b.future.wait(5) and c.future.wait(5)
     finally:
+        release.set()
         w.stop()
-    sizes.clear()
-    w = W(MagicMock(max_batch=4), max_batch_size=4, batch_window_ms=60, lanes=1, wait_when_idle=True)   # the reference's collection
+
+
+def test_batch_worker_reference_collection_waits_out_the_window_when_idle():
+    """wait_when_idle=True is the reference's collection (whisper_live/batch_inference.py:126-153): the first request of a batch
+    waits for the window (or for max_batch_size requests) even when nothing is running."""
+    import threading
+    import time
+    from whisperlive_amd.batching import BatchInferenceWorker, BatchRequest
+
+    sizes = []
+
+    class W(BatchInferenceWorker):
+        def _process_batch(self, batch):
+            sizes.append(len(batch))
+            for r in batch:
+                r.result = []
+                r.future.set()
+
+    mk = lambda: BatchRequest(audio=np.zeros(1600, np.float32), use_vad=False)
+    w = W(MagicMock(max_batch=3), max_batch_size=3, batch_window_ms=20000, lanes=1, wait_when_idle=True)
     w.start()
     try:
-        a, b = mk(), mk(); w.submit(a); time.sleep(0.02); w.submit(b)
-        assert a.future.wait(1) and b.future.wait(1) and sizes == [2]
+        reqs = [mk() for _ in range(3)]
+        w.submit(reqs[0])
+        time.sleep(0.05)
+        assert not reqs[0].future.is_set() and sizes == []  # still inside the window: nothing started
+        w.submit(reqs[1]); w.submit(reqs[2])                # the batch closes on max_batch_size
+        assert all(r.future.wait(5) for r in reqs) and sizes == [3], sizes
     finally:
         w.stop()

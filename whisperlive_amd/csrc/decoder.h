@@ -41,7 +41,9 @@ enum GemvXsrc : int { GEMV_X_PLAIN = 0, GEMV_X_SLABS = 1, GEMV_X_EMBED = 2 };
 struct GemvParams {
     int in_mode, out_mode;
     int M;                                   // live rows (of one row chunk: <= 48 on the lean kernel)
-    int Mtot;                                // (lean kernel, prompt prefill) 0, or the rows of the whole pass: grid.z chunks of 48 rows, see dec_gemv2_kernel
+    int Mtot;                                // (lean kernel) 0, or the rows of the whole pass, walked in row chunks, see dec_gemv2_kernel
+    int chunk;                               // (set by the launcher) rows per chunk: 48 (prompt prefill, grid.z) or 16 (batched decode steps)
+    int rt_nz, rt_tiles, rt_magic;           // (set by the launcher) 16-row chunks folded into blockIdx.x: chunks, live n-tile workgroups, 65536 / rt_nz + 1
     int K, KT, N;                            // K real, KT = Kpad/32, N real outputs
     int KTW;                                 // (set by the launcher) k-tiles per wave, even
     int NCH;                                 // (set by the launcher, lean kernel) chunks of CH k-tiles per wave

@@ -444,10 +444,27 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
     // Row chunks (prompt prefill, round 3): a pass over up to 448 rows runs every projection as ONE launch whose grid.z walks
     // chunks of 48 rows (three MFMA row tiles, the widest this kernel holds); a chunk is this kernel on rebased row pointers.
     // Decode steps launch with Mtot = 0 and skip the block (a scalar branch).
+    // Row tiles (batched decode steps, round 4): 17..64 rows run as row chunks of ONE 16-row MFMA tile each (the MT = 1
+    // instantiations — the ones tuned for a single stream), the chunk index folded into blockIdx.x so that the rt_nz
+    // workgroups that stream the same weight tile are (a) on one XCD (ids 8 apart: one L2 fetches the tile from HBM once)
+    // and (b) dispatched back to back: lin = ((tile / 8) * rt_nz + chunk) * 8 + tile % 8. The three-tile form (48 rows per
+    // workgroup) made every one of the N / 16 workgroups normalise / stage ALL rows on N / 16 CUs (60 rows, d_model 768:
+    // 7.1 us per residual projection at 0.04 of the HBM peak); row tiles spread the same work over 4x the CUs.
     GemvParams p = p_in;
+    int tile = blockIdx.x;
     if (p_in.Mtot > 0) {
-        const int r0 = (int)blockIdx.z * 48;
-        p.M = (p_in.Mtot - r0 < 48) ? p_in.Mtot - r0 : 48;
+        int zc = (int)blockIdx.z;
+        if (p_in.rt_nz > 0) {
+            const int lin = (int)blockIdx.x, t = lin >> 3;
+            const int tq = (int)(((unsigned)t * (unsigned)p_in.rt_magic) >> 16);      // t / rt_nz (host: magic = 65536 / nz + 1, exact for t < 32768)
+            zc = t - tq * p_in.rt_nz;
+            tile = tq * 8 + (lin & 7);
+            if (tile >= p_in.rt_tiles) return;                                        // (the tile count is padded to a multiple of 8)
+        }
+        const int CHK = p_in.chunk;
+        const int r0 = zc * CHK;
+        p.M = (p_in.Mtot - r0 < CHK) ? p_in.Mtot - r0 : CHK;
+        if (p.emb_token) p.emb_token += r0;
         if (p.X) p.X += (long)r0 * p.ldx;
         if (p.Xh) p.Xh += (long)r0 * p.ldxh;
         if (p.Yh) p.Yh += (long)r0 * p.ldyh;
@@ -474,7 +491,6 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
     // (Tried and dropped: sub-tile workgroups — a 16-column tile shared by 2-4 workgroups, each streaming a quarter of
     // the weight rows with the other lanes masked. It spreads N = 768 layers over 192 CUs but does not reduce the number
     // of load INSTRUCTIONS a CU issues, which is what bounds these launches (~11 ns per wave-level load): no gain.)
-    const int tile = blockIdx.x;
     const bool streams = (IN != GEMV_IN_XATTN) || wave < nw;               // this wave streams weights and runs MFMAs (helper waves: XATTN only)
     const int kx0 = (streams ? wave : 0) * p.KTW;                          // first k-tile of this wave inside its K slice
     const int ks0 = (OUT == GEMV_OUT_SLAB) ? (int)blockIdx.y * p.KTS : 0;  // first k-tile of this workgroup's K slice
@@ -629,7 +645,7 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
             if constexpr (XS == GEMV_X_EMBED) {
 #pragma unroll
                 for (int j = 0; j < LNV; ++j) { x[j].x += (float)te[j][0]; x[j].y += (float)te[j][1]; x[j].z += (float)te[j][2]; x[j].w += (float)te[j][3]; }
-                if (blockIdx.x == 0 && keep) {      // workgroup 0 leaves the rows where the residual updates expect them
+                if (tile == 0 && keep) {            // workgroup 0 (of its row chunk) leaves the rows where the residual updates expect them
                     float4* o4 = reinterpret_cast<float4*>(p.Xres + (long)r * p.ldxres) + lane;
 #pragma unroll
                     for (int j = 0; j < LNV; ++j) o4[64 * j] = x[j];
@@ -1036,7 +1052,9 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
         c.shm = sizeof(float) * (size_t)c.nw * c.NTB * c.MT * 256;
     }
     c.xstage = true;
-    if (p.in_mode == GEMV_IN_F16 && (c.MT > 1 || c.shm + xs_bytes > 64 * 1024)) c.xstage = false;   // fragments from global instead
+    // (row tiles of a batched step may stage past the default 64 KiB — large-v3's K-split MLP projection: 16 x 2560 fp16 = 82 KiB)
+    const size_t xstage_max = (p.Mtot > 0 && p.chunk == 16) ? (size_t)WLX_G2_LDS_MAX : (size_t)64 * 1024;
+    if (p.in_mode == GEMV_IN_F16 && (c.MT > 1 || c.shm + xs_bytes > xstage_max)) c.xstage = false;   // fragments from global instead
     if (c.xstage) c.shm += xs_bytes;
     if (c.shm > WLX_G2_LDS_MAX) return c;                              // beyond a CU's LDS (160 KiB, less a margin): older kernel
     if (c.shm > 64 * 1024 && g_lds_optin_refused.load(std::memory_order_relaxed)) return c;   // the device refused the raised limit once
@@ -1093,7 +1111,14 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
       snprintf(nm[q], 48, "gemv2<%d,%d,%d> N%d K%d", p.in_mode, p.out_mode, p.xsrc, p.N, p.K); p.trc = trace_next(nm[q]); }
 #endif
     const int NT_total = (p.N + 15) / 16;
-    dim3 grid((NT_total + c.NTB - 1) / c.NTB, p.out_mode == GEMV_OUT_SLAB ? p.KT / p.KTS : 1, p.Mtot > 0 ? (p.Mtot + 47) / 48 : 1), block(c.nw * 64);
+    if (p.Mtot > 0 && p.chunk <= 0) p.chunk = 48;
+    dim3 grid((NT_total + c.NTB - 1) / c.NTB, p.out_mode == GEMV_OUT_SLAB ? p.KT / p.KTS : 1, p.Mtot > 0 ? (p.Mtot + p.chunk - 1) / p.chunk : 1), block(c.nw * 64);
+    if (p.Mtot > 0 && p.rt_nz > 0) {       // row tiles folded into x (see dec_gemv2_kernel)
+        p.rt_tiles = (int)grid.x;
+        p.rt_magic = 65536 / p.rt_nz + 1;
+        grid.x = ((grid.x + 7) / 8) * 8 * p.rt_nz;
+        grid.z = 1;
+    }
     if (p.in_mode == GEMV_IN_XATTN) {      // helper waves for the combine: one thread per (row, head, 4-float group), <= 1024
         const int want = (p.M * p.H * 8 + 63) / 64;
         block.x = 64 * std::max(c.nw, std::min(c.MT > 1 ? 8 : 16, want));
@@ -1143,9 +1168,15 @@ static bool gemv2_ok(const GemvParams& p, Gemv2Cfg* out) {
     return true;
 }
 // more than 48 rows (prompt prefill): the lean kernel in row chunks of 48 (grid.z), configured for a full chunk
+// 17..WLX_ROWTILE_MAX rows (batched decode steps): row chunks of one 16-row tile folded into blockIdx.x (round 4, see
+// dec_gemv2_kernel). WLX_ROWTILE=0 restores the 48-row form (A/B).
 static GemvParams gemv_chunked(const GemvParams& p) {
+    static const bool rt_on = [] { const char* e = getenv("WLX_ROWTILE"); return !(e && e[0] == '0'); }();
+    static const int rt_max = [] { const char* e = getenv("WLX_ROWTILE_MAX"); const int v = e ? atoi(e) : 64; return v < 16 ? 16 : v; }();
     GemvParams q = p;
-    if (p.M > 48 && p.Mtot == 0 && p.in_mode != GEMV_IN_XATTN && p.xsrc != GEMV_X_EMBED) { q.Mtot = p.M; q.M = 48; }
+    if (p.Mtot != 0 || p.in_mode == GEMV_IN_XATTN) return q;
+    if (rt_on && !g_decode_v1 && p.M > 16 && p.M <= rt_max) { q.Mtot = p.M; q.M = 16; q.chunk = 16; q.rt_nz = (p.M + 15) / 16; }
+    else if (p.M > 48 && p.xsrc != GEMV_X_EMBED) { q.Mtot = p.M; q.M = 48; q.chunk = 48; }
     return q;
 }
 bool dec_gemv_is_lean(const GemvParams& p) { return gemv2_ok(gemv_chunked(p), nullptr); }
@@ -1153,14 +1184,14 @@ bool dec_gemv_is_lean(const GemvParams& p) { return gemv2_ok(gemv_chunked(p), nu
 int dec_gemv_slab_split(int M, int K, int N) {
     static const int ks_env = [] { const char* e = getenv("WLX_FC2_KS"); return e ? atoi(e) : WLX_FC2_KS; }();
     if (ks_env != WLX_FC2_KS || WLX_FC2_KS < 2) return 0;                     // (the slab count is a compile-time constant of the consumers)
-    if (M > 48) M = 48;                                                       // row chunks (prompt prefill): decided for a full chunk
     if (g_decode_v1 || M < 1 || K % 32 || (K / 32) % WLX_FC2_KS || K < 2048) return 0;
-    GemvParams p{};
-    p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_SLAB; p.M = M; p.K = K; p.KT = K / 32; p.N = N; p.KTS = p.KT / WLX_FC2_KS;
+    GemvParams p0{};
+    p0.in_mode = GEMV_IN_F16; p0.out_mode = GEMV_OUT_SLAB; p0.M = M; p0.K = K; p0.KT = K / 32; p0.N = N; p0.KTS = p0.KT / WLX_FC2_KS;
     static const float dummy_bias = 0.f;
-    p.bias = &dummy_bias;                                                     // (cfg only asks whether there is one)
+    p0.bias = &dummy_bias;                                                    // (cfg only asks whether there is one)
+    const GemvParams p = gemv_chunked(p0);                                    // row chunks: decided for a full chunk (16 or 48 rows)
     Gemv2Cfg c;
-    if (!gemv2_ok(p, &c) || (M <= 16 && !c.xstage)) return 0;
+    if (!gemv2_ok(p, &c) || (p.M <= 16 && !c.xstage)) return 0;
     return WLX_FC2_KS;
 }
 

@@ -577,7 +577,7 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         CKR(dalloc(s->allocs, &s->qd, (size_t)RC * d));
         CKR(dalloc(s->allocs, &s->attnd, (size_t)RC * d));
         CKR(dalloc(s->allocs, &s->hd, (size_t)RC * F));
-        CKR(dalloc(s->allocs, &s->slab, (size_t)WLX_FC2_KS * 48 * d));
+        CKR(dalloc(s->allocs, &s->slab, (size_t)WLX_FC2_KS * RC * d));
         CKR(dalloc(s->allocs, &s->part_o, (size_t)s->groups_cap * e->H * WLX_XSPLIT * 16 * 64));
         CKR(dalloc(s->allocs, &s->part_ml, (size_t)s->groups_cap * e->H * WLX_XSPLIT * 16 * 2));
         {   // the one-pass prompt prefill's working set: up to WLX_T_TEXT rows (engine.hip prefill_tokens)
@@ -889,7 +889,7 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
         int *d_token, *d_pos, *d_cache, *d_ancrow, *d_group_item;
         Slot* operator->() const { return base; }
     } s{s_, alt ? alt->xd : s_->xd, alt ? alt->qd : s_->qd, alt ? alt->attnd : s_->attnd, alt ? alt->hd : s_->hd,
-        alt ? alt->slab : s_->slab, alt ? (long)alt->slab_rows : 48L, alt ? alt->part_o : s_->part_o, alt ? alt->part_ml : s_->part_ml,
+        alt ? alt->slab : s_->slab, alt ? (long)alt->slab_rows : (long)s_->rows_cap, alt ? alt->part_o : s_->part_o, alt ? alt->part_ml : s_->part_ml,
         alt ? alt->d_token : s_->d_token, alt ? alt->d_pos : s_->d_pos, alt ? alt->d_cache : s_->d_cache,
         alt ? alt->d_ancrow : s_->d_ancrow, alt ? alt->d_group_item : s_->d_group_item};
     hipStream_t st = s->stream;
@@ -936,9 +936,9 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
     // layer 0's first projection under the same condition. WLX_NO_EMBED_FOLD=1 keeps the embedding launch (A/B).
     static const bool no_fold = [] { const char* v = getenv("WLX_NO_EMBED_FOLD"); return v && v[0] == '1'; }();
     int KS = dec_gemv_slab_split(rows, F, d);
-    if (rows > s.slab_rows) KS = 0;         // the partial-sum slabs of this working set hold slab_rows rows (steps: 48; 49..64 batched rows keep the single launch)
+    if (rows > s.slab_rows) KS = 0;         // the partial-sum slabs of this working set hold slab_rows rows
     if (KS && !(dec_gemv_is_lean(qkv_params(0, GEMV_X_SLABS)) && dec_gemv_is_lean(oproj_params(0, GEMV_X_SLABS)))) KS = 0;
-    const bool fold_embed = !no_fold && rows <= 48 && dec_gemv_is_lean(qkv_params(0, GEMV_X_EMBED));
+    const bool fold_embed = !no_fold && rows <= 64 && dec_gemv_is_lean(qkv_params(0, GEMV_X_EMBED));
     if (!fold_embed)
         plaunch(s.base, "dec_embed_kernel", (double)rows * d * (2 + 4), [&] { launch_dec_embed(e->tok_emb16, e->dec_pos, d, rt, rows, s.xd, done, st); });
     bool slabs_pending = false;             // the residual stream is xd + slabs until the next residual update writes the sum back
