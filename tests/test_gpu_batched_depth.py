@@ -9,7 +9,7 @@ raised dynamic-LDS limit at d_model 1280, per-item cross-attention groups of R =
 
 * the 40 logits rows of a captured batched step, after 5 beam reorders, against the oracle's teacher-forced logits of the
   SAME token histories (rel-rms <= 5e-3): a statement about the kernels that does not depend on how a near-tie was broken;
-* 8-item batched beam-5 == the 8 single decodes on the GPU (token-exact, scores 1e-3), and == the oracle for the
+* 8-item batched beam-5 == the 8 single decodes on the GPU (token-exact, scores 2e-3), and == the oracle for the
   well-conditioned items (token-exact; the GPU's reported score == the oracle's to 5e-3);
 * one clip, beam 5, 64 steps, token-exact against the oracle.
 
@@ -98,7 +98,10 @@ def test_eight_items_batched_beam5_equal_singles_and_oracle(lv3):
     for i in range(N_ITEMS):
         one = sb.generate([[ids.sot]], H.engine_ids(ids), enc_items=[i], **kw)[0]
         assert one.sequences_ids == res[i].sequences_ids, ("batched != single", i, _prefix(one.sequences_ids[0], res[i].sequences_ids[0]))
-        assert abs(one.scores[0] - res[i].scores[0]) <= 1e-3
+        # (scores: the 40-row step and the 5-row step reduce the MLP output projection differently since round 4 — one launch for
+        # batched rows, K-split partial sums for a single stream — so the summed log-probabilities differ by fp16-operand
+        # rounding: measured 1.05e-3 on the length-normalised score, against 5e-3 allowed versus the oracle)
+        assert abs(one.scores[0] - res[i].scores[0]) <= 2e-3
     opts = odec.GenOptions(ids=ids, **kw)
     exact = 0
     for i in (0, 3, 7):

@@ -1053,7 +1053,7 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     }
     c.xstage = true;
     // (row tiles of a batched step may stage past the default 64 KiB — large-v3's K-split MLP projection: 16 x 2560 fp16 = 82 KiB)
-    const size_t xstage_max = (p.Mtot > 0 && p.chunk == 16) ? (size_t)WLX_G2_LDS_MAX : (size_t)64 * 1024;
+    const size_t xstage_max = (p.Mtot > 0 && p.rt_nz > 0) ? (size_t)WLX_G2_LDS_MAX : (size_t)64 * 1024;
     if (p.in_mode == GEMV_IN_F16 && (c.MT > 1 || c.shm + xs_bytes > xstage_max)) c.xstage = false;   // fragments from global instead
     if (c.xstage) c.shm += xs_bytes;
     if (c.shm > WLX_G2_LDS_MAX) return c;                              // beyond a CU's LDS (160 KiB, less a margin): older kernel
@@ -1173,9 +1173,17 @@ static bool gemv2_ok(const GemvParams& p, Gemv2Cfg* out) {
 static GemvParams gemv_chunked(const GemvParams& p) {
     static const bool rt_on = [] { const char* e = getenv("WLX_ROWTILE"); return !(e && e[0] == '0'); }();
     static const int rt_max = [] { const char* e = getenv("WLX_ROWTILE_MAX"); const int v = e ? atoi(e) : 64; return v < 16 ? 16 : v; }();
+    // (experiments: WLX_ROWTILE_NMAX = widest N that is cut into row tiles, WLX_ROWTILE_CHUNK = rows per tile: 16 / 32 / 48)
+    static const int rt_nmax = [] { const char* e = getenv("WLX_ROWTILE_NMAX"); return e ? atoi(e) : (1 << 30); }();
+    static const int rt_chunk = [] { const char* e = getenv("WLX_ROWTILE_CHUNK"); const int v = e ? atoi(e) : 16; return (v == 32 || v == 48) ? v : 16; }();
     GemvParams q = p;
     if (p.Mtot != 0 || p.in_mode == GEMV_IN_XATTN) return q;
-    if (rt_on && !g_decode_v1 && p.M > 16 && p.M <= rt_max) { q.Mtot = p.M; q.M = 16; q.chunk = 16; q.rt_nz = (p.M + 15) / 16; }
+    // Which projections: measured per kernel at 20 / 40 / 60 rows (profiles/r4a-c_*): row tiles win wherever the launch has few
+    // column tiles (N = d_model: 7.1 -> 4.2 us at 60 rows, large-v3 6.7 -> 4.8 us at 40) and for Whisper-small's wide ones
+    // (first MLP projection 10.3 -> 6.9 us); large-v3's N = 3 d / 4 d projections (10-13 MB of weights re-read per row tile
+    // through L2) are faster as three-tile workgroups (8.7 vs 11.8 us, 9.1 vs 9.8 us).
+    const bool rt_shape = p.N <= 1536 || (long)p.N * p.K <= 3200000L;
+    if (rt_on && !g_decode_v1 && p.M > rt_chunk && p.M <= rt_max && p.N <= rt_nmax && (rt_shape || rt_nmax != (1 << 30))) { q.Mtot = p.M; q.M = rt_chunk; q.chunk = rt_chunk; q.rt_nz = (p.M + rt_chunk - 1) / rt_chunk; }
     else if (p.M > 48 && p.xsrc != GEMV_X_EMBED) { q.Mtot = p.M; q.M = 48; q.chunk = 48; }
     return q;
 }
@@ -1195,8 +1203,13 @@ int dec_gemv_slab_split(int M, int K, int N) {
     return WLX_FC2_KS;
 }
 
+static bool vocab2_ok(const GemvParams& p);   // (dec_vocab_kernel, below)
 const char* dec_gemv_kernel_name(const GemvParams& p_any) {
     static thread_local char buf[64];
+    if (vocab2_ok(p_any)) {
+        snprintf(buf, sizeof(buf), "dec_vocab_kernel<%d, %d, %d>", p_any.KT, p_any.KT == 24 ? 6 : p_any.KT == 40 ? 5 : 4, (p_any.M + 15) / 16);
+        return buf;
+    }
     const GemvParams p = gemv_chunked(p_any);
     const int MT = (p.M + 15) / 16;
     Gemv2Cfg c2;
@@ -1206,6 +1219,200 @@ const char* dec_gemv_kernel_name(const GemvParams& p_any) {
     }
     snprintf(buf, sizeof(buf), "dec_gemv_kernel<%d, %d, %d>", MT > 4 ? 4 : MT, MT == 1 ? 2 : 1, p.in_mode);
     return buf;
+}
+
+// ------------------------------------------------------------------ vocabulary projection: final LayerNorm + tied output projection
+// (round 4) The one bandwidth-sized launch of a decode step: V x d_model fp16 (80 MB Whisper-small, 133 MB large-v3) against <= 64
+// rows. As an instance of dec_gemv2_kernel it was 1621 workgroups that each normalised ALL rows before their 48 KiB of weights
+// could be used — 19 us at 5 rows (4.2 TB/s) but 51-80 us at 60 rows (the LayerNorm prologue, not HBM: 1621 x 60 rows x 3 KiB of
+// fp32 loads, ~11 ns per wave-level load per CU). Here a workgroup is 8 waves that share ONE LayerNorm of the rows (fp16 rows in
+// LDS) and then each wave owns a PAIR of 16-column tiles over the whole K: every weight fragment is loaded once (non-temporal,
+// straight into registers, two chunks of KC k-tiles x 2 tiles in flight = 24 KiB per wave) and multiplied against all MT row
+// tiles from LDS — no K split, no cross-wave reduction, fp32 logits leave as 16-byte pieces. 203 workgroups for V = 51864: one
+// round on 256 CUs. A row's result does not depend on how many rows share the launch (same code, same summation order).
+struct VocabParams {
+    const float* X; long ldx; const float* gamma; const float* beta;
+    const half_t* Wp; int M, N, NT;            // rows, real outputs, 16-column tiles of the packed weights
+    float* Y; long ldy;
+    WLX_TR_FIELD
+};
+template <int KT, int KC, int MT>
+__global__ __launch_bounds__(512) void dec_vocab_kernel(VocabParams p) {
+    constexpr int K = KT * 32, LNV = K / 256, NC = KT / KC, LDXS = K + 8;
+    static_assert(K % 256 == 0 && KT % KC == 0 && NC % 2 == 0, "d_model a multiple of 256; an even number of K chunks");
+    constexpr int RPT = (MT == 1) ? 2 : 4;                  // LayerNorm rows a wave requests per trip (8 waves: 16 / 32 rows per trip)
+    constexpr int NTRIP = (MT * 16 + 8 * RPT - 1) / (8 * RPT);
+    extern __shared__ __attribute__((aligned(16))) half_t vxs[];   // [M][LDXS] fp16 LayerNorm rows
+    const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    WLX_TR_BEGIN();
+    const int pair = blockIdx.x * 8 + wave;
+    const int t0 = (2 * pair < p.NT) ? 2 * pair : p.NT - 1, t1 = (2 * pair + 1 < p.NT) ? 2 * pair + 1 : p.NT - 1;
+    // ---- first trip's rows FIRST (vmcnt retires in order: the LayerNorm must not wait behind the weight stream)
+    float4 x[RPT][LNV];
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) {
+        const int r = (wave + 8 * i < p.M) ? wave + 8 * i : p.M - 1;
+        const float4* x4 = reinterpret_cast<const float4*>(p.X + (long)r * p.ldx) + lane;
+#pragma unroll
+        for (int j = 0; j < LNV; ++j) x[i][j] = x4[64 * j];
+    }
+    float4 gq[LNV], bq[LNV];
+    {
+        const float4* g4 = reinterpret_cast<const float4*>(p.gamma) + lane;
+        const float4* b4 = reinterpret_cast<const float4*>(p.beta) + lane;
+#pragma unroll
+        for (int j = 0; j < LNV; ++j) { gq[j] = g4[64 * j]; bq[j] = b4[64 * j]; }
+    }
+    asm volatile("" ::: "memory");                         // compile-time fence: the weight requests stay behind the row requests
+    const half_t* wq[2] = {p.Wp + (long)t0 * KT * 512 + lane * 8, p.Wp + (long)t1 * KT * 512 + lane * 8};
+    f16x8 wf[2][KC][2];                                     // [ring buffer][k-tile of the chunk][tile of the pair]
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < KC; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) wf[b][j][i] = ld_nt_f16x8(wq[i] + (b * KC + j) * 512);
+    constexpr float invK = 1.0f / (float)K;
+    auto ln_row = [&](float4 (&xr)[LNV], int r, bool keep) {
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < LNV; ++j) sm += (xr[j].x + xr[j].y) + (xr[j].z + xr[j].w);
+        const float mean = dpp_wave_sum(sm) * invK;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < LNV; ++j) {
+            xr[j].x -= mean; xr[j].y -= mean; xr[j].z -= mean; xr[j].w -= mean;
+            q += (xr[j].x * xr[j].x + xr[j].y * xr[j].y) + (xr[j].z * xr[j].z + xr[j].w * xr[j].w);
+        }
+        const float rstd = rsqrtf(dpp_wave_sum(q) * invK + 1e-5f);
+        half_t* dst = vxs + (long)r * LDXS + lane * 4;
+#pragma unroll
+        for (int j = 0; j < LNV; ++j) {
+            const f16x4 hv = {(half_t)(xr[j].x * rstd * gq[j].x + bq[j].x), (half_t)(xr[j].y * rstd * gq[j].y + bq[j].y),
+                              (half_t)(xr[j].z * rstd * gq[j].z + bq[j].z), (half_t)(xr[j].w * rstd * gq[j].w + bq[j].w)};
+            if (keep) *reinterpret_cast<f16x4*>(dst + 256 * j) = hv;
+        }
+    };
+    // first trip: straight-line and unconditional (a wave without a row normalises the clamped row it loaded and keeps nothing)
+#pragma unroll
+    for (int i = 0; i < RPT; ++i) ln_row(x[i], (wave + 8 * i < p.M) ? wave + 8 * i : p.M - 1, wave + 8 * i < p.M);
+#pragma unroll 1
+    for (int tr = 1; tr < NTRIP; ++tr) {                    // (49..64 rows, or 33..48: a second trip behind the weight stream)
+        const int rb = wave + 8 * RPT * tr;
+        if (rb >= p.M) break;
+        float4 y[RPT][LNV];
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) {
+            const int r = (rb + 8 * i < p.M) ? rb + 8 * i : p.M - 1;
+            const float4* x4 = reinterpret_cast<const float4*>(p.X + (long)r * p.ldx) + lane;
+#pragma unroll
+            for (int j = 0; j < LNV; ++j) y[i][j] = x4[64 * j];
+        }
+#pragma unroll
+        for (int i = 0; i < RPT; ++i) ln_row(y[i], (rb + 8 * i < p.M) ? rb + 8 * i : p.M - 1, rb + 8 * i < p.M);
+    }
+    WLX_TR_MARK(1);
+    __syncthreads();
+    // ---- the pair's columns over the whole K: chunk ch from ring buffer ch & 1, refilled with chunk ch + 2 behind its MFMAs
+    const half_t* xr[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) xr[mt] = vxs + (long)((mt * 16 + c < p.M) ? mt * 16 + c : p.M - 1) * LDXS + g * 8;   // rows >= M re-read a valid row (never stored)
+    f32x4 acc[2][MT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[i][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ch = 0; ch < NC; ++ch) {
+#pragma unroll
+        for (int j = 0; j < KC; ++j) {
+            f16x8 xf[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const f16x8*>(xr[mt] + (ch * KC + j) * 32);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[i][mt] = mfma16(wf[ch & 1][j][i], xf[mt], acc[i][mt]);
+        }
+        if (ch + 2 < NC) {
+#pragma unroll
+            for (int j = 0; j < KC; ++j)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) wf[ch & 1][j][i] = ld_nt_f16x8(wq[i] + ((ch + 2) * KC + j) * 512);
+        }
+    }
+    WLX_TR_MARK(2);
+    // ---- fp32 logits: lane (c, g) holds columns g*4 .. g*4+3 of row mt*16 + c
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int nt = 2 * pair + i;
+        if (nt >= p.NT) continue;
+        const int n = nt * 16 + g * 4;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int row = mt * 16 + c;
+            if (row >= p.M) continue;
+            float* yp = p.Y + (long)row * p.ldy + n;
+            const f32x4 v = acc[i][mt];
+            if (n + 3 < p.N) *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+            else { if (n < p.N) yp[0] = v[0]; if (n + 1 < p.N) yp[1] = v[1]; if (n + 2 < p.N) yp[2] = v[2]; }
+        }
+    }
+    WLX_TR_END(p.trc);
+}
+
+template <int KT, int KC, int MT>
+static void vocab_go(const VocabParams& p, hipStream_t s) {
+    const size_t shm = (size_t)p.M * (KT * 32 + 8) * sizeof(half_t);
+    if (shm > 64 * 1024) {          // > 64 KiB of dynamic LDS: opt in once per device (first launch of a shape happens outside capture)
+        static std::atomic<signed char> granted[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (dev >= 0 && dev < 64 && granted[dev].load(std::memory_order_acquire) == 0) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_vocab_kernel<KT, KC, MT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    WLX_G2_LDS_MAX) == hipSuccess) granted[dev].store(1, std::memory_order_release);
+            else (void)hipGetLastError();
+        }
+    }
+    const int pairs = (p.NT + 1) / 2;
+    hipLaunchKernelGGL((dec_vocab_kernel<KT, KC, MT>), dim3((pairs + 7) / 8), dim3(512), shm, s, p);
+}
+template <int KT, int KC>
+static void vocab_go_mt(const VocabParams& p, hipStream_t s) {
+    switch ((p.M + 15) / 16) {
+        case 1: vocab_go<KT, KC, 1>(p, s); break;
+        case 2: vocab_go<KT, KC, 2>(p, s); break;
+        case 3: vocab_go<KT, KC, 3>(p, s); break;
+        default: vocab_go<KT, KC, 4>(p, s); break;
+    }
+}
+// WLX_VOCAB2 = 0 off, 1 batched rows only (> 16), 2 every row count (default)
+static int vocab2_mode() {
+    static const int m = [] { const char* e = getenv("WLX_VOCAB2"); return e ? atoi(e) : 2; }();
+    return m;
+}
+static bool vocab2_ok(const GemvParams& p) {
+    if (g_decode_v1 || p.in_mode != GEMV_IN_LN || p.out_mode != GEMV_OUT_F32 || p.bias || p.xsrc != GEMV_X_PLAIN || p.Mtot != 0) return false;
+    const int mode = vocab2_mode();
+    if (mode == 0 || (mode == 1 && p.M <= 16)) return false;
+    if (p.M < 1 || p.M > 64 || p.K != p.KT * 32 || p.N < 256) return false;
+    if (!(p.KT == 16 || p.KT == 24 || p.KT == 32 || p.KT == 40)) return false;
+    return (size_t)p.M * (p.K + 8) * sizeof(half_t) <= WLX_G2_LDS_MAX;       // (large-v3: up to 59 rows)
+}
+static void vocab2_launch(const GemvParams& g, hipStream_t s) {
+    VocabParams p{};
+    p.X = g.X; p.ldx = g.ldx; p.gamma = g.gamma; p.beta = g.beta; p.Wp = g.Wp; p.M = g.M; p.N = g.N; p.NT = (g.N + 15) / 16;
+    p.Y = g.Y; p.ldy = g.ldy;
+#ifdef WLX_TRACE
+    p.trc = trace_next("vocab2");
+#endif
+    switch (g.KT) {
+        case 16: vocab_go_mt<16, 4>(p, s); break;
+        case 24: vocab_go_mt<24, 6>(p, s); break;
+        case 32: vocab_go_mt<32, 4>(p, s); break;
+        default: vocab_go_mt<40, 5>(p, s); break;
+    }
 }
 
 template <int MT, int NTB>
@@ -1218,6 +1425,7 @@ static void gemv_dispatch_in(const GemvParams& p, dim3 grid, dim3 block, size_t 
 }
 
 void launch_dec_gemv(const GemvParams& p_any, hipStream_t s) {
+    if (vocab2_ok(p_any)) { vocab2_launch(p_any, s); return; }
     Gemv2Cfg c2;
     const GemvParams pc = gemv_chunked(p_any);
     if (gemv2_ok(pc, &c2) && gemv2_launch(pc, c2, s)) return;

@@ -937,6 +937,12 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
     static const bool no_fold = [] { const char* v = getenv("WLX_NO_EMBED_FOLD"); return v && v[0] == '1'; }();
     int KS = dec_gemv_slab_split(rows, F, d);
     if (rows > s.slab_rows) KS = 0;         // the partial-sum slabs of this working set hold slab_rows rows
+    // batched decode steps (17..64 rows) keep the single MLP output launch (round 4, profiles/r4b_*): the split saves ~1 us
+    // there but every consumer of the slabs then reads three fp32 copies of every row in its LayerNorm prologue — per 16-column
+    // workgroup — and those launches are bound by load instructions per CU (60 rows, small.en: first projection 9.8 us with
+    // slabs, 7.0 us without; large-v3 at 40 rows: 11.4 -> 8.7 us). WLX_FC2_KS_BATCHED=1 keeps the split (A/B).
+    static const bool ks_batched = [] { const char* v = getenv("WLX_FC2_KS_BATCHED"); return v && v[0] == '1'; }();
+    if (rows > 16 && rows <= 64 && !alt && !ks_batched) KS = 0;
     if (KS && !(dec_gemv_is_lean(qkv_params(0, GEMV_X_SLABS)) && dec_gemv_is_lean(oproj_params(0, GEMV_X_SLABS)))) KS = 0;
     const bool fold_embed = !no_fold && rows <= 64 && dec_gemv_is_lean(qkv_params(0, GEMV_X_EMBED));
     if (!fold_embed)
