@@ -47,6 +47,18 @@ def suppress_list(ids, with_eot: bool):
     return base + ([ids["eot"]] if with_eot else [])
 
 
+def encoder_flops(spec) -> float:
+    """algorithmic FLOPs of one 30 s window through the encoder + the cross-attention K/V projection:
+    conv1 + conv2 as GEMMs, per layer 4 d^2 + 2 d F projections and 4 T^2 d of attention, cross K/V of every decoder layer"""
+    d, F, T = spec.d_model, spec.ffn, spec.n_audio_ctx
+    conv = 2.0 * 2 * T * d * 3 * spec.n_mels + 2.0 * T * d * 3 * d
+    layer = 2.0 * T * (4 * d * d + 2 * d * F) + 4.0 * T * T * d
+    return conv + spec.enc_layers * layer + 2.0 * T * d * 2 * d * spec.dec_layers
+
+
+MFMA_PEAK_TFLOPS = 2500.0      # dense fp16 / bf16 MFMA peak of an MI355X (MI355X_MICROARCH.md; AMD's 5 PF figure includes 2:1 sparsity)
+
+
 def decode_step_bytes(spec, beams: int, t: int) -> int:
     """fp16 weights + cross-attention K/V + self-attention KV read per decode step."""
     d, F, L, V, T = spec.d_model, spec.ffn, spec.dec_layers, spec.vocab, spec.n_audio_ctx
@@ -528,6 +540,7 @@ def main():
     ap.add_argument("--clips", type=int, default=64, help="--config 5: number of 30 s clips per step")
     ap.add_argument("--max-batch", type=int, default=8, help="--config 5: max_batch_size of the BatchInferenceWorker (8 = the reference's default, batch_inference.py:100; up to 12 = 60 decoder rows)")
     ap.add_argument("--lanes", type=int, default=4, help="--config 5: lanes of the BatchInferenceWorker (1 = the reference's single worker thread, 2 = the library default; measured 1086 / 1513 / 1618 / 1708 xRT at 1 / 2 / 3 / 4 lanes, profiles/r3k_*, r3d_*)")
+    ap.add_argument("--no-throughput", action="store_true", help="skip the 4-stream x 12-window throughput leg of the default run")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 FETCH_SIZE pass that fills roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--ws-client", default=None, help=argparse.SUPPRESS)
@@ -699,6 +712,52 @@ def main():
                             "kernels": prof},
             "roofline": roof,
         }
+        # the MFMA-regime roofline (SURVEY.md §8d asks for both regimes): encoder + cross-K/V of the timed run
+        ef = encoder_flops(spec) * B
+        out["roofline_encoder"] = dict(bound="mfma", flops=ef, ms=stage["encode_ms"], achieved=ef / (stage["encode_ms"] * 1e-3) / 1e12,
+                                       peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac_of_mfma_peak=ef / (stage["encode_ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                                       windows_per_launch=B)
+        if world == 1 and S == 1 and B == 1 and not args.no_throughput:
+            # the throughput configuration of ONE GPU, timed by the same driver run (VERDICT r03 task 5): 4 slots on their own
+            # hardware queues x 12 windows batched into every decode — what a --batch_inference server runs
+            note("throughput leg (4 streams x 12 windows per decode)")
+            try:
+                from concurrent.futures import ThreadPoolExecutor
+                TS, TB, tsteps = 4, 12, 3
+                tslots = [eng.create_slot(TB, 5) for _ in range(TS)]
+                for i, sl in enumerate(tslots):
+                    for b in range(TB):
+                        sl.pcm_put(olm.speech_like_pcm(WINDOW_S, seed=5000 + 100 * i + b), b)
+
+                def tstep(sl):
+                    Ts_ = [sl.logmel_resident(b) for b in range(TB)]
+                    sl.encode(TB, seek=[0] * TB, seg=[min(T - 1, 3000) for T in Ts_])
+                    return sl.generate([[ids["sot"]]] * TB, eids, **gen_kw)[0]
+                with ThreadPoolExecutor(max_workers=TS) as tp:
+                    list(tp.map(tstep, tslots))                       # warm-up (graph capture per slot)
+                    torch.cuda.synchronize()
+                    tt0 = time.perf_counter()
+                    for _ in range(tsteps):
+                        list(tp.map(tstep, tslots))
+                    torch.cuda.synchronize()
+                    twall = time.perf_counter() - tt0
+                tm12 = tslots[0].timings()
+                # one slot alone: the batched encoder's MFMA fraction without the other slots' work beside it
+                Ts_ = [tslots[0].logmel_resident(b) for b in range(TB)]
+                tslots[0].encode(TB, seek=[0] * TB, seg=[min(T - 1, 3000) for T in Ts_])
+                enc12 = tslots[0].timings()["encode_ms"]
+                step12 = tslots[0].debug_time_decode_step(rows=5 * TB, t=1 + args.decode_steps // 2, iters=20)
+                out["throughput"] = dict(xrt=TS * TB * tsteps * WINDOW_S / twall, streams=TS, batch_per_stream=TB, steps=tsteps,
+                                         ms_per_step=1e3 * twall / tsteps, windows_per_step=TS * TB,
+                                         stage_ms_slot0=tm12, encode_ms_one_slot=enc12,
+                                         encoder_frac_of_mfma_peak=encoder_flops(spec) * TB / (enc12 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                                         decode_step_60rows_ms=step12,
+                                         note="aggregate of 4 concurrent slots (own hardware queues) x 12 windows batched per decode, 64 tokens each; "
+                                              "engine-level (PCM resident in HBM), no server / VAD in this leg")
+                for sl in tslots:
+                    sl.close()
+            except Exception as e:  # noqa: BLE001 — the headline line must survive a failure of this leg
+                out["throughput"] = {"error": f"{type(e).__name__}: {e}"}
         if S == 1 and B == 1:
             # every window after the first of a stream is CONDITIONED on up to 223 previous tokens
             # (transcriber_faster_whisper.py:1480-1513): the same window with the reference's full prompt [sot_prev] + 223 + [sot]

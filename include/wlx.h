@@ -29,6 +29,16 @@
  * on a busy slot returns WLX_ERR_STATE instead of running, wlx_slot_destroy waits for the call in
  * flight, slot ids are never reused. No entry point uses the legacy (null) HIP stream, so slot
  * creation and destruction are safe while other slots are decoding.
+ * NULL-stream caveat for embedding applications: by default a slot's stream is created with
+ * hipExtStreamCreateWithCUMask (all CUs enabled) so that it owns a hardware queue (the first
+ * WLX_DEDICATED_QUEUES = 4 live slots of a device). That constructor takes no flags:
+ * the stream is a BLOCKING stream (hipStreamGetFlags == 0), i.e. it synchronises implicitly with
+ * the legacy NULL stream of the process. Work that the embedding process issues on the NULL stream
+ * of the same device (a framework's default stream, a synchronous hipMemcpy) therefore serialises
+ * with every slot, and if it is issued while a slot captures its decode-step graph that one
+ * wlx_generate call fails with WLX_ERR_HIP (the slot's stream is replaced, the next call works).
+ * Such processes should set WLX_SLOT_CU_MASK=off (ordinary non-blocking streams on the shared queue
+ * pool). The library states the mode once on stderr at the first slot creation (WLX_QUIET silences it).
  */
 #ifndef WLX_H
 #define WLX_H

@@ -559,3 +559,21 @@ def test_use_vad_without_silero_weights_is_refused_with_a_warning(running_server
     finally:
         vad.set_default_model(None)
     del seen
+
+
+def test_more_than_four_sessions_per_gpu_without_batching_is_warned_about(caplog):
+    """VERDICT r03 task 7: `--max_clients 8` on one GPU silently gave less throughput than 4 — the server now says so at start-up
+    (and stays quiet when the sessions are batched, spread over GPUs, or within four per GPU)."""
+    import logging as _logging
+    from whisperlive_amd.server import TranscriptionServer
+
+    def warned(**kw):
+        caplog.clear()
+        with caplog.at_level(_logging.WARNING):
+            TranscriptionServer().configure(backend="hip", model_factory=lambda *a, **k: None, **kw)
+        return any("--batch_inference" in r.getMessage() for r in caplog.records)
+    assert warned(max_clients=8)
+    assert warned(max_clients=9, devices=[0, 1])
+    assert not warned(max_clients=4)
+    assert not warned(max_clients=8, devices=[0, 1])
+    assert not warned(max_clients=8, batch_enabled=True)

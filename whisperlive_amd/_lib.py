@@ -83,7 +83,7 @@ def _hipcc() -> str:
     return hipcc
 
 
-def _compile(out: Path, defines=(), verbose: bool = False) -> Path:
+def _compile(out: Path, defines=(), verbose: bool = False, force: bool = False) -> Path:
     """hipcc --offload-arch=gfx950 of every source into `out`: one object per source (compiled in parallel, cached under
     csrc/.obj/<variant>/ and rebuilt when the source or any header is newer), linked into a temporary file and renamed
     (concurrent builders never see a half-written library). HIPCC_EXTRA is a hidden LLVM option: a hipcc that does not know
@@ -105,8 +105,8 @@ def _compile(out: Path, defines=(), verbose: bool = False) -> Path:
         def one(src):
             obj = odir / (src + ".o")
             sp = CSRC / src
-            if obj.exists() and obj.stat().st_mtime >= max(sp.stat().st_mtime, hdr_time):
-                return obj, None
+            if not force and obj.exists() and obj.stat().st_mtime >= max(sp.stat().st_mtime, hdr_time):
+                return obj, None           # (force=True: a new hipcc / ROCm or changed flags must not link stale objects)
             tmp = obj.with_name(obj.name + f".tmp{os.getpid()}")
             proc = subprocess.run(base + extra + ["-c", str(sp), "-o", str(tmp)], capture_output=True, text=True)
             if verbose and (proc.stdout or proc.stderr):
@@ -166,7 +166,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile every HIP source for gfx950 into whisperlive_amd/libwlx.so (hipcc cross-compiles without a GPU)."""
     if not force and _fresh(DEFAULT_LIB):
         return DEFAULT_LIB
-    return _compile(DEFAULT_LIB, (), verbose)
+    return _compile(DEFAULT_LIB, (), verbose, force=force)
 
 
 _lib = None

@@ -190,7 +190,8 @@ class BatchInferenceWorker:
                 if req.use_vad:
                     params = req.vad_parameters or {}
                     opts = _vad.VadOptions(**params) if isinstance(params, dict) else params
-                    chunks = _vad.get_speech_timestamps(audio, opts, model=tr._vad_model() if hasattr(tr, "_vad_model") else None)
+                    vm = getattr(type(tr), "_vad_model", None)        # class-level: a MagicMock transcriber has "every" attribute
+                    chunks = _vad.get_speech_timestamps(audio, opts, model=tr._vad_model() if vm is not None else None)
                     if chunks:
                         pieces, _ = _vad.collect_chunks(audio, chunks)
                         audio = np.concatenate(pieces, axis=0) if pieces else audio

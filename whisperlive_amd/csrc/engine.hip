@@ -376,6 +376,12 @@ extern "C" int32_t wlx_engine_create(const wlx_spec* spec, const wlx_tensor* wei
     return WLX_OK;
 }
 
+// live slots per device that may hold a hardware queue of their own (WLX_DEDICATED_QUEUES, default 4 = the reference server's
+// max_clients); the SAME number is the demotion threshold: one more live slot and every slot goes back to the shared pool
+static int max_dedicated_queues() {
+    static const int v = [] { const char* e = getenv("WLX_DEDICATED_QUEUES"); return e ? atoi(e) : 4; }();
+    return v;
+}
 static std::atomic<int> g_dedicated_live[64];      // live slots with a hardware queue of their own, per device (create_slot_stream)
 static std::atomic<int> g_slots_live[64];          // live slots per device
 static std::atomic<bool> g_demote[64];             // more live slots than dedicated queues allowed: dedicated slots fall back at their next call
@@ -383,7 +389,7 @@ static void slot_free(Slot* s) {
     if (!s) return;
     if (s->device_of >= 0 && s->device_of < 64) {
         if (s->dedicated_queue) g_dedicated_live[s->device_of].fetch_sub(1);
-        if (s->counted && g_slots_live[s->device_of].fetch_sub(1) - 1 <= 4) g_demote[s->device_of].store(false);
+        if (s->counted && g_slots_live[s->device_of].fetch_sub(1) - 1 <= max_dedicated_queues()) g_demote[s->device_of].store(false);
     }
     if (s->align_scores) (void)hipFree(s->align_scores);
     for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
@@ -422,6 +428,7 @@ struct SlotGuard {
     Slot* s = nullptr;
     ~SlotGuard() { if (s) s->call_mu.unlock(); }
 };
+static int create_slot_stream(int device, hipStream_t* out, bool* dedicated_out);
 static int slot_acquire(wlx_engine* e, int slot, SlotGuard& g) {
     if (!e) return fail(WLX_ERR_ARG, "null engine");
     std::lock_guard<std::mutex> lk(e->mu);
@@ -441,6 +448,20 @@ static int slot_acquire(wlx_engine* e, int slot, SlotGuard& g) {
             s->stream = ns;
             s->dedicated_queue = false;
             g_dedicated_live[s->device_of].fetch_sub(1);
+        } else {
+            (void)hipGetLastError();
+        }
+    } else if (!s->dedicated_queue && s->counted && s->device_of >= 0 && s->device_of < 64 && !g_demote[s->device_of].load() &&
+               g_dedicated_live[s->device_of].load() < max_dedicated_queues()) {
+        // ... and back: the device is down to <= WLX_DEDICATED_QUEUES live slots again (the fifth client left, a batch
+        // lane was released) — a slot that was demoted, or created while the device was crowded, takes a queue of its own at its
+        // next call instead of staying on the shared pool for the rest of the process
+        hipStream_t ns = nullptr;
+        bool ded = false;
+        if (hipSetDevice(s->device_of) == hipSuccess && hipStreamSynchronize(s->stream) == hipSuccess &&
+            create_slot_stream(s->device_of, &ns, &ded) == WLX_OK) {
+            if (ded) { (void)hipStreamDestroy(s->stream); s->stream = ns; s->dedicated_queue = true; }
+            else (void)hipStreamDestroy(ns);
         } else {
             (void)hipGetLastError();
         }
@@ -484,9 +505,15 @@ static int slot_grow_audio(Engine* e, Slot* s, size_t n_samples) {
 // some number of busy hardware queues the command processor time-slices them (profiles/r3c_bench_s8_default.json).
 static int create_slot_stream(int device, hipStream_t* out, bool* dedicated_out) {
     static const char* cu_mode = getenv("WLX_SLOT_CU_MASK");
-    static const int max_dedicated = [] { const char* v = getenv("WLX_DEDICATED_QUEUES"); return v ? atoi(v) : 4; }();
+    const int max_dedicated = max_dedicated_queues();
     static std::atomic<int> slot_seq{0};
     std::string m = cu_mode ? cu_mode : "full";
+    {   // once per process: which kind of stream the slots get (the default synchronises implicitly with the NULL stream)
+        static std::atomic<bool> said{false};
+        if (!said.exchange(true) && getenv("WLX_QUIET") == nullptr)
+            fprintf(stderr, "[wlx] slot streams: WLX_SLOT_CU_MASK=%s, up to %d hardware queues per device%s\n", m.c_str(), max_dedicated,
+                    m == "off" ? "" : " (CU-mask streams are blocking streams: keep NULL-stream work of this process off the device, or set WLX_SLOT_CU_MASK=off)");
+    }
     *dedicated_out = false;
     if (m != "off") {
         if (device < 0 || device >= 64 || g_dedicated_live[device].fetch_add(1) >= max_dedicated) {
@@ -542,7 +569,7 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         s->device_of = e->device;
         if (e->device >= 0 && e->device < 64) {
             s->counted = true;
-            if (g_slots_live[e->device].fetch_add(1) + 1 > 4) g_demote[e->device].store(true);
+            if (g_slots_live[e->device].fetch_add(1) + 1 > max_dedicated_queues()) g_demote[e->device].store(true);
         }
         if (s->counted && g_demote[e->device].load()) {
             CK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));        // past 4 live slots: the shared pool

@@ -27,8 +27,8 @@ namespace wlx {
 
 // ---------------- epilogue shared by both GEMM forms: lane owns columns n..n+3 of row m (WNT x WMT accumulator tiles of
 // the wave whose first n-tile is nt0 and first row m0)
-template <int WNT, int WMT>
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[WNT][WMT], int nt0, int m0, int z, int c, int g) {
+template <int WNT, int WMT, int MODE>
+__device__ __forceinline__ void gemm_epilogue_m(const GemmParams& p, f32x4 (&acc)[WNT][WMT], int nt0, int m0, int z, int c, int g) {
 #pragma unroll
     for (int ni = 0; ni < WNT; ++ni) {
         const int n = (nt0 + ni) * 16 + g * 4;
@@ -45,10 +45,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = acc[ni][mi][r] + b4[r];
-            switch (p.mode) {
+            switch (MODE) {           // (compile-time: the caller dispatches on p.mode once, not once per accumulator tile)
                 case GEMM_STORE_F16:
                 case GEMM_GELU_F16: {
-                    if (p.mode == GEMM_GELU_F16) {
+                    if (MODE == GEMM_GELU_F16) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
                     }
@@ -113,6 +113,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
         }
     }
 }
+template <int WNT, int WMT>
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[WNT][WMT], int nt0, int m0, int z, int c, int g) {
+    switch (p.mode) {
+        case GEMM_STORE_F16: gemm_epilogue_m<WNT, WMT, GEMM_STORE_F16>(p, acc, nt0, m0, z, c, g); break;
+        case GEMM_GELU_F16: gemm_epilogue_m<WNT, WMT, GEMM_GELU_F16>(p, acc, nt0, m0, z, c, g); break;
+        case GEMM_GELU_POS_F32: gemm_epilogue_m<WNT, WMT, GEMM_GELU_POS_F32>(p, acc, nt0, m0, z, c, g); break;
+        case GEMM_RESID_F32: gemm_epilogue_m<WNT, WMT, GEMM_RESID_F32>(p, acc, nt0, m0, z, c, g); break;
+        case GEMM_QKV: gemm_epilogue_m<WNT, WMT, GEMM_QKV>(p, acc, nt0, m0, z, c, g); break;
+        case GEMM_CROSS_KV: gemm_epilogue_m<WNT, WMT, GEMM_CROSS_KV>(p, acc, nt0, m0, z, c, g); break;
+        default: break;
+    }
+}
 
 // ---------------- LDS-transposed epilogue of the second form (round 2; the phase-removal probe of round 1,
 // profiles/r03m, priced the direct epilogue above at 35 % of the MLP-up launch and 27 % of the QKV launch: a wave-level
@@ -121,10 +133,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, f32x4 (&acc)[
 // destination wants: row-major destinations (C, q, K rows, tile-packed cross-K) as 16-byte pieces, a wave covering 8 full
 // 128-byte rows; column-major ones (V^T, tile-packed cross-V) as 8-byte pieces of 4 consecutive rows.
 // Values are bit-identical to gemm_epilogue's. The fp32 modes keep the direct form (a lane already owns 16 bytes).
-template <int WNT, int WMT>
+// (NWN x NWM = waves of the workgroup along n / m: 2 x 2 for the second form, 4 x 2 for the third)
+template <int WNT, int WMT, int NWN = 2, int NWM = 2>
 __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&acc)[WNT][WMT], half_t* T, int ntb, int mb, int wn, int wm,
                                                   int z, int c, int g, int tid) {
-    constexpr int TN = 32 * WNT, TM = 32 * WMT, PT = TN + 8;         // tile columns / rows, LDS pitch in halfs (16-byte aligned rows)
+    constexpr int TN = 16 * NWN * WNT, TM = 16 * NWM * WMT, PT = TN + 8, NTHR = 64 * NWN * NWM;   // tile columns / rows, LDS pitch in halfs (16-byte aligned rows)
     const int n_wg = ntb * 16;                                        // first column of the workgroup (multiple of 32 WNT)
     // what the workgroup's columns are (uniform: d_model is a multiple of the tile width)
     int part = 0;                                                     // QKV: 0 q, 1 k, 2 v;  CROSS_KV: 0 k, 1 v
@@ -152,7 +165,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
         // 16-byte pieces: (row, 8-column segment). Row-major destinations: segment fastest (a wave = 8 full rows);
         // tile-packed cross-K: row fastest (16 consecutive keys of a segment are 256 contiguous bytes of the image)
         constexpr int SEG = TN / 8, UNITS = TM * SEG;
-        for (int u = tid; u < UNITS; u += 256) {
+        for (int u = tid; u < UNITS; u += NTHR) {
             int row, seg;
             if (p.mode == GEMM_CROSS_KV) { seg = u / TM; row = u - seg * TM; } else { row = u / SEG; seg = u - row * SEG; }
             const int m = mb + row, n = n_wg + seg * 8;
@@ -178,7 +191,7 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
     } else {
         // 8-byte pieces: (column, 4 consecutive rows); rows_per_item is a multiple of 4, so a piece never straddles two items
         constexpr int MG = TM / 4, UNITS = TN * MG;
-        for (int u = tid; u < UNITS; u += 256) {
+        for (int u = tid; u < UNITS; u += NTHR) {
             int col, mg;
             if (p.mode == GEMM_CROSS_KV) { mg = u / TN; col = u - mg * TN; } else { col = u / MG; mg = u - col * MG; }
             const int m0 = mb + mg * 4, n = n_wg + col;
@@ -455,6 +468,239 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
         gemm_epilogue<WNT, WMT>(p, acc, nt0, m0, z, c, g);
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Third form (round 4): the LARGE-M GEMM. The second form's 64 x 96 tile was tuned for M = 1500 (one window: ~1.1
+// workgroup rounds, latency-bound); a batched encoder (M = 1500 B, B = 4..12) is throughput-bound and ran the same tile at
+// 15 % of the MFMA peak. Here: 256 (m) x 256 (n) x 64 (k) workgroup tiles, 8 waves as 2 (m) x 4 (n), 128 x 64 outputs per wave
+// (128 accumulator registers), and the K loop as FOUR PHASES per 64-deep K tile (the guide's 8-phase schedule = two K tiles
+// per trip): each phase reads one register subtile from LDS, requests one 16 KiB half-tile of a LATER K tile by LDS-DMA,
+// and runs the 16 MFMAs of one quadrant of the wave's outputs. The two wave groups (waves 0-3 / 4-7: one of each per SIMD) run
+// half a phase apart (one extra s_barrier), so on every SIMD one wave is in its MFMA burst while its partner issues LDS reads and
+// DMA requests. LDS = 2 K-tile buffers x {X0, W0, W1, X1} half-tiles of 16 KiB = 128 KiB:
+//   X half h = for each wave row wm the 64 activation rows wm*128 + h*64 .. +63   (read by the phase that starts quadrant row h)
+//   W half h = for each wave column wn the 32 weight rows wn*64 + h*32 .. +31
+// Phase order per K tile (q = (quadrant row, quadrant column)): P0 reads X0 + W0 -> q(0,0); P1 reads W1 -> q(0,1); P2 reads X1 ->
+// q(1,1); P3 -> q(1,0) from registers. So every half-tile is read in exactly ONE phase and its slot is re-staged two phases later:
+//   P0 requests W1(t+1), P1 X1(t+1), P2 X0(t+2), P3 W0(t+2); the only wait is `vmcnt(4)` in P3 (this wave's two newest
+//   half-tiles stay in flight): everything of K tile t+1 has landed before the barrier that precedes its first read.
+// RAW: wait in phase p (both groups, before a barrier), read in phase p+1. WAR: re-stage >= 2 phases after the last read (the
+// staggered group's reads are complete — lgkmcnt(0) — one barrier before the re-staging request is issued).
+// Weights stay in their packed fragment order (1 KiB per DMA piece, lane-linear, conflict-free ds_read_b128). Activations are
+// fetched as FULL 128-byte row segments (a DMA piece = 8 rows x 128 B; the second form's fragment-shaped pieces, 16 rows x 64 B,
+// cost the texture path twice the cycles and this tile runs it at ~50 % of its rate) into a swizzled image: LDS row
+// p = (r % 8) * 2 + r / 8 of a 16-row tile holds global row r, 16-byte slot s holds segment s ^ (r & 7) — the permutation is
+// applied to the per-lane SOURCE address (the LDS side of an LDS-DMA is lane-linear) and again on the read; ds_read_b128's four
+// 16-lane groups ({0-3,12-15,20-27}, ...) then touch 16 distinct slots of the 256-byte bank row.
+// K tiles past the end are requested again from the last K tile (clamped): the slots they land in are never read, the request
+// count per phase — and with it every vmcnt — stays uniform; the cost is two K tiles of L2 hits per workgroup.
+#define G3_XH 16384
+// PERSISTENT form (round 4, second step): one workgroup per CU walks its share of the tile list. With one workgroup per CU (128 KiB of
+// LDS, 256 registers) nothing overlapped a tile's prologue (first K tile: an HBM round trip) and epilogue with another tile's K loop:
+// per-launch traces at 12 windows showed ~40 us per tile for the K = 768 GEMMs whose 12 K tiles need ~17 us. Now the NEXT tile's
+// prologue requests are issued before the epilogue of the finished one wherever the epilogue does not need the ring: fp32 modes store
+// from registers; the fp16 row-major modes (MLP up-projection) go through a WAVE-PRIVATE 4.5 KiB staging area in the dead W1 / X1 slots
+// of buffer 1 (32 rows x 64 columns at a time -> 16-byte pieces, a wave store = 8 full 128-byte rows; no workgroup barrier); the
+// scattering modes (QKV, cross K/V) keep the workgroup-wide LDS-transposed epilogue and request their next tile after it.
+// The epilogue's stores share the vmcnt queue with the LDS-DMA requests, so a tile starts with vmcnt(0) instead of a counted wait.
+__global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char g3lds[];           // [2][X0 | W0 | W1 | X1] x 16 KiB (+ 4 KiB) — the ONLY LDS object
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int c = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    // ---- tile list: n fastest; each XCD (workgroup id % 8) owns a contiguous run of it (its L2 holds that run's activation panels and —
+    // N / 256 <= 12 panels for the layer GEMMs — all the weight panels); the XCD's workgroups walk the run together
+    const int gx = p.g3_gx, ntiles = p.g3_tiles;
+    const int xcd = (int)blockIdx.x & 7, nper = (int)gridDim.x >> 3;
+    const int q8 = ntiles >> 3, r8 = ntiles & 7;
+    const int run0 = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8, runlen = q8 + (xcd < r8 ? 1 : 0);
+    int kpos = (int)blockIdx.x >> 3;                                        // position in the XCD's run
+    if (kpos >= runlen) return;
+    const int KT = p.KT, NK = KT >> 1;
+    const half_t* xsrc[2][2];
+    const half_t* wsrc[2][2];
+    int n_blk = 0, m_blk = 0;
+    // ---- LDS-DMA sources of a tile. A half-tile = 16 pieces of 1 KiB; wave w requests pieces w and w + 8.
+    //   X half h, piece j: 16-row tile mi = j >> 1 of the half (wave row mi >> 2, tile mi & 3), LDS rows (j & 1) * 8 .. + 7
+    //   W half h, piece j: wave column j >> 2, n-tile (j >> 1) & 1 of its half, k-tile j & 1 of the K tile
+    auto set_tile = [&](int lin) {
+        const int by = lin / gx, bx = lin - by * gx;
+        n_blk = bx * 256; m_blk = by * 256;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int j = wave + 8 * q;
+                const int mi = j >> 1, ph = j & 1;
+                const int r = ((lane >> 3) & 1) * 8 + ph * 4 + (lane >> 4);  // global row of the 16-row tile this lane fetches
+                int row = m_blk + (mi >> 2) * 128 + h * 64 + (mi & 3) * 16 + r;
+                if (row >= p.M) row = p.M - 1;
+                xsrc[h][q] = p.A + (long)row * p.lda + (((lane & 7) ^ (r & 7)) << 3);
+                const int ntile = (n_blk >> 4) + (j >> 2) * 4 + h * 2 + ((j >> 1) & 1);
+                wsrc[h][q] = p.Wp + ((long)ntile * KT + (j & 1)) * 512 + lane * 8;
+            }
+    };
+    // slot of half-tile `part` (0 X0, 1 W0, 2 W1, 3 X1) in K-tile buffer b; piece j at + j KiB
+    auto dma_x = [&](int b, int part, int h, int kt64) {
+        const int kk = kt64 < NK ? kt64 : NK - 1;
+        char* dst = g3lds + b * 65536 + part * G3_XH;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_global_load_lds((const void*)(xsrc[h][q] + (long)kk * 64), (wlx_lds_void*)(dst + (wave + 8 * q) * 1024), 16, 0, 0);
+    };
+    auto dma_w = [&](int b, int part, int h, int kt64) {
+        const int kk = kt64 < NK ? kt64 : NK - 1;
+        char* dst = g3lds + b * 65536 + part * G3_XH;
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            __builtin_amdgcn_global_load_lds((const void*)(wsrc[h][q] + (long)kk * 1024), (wlx_lds_void*)(dst + (wave + 8 * q) * 1024), 16, 0, 0);
+    };
+    auto prologue = [&]() {                     // K tile 0 complete, X0 / W0 of K tile 1
+        dma_x(0, 0, 0, 0); dma_w(0, 1, 0, 0); dma_w(0, 2, 1, 0); dma_x(0, 3, 1, 0);
+        dma_x(1, 0, 0, 1); dma_w(1, 1, 0, 1);
+    };
+    // ---- LDS read offsets of this lane
+    const int xrow = (((c & 7) << 1) + (c >> 3)) * 128 + wm * 8192;          // LDS row p(c) of the wave row's first tile
+    const int xo0 = xrow + (((0 + g) ^ (c & 7)) << 4), xo1 = xrow + (((4 + g) ^ (c & 7)) << 4);   // k-tile 0 / 1 of the K tile
+    const int wo = wn * 4096 + lane * 16;
+    f16x8 xr[4][2], w0r[2][2], w1r[2][2];       // register subtiles: X half (4 m-tiles x 2 k-tiles), W halves (2 n-tiles x 2 k-tiles)
+    auto read_x = [&](int b, int part) {
+        const char* base = g3lds + b * 65536 + part * G3_XH;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            xr[mt][0] = *reinterpret_cast<const f16x8*>(base + mt * 2048 + xo0);
+            xr[mt][1] = *reinterpret_cast<const f16x8*>(base + mt * 2048 + xo1);
+        }
+    };
+    auto read_w = [&](int b, int part, f16x8 (&wr)[2][2]) {
+        const char* base = g3lds + b * 65536 + part * G3_XH + wo;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) wr[nt][kt] = *reinterpret_cast<const f16x8*>(base + (nt * 2 + kt) * 1024);
+    };
+    const bool f16_out = p.mode == GEMM_STORE_F16 || p.mode == GEMM_GELU_F16 || p.mode == GEMM_QKV || p.mode == GEMM_CROSS_KV;
+    const bool wide_lds = p.epi_lds && f16_out && (p.mode == GEMM_QKV || p.mode == GEMM_CROSS_KV);   // workgroup-wide LDS epilogue: no early prologue
+    const bool staged = p.epi_lds && (p.mode == GEMM_STORE_F16 || p.mode == GEMM_GELU_F16);
+
+    set_tile(run0 + kpos);
+    prologue();
+#pragma unroll 1
+    for (;;) {
+        f32x4 acc[4][8];                        // [n-tile of the wave: quadrant column * 2 + tile][m-tile: quadrant row * 4 + tile]
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int mi = 0; mi < 8; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        auto quad = [&](int qn, int qm, f16x8 (&wr)[2][2]) {     // 16 MFMAs: k-tile outermost (dependent pairs 8 apart)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[qn * 2 + nt][qm * 4 + mt] = mfma16(wr[nt][kt], xr[mt][kt], acc[qn * 2 + nt][qm * 4 + mt]);
+        };
+        __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): this wave's prologue pieces (and the previous tile's stores)
+        __builtin_amdgcn_s_barrier();
+        if (wm == 1) __builtin_amdgcn_s_barrier();  // the second wave group runs half a phase behind
+#define G3_MID()  do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_waitcnt(0xC07F); \
+                       __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); } while (0)
+#define G3_END()  do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#pragma unroll 1
+        for (int t = 0; t < NK; t += 2) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {       // K tile t + u lives in buffer u (NK is even: launcher)
+                const int tt = t + u;
+                // P0: X0 + W0 -> quadrant (0, 0); request W1(t+1)
+                read_w(u, 1, w0r); __builtin_amdgcn_sched_barrier(0); read_x(u, 0);
+                dma_w(u ^ 1, 2, 1, tt + 1);
+                G3_MID(); quad(0, 0, w0r); G3_END();
+                // P1: W1 -> quadrant (0, 1); request X1(t+1)
+                read_w(u, 2, w1r);
+                dma_x(u ^ 1, 3, 1, tt + 1);
+                G3_MID(); quad(1, 0, w1r); G3_END();
+                // P2: X1 -> quadrant (1, 1); request X0(t+2)
+                read_x(u, 3);
+                dma_x(u, 0, 0, tt + 2);
+                G3_MID(); quad(1, 1, w1r); G3_END();
+                // P3: quadrant (1, 0) from registers; request W0(t+2); everything of K tile t+1 must have landed
+                dma_w(u, 1, 0, tt + 2);
+                __builtin_amdgcn_s_waitcnt(0x0F74);                         // vmcnt(4)
+                G3_MID(); quad(0, 1, w0r); G3_END();
+            }
+        }
+#undef G3_MID
+#undef G3_END
+        if (wm == 0) __builtin_amdgcn_s_barrier();  // (pairs with the second group's last phase barrier): every read of the ring is done
+        // ---- this tile's outputs; the next tile's first K tiles are requested as early as the epilogue allows
+        const int nt0 = (n_blk >> 4) + wn * 4, m0 = m_blk + wm * 128, n_cur = n_blk, m_cur = m_blk;
+        kpos += nper;
+        const bool more = kpos < runlen;
+        if (more && !wide_lds) { set_tile(run0 + kpos); prologue(); }       // (the clamped tail requests of this wave land before these: same wave, in order)
+        if (wide_lds) {
+            __builtin_amdgcn_s_waitcnt(0x0F70);                             // the clamped tail requests: nothing may still be writing the ring
+            __syncthreads();
+            gemm_epilogue_lds<4, 8, 4, 2>(p, acc, reinterpret_cast<half_t*>(g3lds), n_cur >> 4, m_cur, wn, wm, 0, c, g, tid);
+            if (!more) break;
+            __syncthreads();                                                // everyone is done reading the tile image
+            set_tile(run0 + kpos); prologue();
+        } else if (staged) {
+            // wave-private staging in buffer 1's W1 / X1 slots (+ the 4 KiB above the ring): neither the tail requests of the finished K
+            // loop nor the next tile's prologue touch them
+            half_t* stg = reinterpret_cast<half_t*>(g3lds + 98304 + wave * 4608);   // [32 rows][72] fp16 (64 columns + 16 bytes of pitch padding)
+            float4 bv[4];
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) bv[ni] = p.bias ? *reinterpret_cast<const float4*>(p.bias + (nt0 + ni) * 16 + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) {                                // 2 m-tiles = 32 rows of the wave's 128 at a time
+#pragma unroll
+                for (int mi2 = 0; mi2 < 2; ++mi2)
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        const f32x4 a = acc[ni][ch * 2 + mi2];
+                        float v0 = a[0] + bv[ni].x, v1 = a[1] + bv[ni].y, v2 = a[2] + bv[ni].z, v3 = a[3] + bv[ni].w;
+                        if (p.mode == GEMM_GELU_F16) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+                        const f16x4 o = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
+                        *reinterpret_cast<f16x4*>(stg + (mi2 * 16 + c) * 72 + ni * 16 + g * 4) = o;
+                    }
+                __builtin_amdgcn_s_waitcnt(0xC07F);                         // lgkmcnt(0): this wave's own writes (LDS serves a wave in order)
+#pragma unroll
+                for (int it = 0; it < 4; ++it) {
+                    const int row = it * 8 + (lane >> 3), seg = lane & 7;
+                    const f16x8 v = *reinterpret_cast<const f16x8*>(stg + row * 72 + seg * 8);
+                    const int m = m0 + ch * 32 + row;
+                    if (m < p.M) *reinterpret_cast<f16x8*>(p.C + (long)m * p.ldc + nt0 * 16 + seg * 8) = v;
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);                         // the reads are done before the next chunk overwrites the area
+            }
+            if (!more) break;
+        } else {
+            gemm_epilogue<4, 8>(p, acc, nt0, m0, 0, c, g);
+            if (!more) break;
+        }
+    }
+}
+#define G3_LDS_BYTES (256 * (256 + 8) * 2)      // the fp16 output tile of the LDS-transposed epilogue (135168 B) >= the 128 KiB ring
+static bool gemm3_ok(const GemmParams& p, int zbatch) {
+    static const int mode = [] { const char* e = getenv("WLX_GEMM3"); return e ? atoi(e) : 1; }();   // 0 = off (A/B), 2 = any M
+    if (mode == 0 || zbatch != 1 || (p.N & 255) || (p.KT & 3) || p.KT < 8) return false;
+    return mode == 2 ? p.M >= 256 : p.M >= 5000;
+}
+static void gemm3_go(const GemmParams& p0, hipStream_t s) {
+    GemmParams p = p0;
+    if (p.rows_per_item <= 0) p.rows_per_item = 4;
+    static const bool epi_lds = [] { const char* e = getenv("WLX_GEMM_EPI_LDS"); return !(e && e[0] == '0'); }();   // 0 = direct epilogue (A/B)
+    const bool scatter = p.mode == GEMM_QKV || p.mode == GEMM_CROSS_KV;
+    p.epi_lds = (epi_lds && (p.rows_per_item & 3) == 0 && (!scatter || p.d % 256 == 0)) ? 1 : 0;
+    p.g3_gx = p.N / 256;
+    p.g3_tiles = p.g3_gx * ((p.M + 255) / 256);
+    // one workgroup per CU (the kernel holds 128 KiB of LDS and 256 registers); fewer when there are fewer tiles. A multiple of 8:
+    // workgroup id % 8 is the XCD
+    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount; return n; }();
+    const int nwg = std::min((n_cu / 8) * 8, ((p.g3_tiles + 7) / 8) * 8);   // (workgroups past the end of their XCD's run leave at once)
+    hipLaunchKernelGGL(gemm3_kernel, dim3(nwg), dim3(512), G3_LDS_BYTES, s, p);
+}
+
 // tile shapes of the second form: (WNT, WMT) wave tiles -> workgroup tile (32 WNT) x (32 WMT); ring depth by what fits
 // the 160 KiB of LDS with one workgroup per CU
 struct Gemm2Shape { int wnt, wmt, depth; };
@@ -525,11 +771,13 @@ int gemm_prepare_device() {      // once per engine, on the engine's device (wlx
     if (e == hipSuccess) e = gemm2_optin<2, 4, 4>();
     if (e == hipSuccess) e = gemm2_optin<4, 2, 4>();
     if (e == hipSuccess) e = gemm2_optin<2, 2, 4>();
+    if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES);
     return (int)e;
 }
 
 void launch_gemm(const GemmParams& p, int zbatch, hipStream_t s) {
     static const int form = [] { const char* e = getenv("WLX_ENC_GEMM"); return e ? atoi(e) : 2; }();   // 1 = first form (A/B)
+    if (form != 1 && gemm3_ok(p, zbatch)) { gemm3_go(p, s); return; }
     if (form != 1 && (p.KT & 1) == 0 && p.KT >= 2) {
         switch (gemm2_pick(p, zbatch)) {
             case 0: gemm2_go<4, 4, 4>(p, zbatch, s); return;

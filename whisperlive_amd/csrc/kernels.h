@@ -54,6 +54,7 @@ struct GemmParams {
     long kv_layer_stride_k, kv_layer_stride_v; // per decoder layer (mode 5)
     int xcd_a, xcd_b;                          // (set by the launcher, second GEMM form) XCD-aware tile map: a m-parts x b n-parts
     int epi_lds;                               // (set by the launcher, second GEMM form) fp16 outputs leave through an LDS-transposed epilogue
+    int g3_gx, g3_tiles;                       // (set by the launcher, third GEMM form) tiles along n, tiles in all
 };
 void launch_gemm(const GemmParams& p, int zbatch, hipStream_t s);
 // per-device set-up of the GEMM kernels (large dynamic-LDS opt-in); returns a hipError_t value

@@ -133,6 +133,15 @@ class ServeClientBase:
                 return self.transcriber.transcribe(input_sample, **kw)
         return self.transcriber.transcribe(input_sample, **kw)                 # concurrent: own slot / HIP stream
 
+    def _downgrade_vad(self, e):
+        logging.warning(f"use_vad requested by {self.client_uid} but unavailable: {e}")
+        self.use_vad = False
+        try:
+            self.websocket.send(json.dumps({"uid": self.client_uid, "status": "WARNING",
+                                            "message": "use_vad ignored: no Silero VAD weights are configured on this server"}))
+        except Exception:  # noqa: BLE001 — a closed socket must not hide the transcript path
+            pass
+
     def on_transcription_thread_exit(self):
         """Hook run by the transcription thread as it ends (backends release per-thread resources here)."""
 
@@ -383,6 +392,15 @@ class ServeClientHIP(ServeClientBase):
                                word_timestamps=self.word_timestamps, client_uid=self.client_uid)
             worker.submit(req)
             req.future.wait(timeout=30)
+            if isinstance(req.error, _vad.VadUnavailable) and self.use_vad:
+                # the worker's transcriber has no Silero weights (a model_factory-built one): same downgrade as the direct path
+                # below — tell the client ONCE, run ungated from now on, resubmit this chunk (re-raising on every
+                # chunk left the session alive but silent)
+                self._downgrade_vad(req.error)
+                req = BatchRequest(audio=input_sample, language=self.language, task=self.task, initial_prompt=self.initial_prompt,
+                                   use_vad=False, vad_parameters=None, word_timestamps=self.word_timestamps, client_uid=self.client_uid)
+                worker.submit(req)
+                req.future.wait(timeout=30)
             if req.error:
                 raise req.error
             if self.language is None and req.info is not None:
@@ -397,13 +415,7 @@ class ServeClientHIP(ServeClientBase):
             # use_vad reached a transcriber with no Silero weights (a model_factory-built one: the server's own availability
             # check only covers transcribers it builds itself). Same outcome as there: tell the client ONCE, run ungated —
             # raising here on every chunk would leave the session alive but silent.
-            logging.warning(f"use_vad requested by {self.client_uid} but unavailable: {e}")
-            self.use_vad = False
-            try:
-                self.websocket.send(json.dumps({"uid": self.client_uid, "status": "WARNING",
-                                                "message": "use_vad ignored: no Silero VAD weights are configured on this server"}))
-            except Exception:  # noqa: BLE001 — a closed socket must not hide the transcript path
-                pass
+            self._downgrade_vad(e)
             kw.update(vad_filter=False, vad_parameters=None)
             result, info = self._transcribe_locked(input_sample, kw)
         if self.language is None and info is not None:

@@ -370,6 +370,18 @@ class TranscriptionServer:
         if any(d < 0 for d in self.devices):
             raise ValueError("device indices must be >= 0")
         self.model_factory = model_factory
+        # More than four concurrent sessions per GPU on independent slots lose throughput: a device gives at most four slots a
+        # hardware queue of their own (libwlx: WLX_DEDICATED_QUEUES), the fifth live slot sends every slot back to the shared queue
+        # pool (measured on one MI355X, Whisper-small shapes: 4 streams 2753x real time, 8 streams 2190x), while rows
+        # batched into one decode are nearly free (--batch_inference: 12 windows per decode 6050x). Say so instead of degrading
+        # silently (task 7); the mode is the operator's choice because the batched path keeps the reference's
+        # batch-mode result quirks (first 30 s per request, greedy fallback temperatures: whisper_live/batch_inference.py:259,343).
+        per_gpu = -(-int(max_clients) // max(1, len(self.devices)))
+        if not batch_enabled and per_gpu > 4:
+            logging.warning(f"max_clients={max_clients} over {len(self.devices)} GPU(s) = up to {per_gpu} concurrent sessions per GPU without "
+                            "--batch_inference: beyond 4 sessions per GPU the independent decode streams share hardware queues and aggregate "
+                            "throughput DROPS (8 streams: 2190x real time vs 2753x with 4). Start the server with --batch_inference "
+                            "(--batch_max_size 8..12, --batch_lanes 2..4) or add GPUs with --devices.")
         if vad_weights:
             _vad.configure(vad_weights, self.devices[0])         # silero_vad.onnx or .npz -> Silero on every GPU that serves a client
         return BackendType(backend)
@@ -426,8 +438,10 @@ def main(argv=None):
     ap.add_argument("--batch_inference", action="store_true")
     ap.add_argument("--batch_max_size", type=int, default=8)
     ap.add_argument("--batch_window_ms", type=int, default=50)
-    ap.add_argument("--batch_lanes", type=int, default=2, help="worker lanes per GPU in --batch_inference mode (each lane: own engine slot and "
-                                                                "hardware queue; 4 lanes x --batch_max_size 12 measured 8651x real time on one MI355X)")
+    ap.add_argument("--batch_lanes", type=int, default=2, help="worker lanes per GPU in --batch_inference mode (each lane: own engine slot and hardware "
+                                                                "queue). Measured THROUGH the worker, 64 clips of 30 s, Whisper-large-v3 shapes, one MI355X, "
+                                                                "--batch_max_size 8: 1086 / 1513 / 1618 / 1708x real time at 1 / 2 / 3 / 4 lanes (profiles/r3k_*, "
+                                                                "r3d_*); --batch_max_size 12 is slower there (1444x, profiles/r3v_*)")
     ap.add_argument("--raw_pcm_input", action="store_true")
     ap.add_argument("--metrics_port", type=int, default=0)
     ap.add_argument("--api_key", default=os.environ.get("WHISPERLIVE_API_KEY"))
