@@ -325,6 +325,10 @@ def stream_through_server(make_transcriber, seconds: float = 40.0, paced_seconds
         srv.shutdown()
         th.join(5)
         ServeClientHIP.MODELS.clear()
+        try:
+            tr.close()                 # its pooled engine slots: a live slot counts against the device's dedicated hardware queues
+        except Exception:  # noqa: BLE001
+            pass
     return out
 
 
@@ -512,6 +516,48 @@ def config5(args, rank, world, local, dist, torch):
         dist.destroy_process_group()
     if rank == 0:
         print(json.dumps(out))
+
+
+def throughput_leg(eng, spec, olm, torch, ids, eids, gen_kw, decode_steps):
+    """The throughput configuration of ONE GPU, timed by the same driver run (VERDICT r03 task 5): 4 slots on their own hardware
+    queues x 12 windows batched into every decode — what a --batch_inference server with four lanes runs. Called after
+    the headline's own slot is closed: a fifth live slot would send every slot back to the shared queue pool."""
+    from concurrent.futures import ThreadPoolExecutor
+    TS, TB, tsteps = 4, 12, 3
+    tslots = [eng.create_slot(TB, 5) for _ in range(TS)]
+    try:
+        for i, sl in enumerate(tslots):
+            for b in range(TB):
+                sl.pcm_put(olm.speech_like_pcm(WINDOW_S, seed=5000 + 100 * i + b), b)
+
+        def tstep(sl):
+            Ts_ = [sl.logmel_resident(b) for b in range(TB)]
+            sl.encode(TB, seek=[0] * TB, seg=[min(T - 1, 3000) for T in Ts_])
+            return sl.generate([[ids["sot"]]] * TB, eids, **gen_kw)[0]
+        with ThreadPoolExecutor(max_workers=TS) as tp:
+            list(tp.map(tstep, tslots))                       # warm-up (graph capture per slot)
+            torch.cuda.synchronize()
+            tt0 = time.perf_counter()
+            for _ in range(tsteps):
+                list(tp.map(tstep, tslots))
+            torch.cuda.synchronize()
+            twall = time.perf_counter() - tt0
+        tm12 = tslots[0].timings()
+        # one slot alone: the batched encoder's MFMA fraction without the other slots' work beside it
+        Ts_ = [tslots[0].logmel_resident(b) for b in range(TB)]
+        tslots[0].encode(TB, seek=[0] * TB, seg=[min(T - 1, 3000) for T in Ts_])
+        enc12 = tslots[0].timings()["encode_ms"]
+        step12 = tslots[0].debug_time_decode_step(rows=5 * TB, t=1 + decode_steps // 2, iters=20)
+        return dict(xrt=TS * TB * tsteps * WINDOW_S / twall, streams=TS, batch_per_stream=TB, steps=tsteps,
+                    ms_per_step=1e3 * twall / tsteps, windows_per_step=TS * TB,
+                    stage_ms_slot0=tm12, encode_ms_one_slot=enc12,
+                    encoder_frac_of_mfma_peak=encoder_flops(spec) * TB / (enc12 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                    decode_step_60rows_ms=step12,
+                    note="aggregate of 4 concurrent slots (own hardware queues) x 12 windows batched per decode, 64 tokens each; "
+                         "engine-level (PCM resident in HBM), no server / VAD in this leg")
+    finally:
+        for sl in tslots:
+            sl.close()
 
 
 def main():
@@ -717,47 +763,6 @@ def main():
         out["roofline_encoder"] = dict(bound="mfma", flops=ef, ms=stage["encode_ms"], achieved=ef / (stage["encode_ms"] * 1e-3) / 1e12,
                                        peak=MFMA_PEAK_TFLOPS, unit="TFLOP/s", frac_of_mfma_peak=ef / (stage["encode_ms"] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
                                        windows_per_launch=B)
-        if world == 1 and S == 1 and B == 1 and not args.no_throughput:
-            # the throughput configuration of ONE GPU, timed by the same driver run (VERDICT r03 task 5): 4 slots on their own
-            # hardware queues x 12 windows batched into every decode — what a --batch_inference server runs
-            note("throughput leg (4 streams x 12 windows per decode)")
-            try:
-                from concurrent.futures import ThreadPoolExecutor
-                TS, TB, tsteps = 4, 12, 3
-                tslots = [eng.create_slot(TB, 5) for _ in range(TS)]
-                for i, sl in enumerate(tslots):
-                    for b in range(TB):
-                        sl.pcm_put(olm.speech_like_pcm(WINDOW_S, seed=5000 + 100 * i + b), b)
-
-                def tstep(sl):
-                    Ts_ = [sl.logmel_resident(b) for b in range(TB)]
-                    sl.encode(TB, seek=[0] * TB, seg=[min(T - 1, 3000) for T in Ts_])
-                    return sl.generate([[ids["sot"]]] * TB, eids, **gen_kw)[0]
-                with ThreadPoolExecutor(max_workers=TS) as tp:
-                    list(tp.map(tstep, tslots))                       # warm-up (graph capture per slot)
-                    torch.cuda.synchronize()
-                    tt0 = time.perf_counter()
-                    for _ in range(tsteps):
-                        list(tp.map(tstep, tslots))
-                    torch.cuda.synchronize()
-                    twall = time.perf_counter() - tt0
-                tm12 = tslots[0].timings()
-                # one slot alone: the batched encoder's MFMA fraction without the other slots' work beside it
-                Ts_ = [tslots[0].logmel_resident(b) for b in range(TB)]
-                tslots[0].encode(TB, seek=[0] * TB, seg=[min(T - 1, 3000) for T in Ts_])
-                enc12 = tslots[0].timings()["encode_ms"]
-                step12 = tslots[0].debug_time_decode_step(rows=5 * TB, t=1 + args.decode_steps // 2, iters=20)
-                out["throughput"] = dict(xrt=TS * TB * tsteps * WINDOW_S / twall, streams=TS, batch_per_stream=TB, steps=tsteps,
-                                         ms_per_step=1e3 * twall / tsteps, windows_per_step=TS * TB,
-                                         stage_ms_slot0=tm12, encode_ms_one_slot=enc12,
-                                         encoder_frac_of_mfma_peak=encoder_flops(spec) * TB / (enc12 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
-                                         decode_step_60rows_ms=step12,
-                                         note="aggregate of 4 concurrent slots (own hardware queues) x 12 windows batched per decode, 64 tokens each; "
-                                              "engine-level (PCM resident in HBM), no server / VAD in this leg")
-                for sl in tslots:
-                    sl.close()
-            except Exception as e:  # noqa: BLE001 — the headline line must survive a failure of this leg
-                out["throughput"] = {"error": f"{type(e).__name__}: {e}"}
         if S == 1 and B == 1:
             # every window after the first of a stream is CONDITIONED on up to 223 previous tokens
             # (transcriber_faster_whisper.py:1480-1513): the same window with the reference's full prompt [sot_prev] + 223 + [sot]
@@ -808,6 +813,12 @@ def main():
                                       "fp16-vs-fp32 near-tie ends the common prefix")
     for sl in slots:
         sl.close()
+    if rank == 0 and world == 1 and S == 1 and B == 1 and not args.no_throughput:
+        note("throughput leg (4 streams x 12 windows per decode)")
+        try:
+            out["throughput"] = throughput_leg(eng, spec, olm, torch, ids, eids, gen_kw, args.decode_steps)
+        except Exception as e:  # noqa: BLE001 — the headline line must survive a failure of this leg
+            out["throughput"] = {"error": f"{type(e).__name__}: {e}"}
     eng.close()
     if dist is not None:
         dist.barrier()

@@ -21,6 +21,7 @@
 // for the attention kernels).
 #include "kernels.h"
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 namespace wlx {
@@ -499,8 +500,14 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
 // per-launch traces at 12 windows showed ~40 us per tile for the K = 768 GEMMs whose 12 K tiles need ~17 us. Now the NEXT tile's
 // prologue requests are issued before the epilogue of the finished one wherever the epilogue does not need the ring: fp32 modes store
 // from registers; the fp16 row-major modes (MLP up-projection) go through a WAVE-PRIVATE 4.5 KiB staging area in the dead W1 / X1 slots
-// of buffer 1 (32 rows x 64 columns at a time -> 16-byte pieces, a wave store = 8 full 128-byte rows; no workgroup barrier); the
-// scattering modes (QKV, cross K/V) keep the workgroup-wide LDS-transposed epilogue and request their next tile after it.
+// of buffer 1 (32 rows x 64 columns at a time -> 16-byte pieces, a wave store = 8 full 128-byte rows; no workgroup barrier) — also q,
+// K rows and the tile-packed cross K of the scattering modes, whose pieces are 16 bytes of one row as well. The column-major outputs
+// (V^T for the encoder attention, the tile-packed cross V) need no transposition at all: for a tile whose 256 columns are V columns
+// (uniform per tile: d_model % 256 == 0) the MFMAs run with their operands SWAPPED — the A and B fragments of 16x16x32 have the same
+// register layout (row c, 8 k at g*8), so mfma(x, w) instead of mfma(w, x) yields the transposed accumulator tile: a lane then holds
+// 4 consecutive ROWS (time steps) of one column, i.e. one 8-byte piece of V^T / of the packed V image, stored straight from registers.
+// (Same products, same k order: the values are those of the untransposed tile.) Probes of the first persistent version (profiles/r4h_*:
+// K loop only / epilogue only) had the workgroup-wide LDS-transposed epilogue at 15 us per QKV tile against a 20 us K loop.
 // The epilogue's stores share the vmcnt queue with the LDS-DMA requests, so a tile starts with vmcnt(0) instead of a counted wait.
 __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char g3lds[];           // [2][X0 | W0 | W1 | X1] x 16 KiB (+ 4 KiB) — the ONLY LDS object
@@ -517,8 +524,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     int kpos = (int)blockIdx.x >> 3;                                        // position in the XCD's run
     if (kpos >= runlen) return;
     const int KT = p.KT, NK = KT >> 1;
-    const half_t* xsrc[2][2];
-    const half_t* wsrc[2][2];
+    // LDS-DMA requests go through buffer descriptors (buffer_load_dwordx4 ... lds): the per-lane part of an address is ONE 32-bit
+    // register per distinct lane pattern (4 for the activations, 1 for the weights), everything else — tile, K position — is a scalar
+    // offset. (As 64-bit global addresses the eight source pointers and their per-request adds pushed the kernel into scratch.)
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.A, 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc((void*)p.Wp, 0, 0x7fffffff, 0x00020000);
+    int xvo[2][2];                              // per-lane byte offsets of the four activation pieces this wave requests per K tile
+    int wso[2][2];                              // scalar byte offsets of its four weight pieces (K tile 0)
+    const int wvo = lane * 16;
     int n_blk = 0, m_blk = 0;
     // ---- LDS-DMA sources of a tile. A half-tile = 16 pieces of 1 KiB; wave w requests pieces w and w + 8.
     //   X half h, piece j: 16-row tile mi = j >> 1 of the half (wave row mi >> 2, tile mi & 3), LDS rows (j & 1) * 8 .. + 7
@@ -535,9 +548,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
                 const int r = ((lane >> 3) & 1) * 8 + ph * 4 + (lane >> 4);  // global row of the 16-row tile this lane fetches
                 int row = m_blk + (mi >> 2) * 128 + h * 64 + (mi & 3) * 16 + r;
                 if (row >= p.M) row = p.M - 1;
-                xsrc[h][q] = p.A + (long)row * p.lda + (((lane & 7) ^ (r & 7)) << 3);
+                xvo[h][q] = (int)(((long)row * p.lda + (((lane & 7) ^ (r & 7)) << 3)) * 2);      // (launcher: M * lda * 2 < 2^31)
                 const int ntile = (n_blk >> 4) + (j >> 2) * 4 + h * 2 + ((j >> 1) & 1);
-                wsrc[h][q] = p.Wp + ((long)ntile * KT + (j & 1)) * 512 + lane * 8;
+                wso[h][q] = __builtin_amdgcn_readfirstlane((int)(((long)ntile * KT + (j & 1)) * 1024));   // (launcher: N * K * 2 < 2^31)
             }
     };
     // slot of half-tile `part` (0 X0, 1 W0, 2 W1, 3 X1) in K-tile buffer b; piece j at + j KiB
@@ -546,14 +559,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
         char* dst = g3lds + b * 65536 + part * G3_XH;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-            __builtin_amdgcn_global_load_lds((const void*)(xsrc[h][q] + (long)kk * 64), (wlx_lds_void*)(dst + (wave + 8 * q) * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (wlx_lds_void*)(dst + (wave + 8 * q) * 1024), 16, xvo[h][q], kk * 128, 0, 0);
     };
     auto dma_w = [&](int b, int part, int h, int kt64) {
         const int kk = kt64 < NK ? kt64 : NK - 1;
         char* dst = g3lds + b * 65536 + part * G3_XH;
 #pragma unroll
         for (int q = 0; q < 2; ++q)
-            __builtin_amdgcn_global_load_lds((const void*)(wsrc[h][q] + (long)kk * 1024), (wlx_lds_void*)(dst + (wave + 8 * q) * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (wlx_lds_void*)(dst + (wave + 8 * q) * 1024), 16, wvo, wso[h][q] + kk * 2048, 0, 0);
     };
     auto prologue = [&]() {                     // K tile 0 complete, X0 / W0 of K tile 1
         dma_x(0, 0, 0, 0); dma_w(0, 1, 0, 0); dma_w(0, 2, 1, 0); dma_x(0, 3, 1, 0);
@@ -580,13 +593,22 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
             for (int kt = 0; kt < 2; ++kt) wr[nt][kt] = *reinterpret_cast<const f16x8*>(base + (nt * 2 + kt) * 1024);
     };
     const bool f16_out = p.mode == GEMM_STORE_F16 || p.mode == GEMM_GELU_F16 || p.mode == GEMM_QKV || p.mode == GEMM_CROSS_KV;
-    const bool wide_lds = p.epi_lds && f16_out && (p.mode == GEMM_QKV || p.mode == GEMM_CROSS_KV);   // workgroup-wide LDS epilogue: no early prologue
-    const bool staged = p.epi_lds && (p.mode == GEMM_STORE_F16 || p.mode == GEMM_GELU_F16);
+    const bool staged = p.epi_lds && f16_out;   // (launcher: rows_per_item % 4 == 0 and d_model % 256 == 0 for the scattering modes)
+    // what the tile's 256 columns are (uniform): QKV part 0 q / 1 k / 2 v; cross K/V: decoder layer, part 0 k / 1 v
+    int part = 0, layer = 0, col0 = 0;
+    bool tr = false;                            // this tile accumulates transposed (V columns)
+    auto classify = [&]() {
+        part = 0; layer = 0; col0 = n_blk;
+        if (p.mode == GEMM_QKV) { part = n_blk / p.d; col0 = n_blk - part * p.d; }
+        else if (p.mode == GEMM_CROSS_KV) { layer = n_blk / (2 * p.d); const int nn = n_blk - layer * 2 * p.d; part = nn / p.d; col0 = nn - part * p.d; }
+        tr = staged && ((p.mode == GEMM_QKV && part == 2) || (p.mode == GEMM_CROSS_KV && part == 1));
+    };
 
     set_tile(run0 + kpos);
     prologue();
 #pragma unroll 1
     for (;;) {
+        classify();
         f32x4 acc[4][8];                        // [n-tile of the wave: quadrant column * 2 + tile][m-tile: quadrant row * 4 + tile]
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
@@ -600,54 +622,107 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
 #pragma unroll
                     for (int mt = 0; mt < 4; ++mt) acc[qn * 2 + nt][qm * 4 + mt] = mfma16(wr[nt][kt], xr[mt][kt], acc[qn * 2 + nt][qm * 4 + mt]);
         };
+        auto quad_t = [&](int qn, int qm, f16x8 (&wr)[2][2]) {   // the same tile transposed: D[i = m][j = n], lane = (column c, rows g*4 ..)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc[qn * 2 + nt][qm * 4 + mt] = mfma16(xr[mt][kt], wr[nt][kt], acc[qn * 2 + nt][qm * 4 + mt]);
+        };
+        const bool trq = tr;                    // (uniform; read once per tile) — the K loop exists twice, selected per tile: a branch per
+                                                // phase between the two MFMA orders costs registers (both operand orders live) and spilled
         __builtin_amdgcn_s_waitcnt(0x0F70);     // vmcnt(0): this wave's prologue pieces (and the previous tile's stores)
         __builtin_amdgcn_s_barrier();
         if (wm == 1) __builtin_amdgcn_s_barrier();  // the second wave group runs half a phase behind
 #define G3_MID()  do { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_waitcnt(0xC07F); \
                        __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(1); } while (0)
 #define G3_END()  do { __builtin_amdgcn_s_setprio(0); __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_barrier(); __builtin_amdgcn_sched_barrier(0); } while (0)
+        auto kloop = [&](auto TRc) {
+        constexpr bool TR = decltype(TRc)::value;
 #pragma unroll 1
-        for (int t = 0; t < NK; t += 2) {
+        for (int t = 0; t < ((p.xcd_a & 2) ? 2 : NK); t += 2) {    // (xcd_a: timing probes, 0 in production — WLX_GEMM3_PROBE, gemm3_go)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {       // K tile t + u lives in buffer u (NK is even: launcher)
                 const int tt = t + u;
                 // P0: X0 + W0 -> quadrant (0, 0); request W1(t+1)
                 read_w(u, 1, w0r); __builtin_amdgcn_sched_barrier(0); read_x(u, 0);
                 dma_w(u ^ 1, 2, 1, tt + 1);
-                G3_MID(); quad(0, 0, w0r); G3_END();
+                G3_MID(); if constexpr (TR) quad_t(0, 0, w0r); else quad(0, 0, w0r); G3_END();
                 // P1: W1 -> quadrant (0, 1); request X1(t+1)
                 read_w(u, 2, w1r);
                 dma_x(u ^ 1, 3, 1, tt + 1);
-                G3_MID(); quad(1, 0, w1r); G3_END();
+                G3_MID(); if constexpr (TR) quad_t(1, 0, w1r); else quad(1, 0, w1r); G3_END();
                 // P2: X1 -> quadrant (1, 1); request X0(t+2)
                 read_x(u, 3);
                 dma_x(u, 0, 0, tt + 2);
-                G3_MID(); quad(1, 1, w1r); G3_END();
+                G3_MID(); if constexpr (TR) quad_t(1, 1, w1r); else quad(1, 1, w1r); G3_END();
                 // P3: quadrant (1, 0) from registers; request W0(t+2); everything of K tile t+1 must have landed
                 dma_w(u, 1, 0, tt + 2);
                 __builtin_amdgcn_s_waitcnt(0x0F74);                         // vmcnt(4)
-                G3_MID(); quad(0, 1, w0r); G3_END();
+                G3_MID(); if constexpr (TR) quad_t(0, 1, w0r); else quad(0, 1, w0r); G3_END();
             }
         }
+        };
+        if (trq) kloop(std::true_type{}); else kloop(std::false_type{});
 #undef G3_MID
 #undef G3_END
         if (wm == 0) __builtin_amdgcn_s_barrier();  // (pairs with the second group's last phase barrier): every read of the ring is done
-        // ---- this tile's outputs; the next tile's first K tiles are requested as early as the epilogue allows
-        const int nt0 = (n_blk >> 4) + wn * 4, m0 = m_blk + wm * 128, n_cur = n_blk, m_cur = m_blk;
+        // ---- this tile's outputs; the next tile's first K tiles are requested first (no epilogue needs the ring any more)
+        const int nt0 = (n_blk >> 4) + wn * 4, m0 = m_blk + wm * 128;
+        const int e_part = part, e_layer = layer, e_col0 = col0 + wn * 64;    // (of the finished tile; e_col0: this wave's first column inside its part)
         kpos += nper;
         const bool more = kpos < runlen;
-        if (more && !wide_lds) { set_tile(run0 + kpos); prologue(); }       // (the clamped tail requests of this wave land before these: same wave, in order)
-        if (wide_lds) {
-            __builtin_amdgcn_s_waitcnt(0x0F70);                             // the clamped tail requests: nothing may still be writing the ring
-            __syncthreads();
-            gemm_epilogue_lds<4, 8, 4, 2>(p, acc, reinterpret_cast<half_t*>(g3lds), n_cur >> 4, m_cur, wn, wm, 0, c, g, tid);
-            if (!more) break;
-            __syncthreads();                                                // everyone is done reading the tile image
-            set_tile(run0 + kpos); prologue();
-        } else if (staged) {
-            // wave-private staging in buffer 1's W1 / X1 slots (+ the 4 KiB above the ring): neither the tail requests of the finished K
-            // loop nor the next tile's prologue touch them
+        if (more) { set_tile(run0 + kpos); prologue(); }                    // (the clamped tail requests of this wave land before these: same wave, in order)
+        if (p.xcd_a & 1) {                                                  // probe: no epilogue (keep the accumulators alive)
+            float tsum = 0.f;
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) tsum += acc[ni][mi][0] + acc[ni][mi][3];
+            if (tsum == 1.2345e30f) p.X[0] = tsum;
+        } else if (!staged) {
+            gemm_epilogue<4, 8>(p, acc, nt0, m0, 0, c, g);
+        } else if (trq) {
+            // transposed accumulators: lane (c, g) holds rows m = m-tile + g*4 .. +3 of column nt*16 + c: an 8-byte piece of V^T (QKV) or of
+            // the tile-packed cross V (4 consecutive keys of one dim). rows_per_item % 4 == 0: a piece never straddles two items.
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int da = e_col0 + ni * 16 + c;                        // column inside V (dim of the model)
+                const float bn = p.bias ? p.bias[(nt0 + ni) * 16 + c] : 0.f;
+#pragma unroll
+                for (int mi = 0; mi < 8; ++mi) {
+                    const int m = m0 + mi * 16 + g * 4;
+                    if (m >= p.M) continue;
+                    const f32x4 a = acc[ni][mi];
+                    const f16x4 o = {(half_t)(a[0] + bn), (half_t)(a[1] + bn), (half_t)(a[2] + bn), (half_t)(a[3] + bn)};
+                    const int item = m / p.rows_per_item, t = m - item * p.rows_per_item;
+                    half_t* dst;
+                    if (p.mode == GEMM_QKV) dst = p.Vt + (long)item * p.kv_item_stride_v + (long)da * p.ldvt + t;
+                    else {
+                        const int hd = da >> 6, dd = da & 63, tile = t >> 5, k32 = t & 31;
+                        dst = p.Vt + (long)e_layer * p.kv_layer_stride_v + (long)item * p.kv_item_stride_v + ((long)hd * (WLX_T_AUDIO_PAD / 32) + tile) * 2048 +
+                              ((dd >> 4) * 64 + ((k32 & 15) >> 2) * 16 + (dd & 15)) * 8 + ((k32 >> 4) << 2);
+                    }
+                    if (m + 3 < p.M) *reinterpret_cast<f16x4*>(dst) = o;
+                    else {                                                  // ragged last rows (M not a multiple of 4): element by element
+                        for (int j = 0; j < 4 && m + j < p.M; ++j) {
+                            if (p.mode == GEMM_QKV) dst[j] = o[j];
+                            else {
+                                const int tj = t + j, hd = da >> 6, dd = da & 63, k32j = tj & 31;
+                                p.Vt[(long)e_layer * p.kv_layer_stride_v + (long)item * p.kv_item_stride_v + ((long)hd * (WLX_T_AUDIO_PAD / 32) + (tj >> 5)) * 2048 +
+                                     ((dd >> 4) * 64 + ((k32j & 15) >> 2) * 16 + (dd & 15)) * 8 + (k32j & 3) + ((k32j >> 4) << 2)] = o[j];
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            // row-major pieces through a wave-private staging area in buffer 1's W1 / X1 slots (+ the 4 KiB above the ring): neither the
+            // tail requests of the finished K loop nor the next tile's prologue touch them. 32 rows x 64 columns at a time; a lane then
+            // takes 16 bytes = 8 consecutive columns of one row: fp16 rows of C / q / K, or one lane-slot of the tile-packed cross K.
             half_t* stg = reinterpret_cast<half_t*>(g3lds + 98304 + wave * 4608);   // [32 rows][72] fp16 (64 columns + 16 bytes of pitch padding)
+            const float scale = (p.mode == GEMM_QKV && e_part == 0) ? p.qscale : 1.0f;
             float4 bv[4];
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) bv[ni] = p.bias ? *reinterpret_cast<const float4*>(p.bias + (nt0 + ni) * 16 + g * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -660,7 +735,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
                         const f32x4 a = acc[ni][ch * 2 + mi2];
                         float v0 = a[0] + bv[ni].x, v1 = a[1] + bv[ni].y, v2 = a[2] + bv[ni].z, v3 = a[3] + bv[ni].w;
                         if (p.mode == GEMM_GELU_F16) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
-                        const f16x4 o = {(half_t)v0, (half_t)v1, (half_t)v2, (half_t)v3};
+                        const f16x4 o = {(half_t)(v0 * scale), (half_t)(v1 * scale), (half_t)(v2 * scale), (half_t)(v3 * scale)};
                         *reinterpret_cast<f16x4*>(stg + (mi2 * 16 + c) * 72 + ni * 16 + g * 4) = o;
                     }
                 __builtin_amdgcn_s_waitcnt(0xC07F);                         // lgkmcnt(0): this wave's own writes (LDS serves a wave in order)
@@ -669,21 +744,33 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
                     const int row = it * 8 + (lane >> 3), seg = lane & 7;
                     const f16x8 v = *reinterpret_cast<const f16x8*>(stg + row * 72 + seg * 8);
                     const int m = m0 + ch * 32 + row;
-                    if (m < p.M) *reinterpret_cast<f16x8*>(p.C + (long)m * p.ldc + nt0 * 16 + seg * 8) = v;
+                    if (m >= p.M) continue;
+                    half_t* dst;
+                    if (p.mode == GEMM_QKV) {
+                        if (e_part == 0) dst = p.C + (long)m * p.ldc + nt0 * 16 + seg * 8;
+                        else {
+                            const int item = m / p.rows_per_item, t = m - item * p.rows_per_item;
+                            dst = p.Kout + (long)item * p.kv_item_stride_k + (long)t * p.ldk + (e_col0 + seg * 8);
+                        }
+                    } else if (p.mode == GEMM_CROSS_KV) {
+                        const int item = m / p.rows_per_item, t = m - item * p.rows_per_item;
+                        const int da = e_col0 + seg * 8, hd = da >> 6, dd = da & 63, tile = t >> 5, k32 = t & 31;
+                        dst = p.Kout + (long)e_layer * p.kv_layer_stride_k + (long)item * p.kv_item_stride_k + ((long)hd * (WLX_T_AUDIO_PAD / 32) + tile) * 2048 +
+                              (((k32 >> 4) * 2 + (dd >> 5)) * 64 + ((dd & 31) >> 3) * 16 + (k32 & 15)) * 8;
+                    } else dst = p.C + (long)m * p.ldc + nt0 * 16 + seg * 8;
+                    *reinterpret_cast<f16x8*>(dst) = v;
                 }
                 __builtin_amdgcn_s_waitcnt(0xC07F);                         // the reads are done before the next chunk overwrites the area
             }
-            if (!more) break;
-        } else {
-            gemm_epilogue<4, 8>(p, acc, nt0, m0, 0, c, g);
-            if (!more) break;
         }
+        if (!more) break;
     }
 }
 #define G3_LDS_BYTES (256 * (256 + 8) * 2)      // the fp16 output tile of the LDS-transposed epilogue (135168 B) >= the 128 KiB ring
 static bool gemm3_ok(const GemmParams& p, int zbatch) {
     static const int mode = [] { const char* e = getenv("WLX_GEMM3"); return e ? atoi(e) : 1; }();   // 0 = off (A/B), 2 = any M
     if (mode == 0 || zbatch != 1 || (p.N & 255) || (p.KT & 3) || p.KT < 8) return false;
+    if ((long)p.M * p.lda * 2 >= (1L << 31) || (long)p.N * p.KT * 64 >= (1L << 31)) return false;   // 32-bit buffer offsets
     return mode == 2 ? p.M >= 256 : p.M >= 5000;
 }
 static void gemm3_go(const GemmParams& p0, hipStream_t s) {
@@ -692,6 +779,8 @@ static void gemm3_go(const GemmParams& p0, hipStream_t s) {
     static const bool epi_lds = [] { const char* e = getenv("WLX_GEMM_EPI_LDS"); return !(e && e[0] == '0'); }();   // 0 = direct epilogue (A/B)
     const bool scatter = p.mode == GEMM_QKV || p.mode == GEMM_CROSS_KV;
     p.epi_lds = (epi_lds && (p.rows_per_item & 3) == 0 && (!scatter || p.d % 256 == 0)) ? 1 : 0;
+    static const int probe = [] { const char* e = getenv("WLX_GEMM3_PROBE"); return e ? atoi(e) : 0; }();   // timing probes: 1 no epilogue, 2 one K-tile pair only
+    p.xcd_a = probe;
     p.g3_gx = p.N / 256;
     p.g3_tiles = p.g3_gx * ((p.M + 255) / 256);
     // one workgroup per CU (the kernel holds 128 KiB of LDS and 256 registers); fewer when there are fewer tiles. A multiple of 8:
