@@ -793,7 +793,7 @@ static void gemm3_go(const GemmParams& p0, hipStream_t s) {
 // tile shapes of the second form: (WNT, WMT) wave tiles -> workgroup tile (32 WNT) x (32 WMT); ring depth by what fits
 // the 160 KiB of LDS with one workgroup per CU
 struct Gemm2Shape { int wnt, wmt, depth; };
-static const Gemm2Shape kGemm2Shapes[] = {{4, 4, 4}, {4, 6, 3}, {6, 4, 3}, {2, 3, 4}, {2, 4, 4}, {4, 2, 4}, {2, 2, 4}};
+static const Gemm2Shape kGemm2Shapes[] = {{4, 4, 4}, {4, 6, 3}, {6, 4, 3}, {2, 3, 4}, {2, 4, 4}, {4, 2, 4}, {2, 2, 4}, {4, 4, 2}};   // (the last: 128 x 128 with 64 KiB = two workgroups per CU, measured for large M in round 4)
 template <int WNT, int WMT, int DEPTH>
 static void gemm2_go(const GemmParams& p0, int zbatch, hipStream_t s) {
     constexpr size_t shm = (size_t)DEPTH * (4 * WNT + 4 * WMT) * 1024;
@@ -860,6 +860,7 @@ int gemm_prepare_device() {      // once per engine, on the engine's device (wlx
     if (e == hipSuccess) e = gemm2_optin<2, 4, 4>();
     if (e == hipSuccess) e = gemm2_optin<4, 2, 4>();
     if (e == hipSuccess) e = gemm2_optin<2, 2, 4>();
+    if (e == hipSuccess) e = gemm2_optin<4, 4, 2>();
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES);
     return (int)e;
 }
@@ -875,6 +876,7 @@ void launch_gemm(const GemmParams& p, int zbatch, hipStream_t s) {
             case 3: gemm2_go<2, 3, 4>(p, zbatch, s); return;
             case 4: gemm2_go<2, 4, 4>(p, zbatch, s); return;
             case 5: gemm2_go<4, 2, 4>(p, zbatch, s); return;
+            case 7: gemm2_go<4, 4, 2>(p, zbatch, s); return;
             default: gemm2_go<2, 2, 4>(p, zbatch, s); return;
         }
     }
