@@ -1,5 +1,5 @@
 """GPU parity (-m gpu) of the LARGE-M encoder GEMM (gemm.hip gemm3_kernel: 256 x 256 x 64 tiles, 8 waves, four phases per K tile,
-chosen for M >= 5000 rows, i.e. a batched encoder of >= 4 windows): the batched encode of B windows against
+chosen for M >= 4000 rows, i.e. a batched encoder of >= 3 windows): the batched encode of B windows against
 
   * the single-window encodes of the same clips on the M = 1500 kernel (gemm2_kernel) — both accumulate K in the same order in
     fp32, so the encoder states must agree to the last bit or nearly (<= 1e-5 relative), for EVERY item (256-row tiles straddle

@@ -771,7 +771,9 @@ static bool gemm3_ok(const GemmParams& p, int zbatch) {
     static const int mode = [] { const char* e = getenv("WLX_GEMM3"); return e ? atoi(e) : 1; }();   // 0 = off (A/B), 2 = any M
     if (mode == 0 || zbatch != 1 || (p.N & 255) || (p.KT & 3) || p.KT < 8) return false;
     if ((long)p.M * p.lda * 2 >= (1L << 31) || (long)p.N * p.KT * 64 >= (1L << 31)) return false;   // 32-bit buffer offsets
-    return mode == 2 ? p.M >= 256 : p.M >= 5000;
+    // measured (profiles/r4k_encode_shape_times.txt, Whisper-small): 2 windows (M = 3000) 2.77 ms here vs 2.60 on the 64 x 96 tile, 3 windows
+    // (M = 4500) 3.10 vs 3.64, 12 windows 7.75 vs 11.8
+    return mode == 2 ? p.M >= 256 : p.M >= 4000;
 }
 static void gemm3_go(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
