@@ -48,6 +48,8 @@ struct Slot {
     int device_of = -1;
     bool counted = false;               // in the per-device live-slot count
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_poll0 = nullptr, ev_poll1 = nullptr;
+    hipEvent_t ev_lm0 = nullptr, ev_lm1 = nullptr;   // the last log-mel launch (its time is read lazily: wlx_logmel_resident does not wait)
+    bool lm_pending = false;
     std::vector<void*> allocs;
     // features
     float* pcm = nullptr; size_t pcm_cap = 0;       // [B][pcm_cap]

@@ -400,6 +400,8 @@ static void slot_free(Slot* s) {
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->ev_poll0) (void)hipEventDestroy(s->ev_poll0);
     if (s->ev_poll1) (void)hipEventDestroy(s->ev_poll1);
+    if (s->ev_lm0) (void)hipEventDestroy(s->ev_lm0);
+    if (s->ev_lm1) (void)hipEventDestroy(s->ev_lm1);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -579,6 +581,7 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         CK(hipEventCreate(&s->ev0)); CK(hipEventCreate(&s->ev1));
         CK(hipEventCreateWithFlags(&s->ev_poll0, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&s->ev_poll1, hipEventDisableTiming));
+        CK(hipEventCreate(&s->ev_lm0)); CK(hipEventCreate(&s->ev_lm1));
         CKR(slot_grow_audio(e, s, 480000));
         CKR(dalloc(s->allocs, &s->gmax, (size_t)B));
         s->featT_stride = (long)(WLX_N_FRAMES + 2) * sp.n_mels + 64;
@@ -716,6 +719,12 @@ extern "C" int32_t wlx_timings_get(wlx_engine* e, int32_t slot, wlx_timings* out
     CKR(slot_acquire(e, slot, sg_));
     Slot* s = sg_.s;
     if (!out) return fail(WLX_ERR_ARG, "null out");
+    if (s->lm_pending) {                      // the last log-mel launch: waited for here, not in wlx_logmel_resident
+        CK(hipSetDevice(e->device));
+        CK(hipEventSynchronize(s->ev_lm1));
+        CK(hipEventElapsedTime(&s->tm.logmel_ms, s->ev_lm0, s->ev_lm1));
+        s->lm_pending = false;
+    }
     *out = s->tm;
     return WLX_OK;
 }
@@ -749,12 +758,14 @@ extern "C" int32_t wlx_logmel_resident(wlx_engine* e, int32_t slot, int32_t item
     const int T = (int)((n + 160) / 160);
     float* dp = s->pcm + (size_t)item * s->pcm_cap;
     float* df = s->feats + (size_t)item * e->spec.n_mels * s->feat_ld;
-    CK(hipEventRecord(s->ev0, s->stream));
+    // No host wait (round 4): the frame count is a function of the sample count, everything downstream (features_get, encode) is
+    // ordered on the slot's stream, and the launch's time is read lazily by wlx_timings_get. A batch of 12 windows used to pay 12
+    // launch -> wait round trips (~100 us each) in front of its encoder.
+    CK(hipEventRecord(s->ev_lm0, s->stream));
     launch_logmel(dp, (long)n, e->spec.n_mels, e->lm, df, s->feat_ld, T, s->gmax + item, s->stream);
     CK(hipGetLastError());
-    CK(hipEventRecord(s->ev1, s->stream));
-    CK(hipStreamSynchronize(s->stream));
-    CK(hipEventElapsedTime(&s->tm.logmel_ms, s->ev0, s->ev1));
+    CK(hipEventRecord(s->ev_lm1, s->stream));
+    s->lm_pending = true;
     s->nframes[item] = T;
     if (n_frames_out) *n_frames_out = T;
     return WLX_OK;
