@@ -586,6 +586,7 @@ def main():
     ap.add_argument("--clips", type=int, default=64, help="--config 5: number of 30 s clips per step")
     ap.add_argument("--max-batch", type=int, default=8, help="--config 5: max_batch_size of the BatchInferenceWorker (8 = the reference's default, batch_inference.py:100; up to 12 = 60 decoder rows)")
     ap.add_argument("--lanes", type=int, default=4, help="--config 5: lanes of the BatchInferenceWorker (1 = the reference's single worker thread, 2 = the library default; measured 1086 / 1513 / 1618 / 1708 xRT at 1 / 2 / 3 / 4 lanes, profiles/r3k_*, r3d_*)")
+    ap.add_argument("--free-run", action="store_true", help="--streams S: every stream runs its steps back to back, started 1/S of a step apart, instead of a barrier per step")
     ap.add_argument("--no-throughput", action="store_true", help="skip the 4-stream x 12-window throughput leg of the default run")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 FETCH_SIZE pass that fills roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
@@ -692,12 +693,35 @@ def main():
     lat = []
     stage = dict(logmel_ms=0.0, encode_ms=0.0, generate_ms=0.0)
     last = None
-    for _ in range(args.steps):
-        dt, last = step()
-        lat.append(dt)
+    if S > 1 and args.free_run:
+        # the streams run their K steps back to back WITHOUT a barrier per step, started a fraction of a step apart: clients
+        # are not phase-locked (the stream leg's clients are separate processes for the same reason), and in lockstep all S
+        # encoders — the launches that fill the whole GPU — collide while the S latency-bound decode chains leave it half idle
+        tw0 = time.perf_counter(); step(); est = time.perf_counter() - tw0      # (one more untimed lockstep step: the stagger unit)
+        barrier()
+        t0 = time.perf_counter()
+
+        def run_stream(i):
+            time.sleep(i * est / S)
+            out_l, r = [], None
+            for _ in range(args.steps):
+                dt, r = step_on(slots[i])
+                out_l.append(dt)
+            return out_l, r
+        res = list(pool.map(run_stream, range(S)))
+        for out_l, _ in res:
+            lat.extend(out_l)
+        last = res[0][1]
         tm = slot.timings()
         for k in stage:
-            stage[k] += tm[k] / args.steps
+            stage[k] = tm[k]
+    else:
+        for _ in range(args.steps):
+            dt, last = step()
+            lat.append(dt)
+            tm = slot.timings()
+            for k in stage:
+                stage[k] += tm[k] / args.steps
     barrier()
     wall = time.perf_counter() - t0
     if dist is not None:
