@@ -987,7 +987,8 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     const bool combo = (p.in_mode == GEMV_IN_LN && (p.out_mode == GEMV_OUT_QKV || p.out_mode == GEMV_OUT_F16 ||
                                                     p.out_mode == GEMV_OUT_GELU_F16 || p.out_mode == GEMV_OUT_F32)) ||
                        (p.in_mode != GEMV_IN_LN && p.out_mode == GEMV_OUT_RESID) ||
-                       (p.in_mode == GEMV_IN_F16 && p.out_mode == GEMV_OUT_SLAB);
+                       (p.in_mode == GEMV_IN_F16 && p.out_mode == GEMV_OUT_SLAB) ||
+                       (p.in_mode == GEMV_IN_F16 && p.xsrc == GEMV_X_PLAIN && (p.out_mode == GEMV_OUT_QKV || p.out_mode == GEMV_OUT_F16 || p.out_mode == GEMV_OUT_GELU_F16));   // rows normalised by dec_ln_rows_kernel
     if (!combo || p.K != p.KT * 32) return c;
     // sources other than the plain rows: one row tile, and only where the kernel is instantiated for them
     if (p.xsrc != GEMV_X_PLAIN) {
@@ -1096,6 +1097,9 @@ static bool gemv2_launch_qkv_xs(const GemvParams& p, const Gemv2Cfg& c, dim3 gri
 template <int CH, int MT>
 static bool gemv2_launch_other(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, dim3 block, hipStream_t s) {
     if (p.in_mode == GEMV_IN_F16) {
+        if (p.out_mode == GEMV_OUT_QKV) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_QKV, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
+        if (p.out_mode == GEMV_OUT_F16) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_F16, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
+        if (p.out_mode == GEMV_OUT_GELU_F16) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_GELU_F16, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
         if (p.out_mode == GEMV_OUT_SLAB) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_SLAB, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
         if (p.xsrc == GEMV_X_SLABS) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, MT, GEMV_X_SLABS>(grid, block, c.shm, s, p); return true; }
         g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p);
@@ -1219,6 +1223,57 @@ const char* dec_gemv_kernel_name(const GemvParams& p_any) {
     }
     snprintf(buf, sizeof(buf), "dec_gemv_kernel<%d, %d, %d>", MT > 4 ? 4 : MT, MT == 1 ? 2 : 1, p.in_mode);
     return buf;
+}
+
+// ------------------------------------------------------------------ LayerNorm of the decoder rows on its own (batched rows, A/B)
+// One wave per row, the arithmetic of the LayerNorm prologues above to the last bit (same lane layout, same summation order): fp16
+// rows for projections that then run as plain fp16-rows-in launches. At 60 rows a LayerNorm-fronted projection spends ~90 % of its
+// instructions re-normalising the rows in every 16-column workgroup (144-192 times per launch); this is the alternative the
+// round-2 / round-3 reviews asked for. WLX_BATCHED_LN=1 selects it (engine.hip decoder_pass); see DESIGN.md §7 for the measurement.
+template <int LNV>
+__global__ __launch_bounds__(256) void dec_ln_rows_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, half_t* __restrict__ out, long ldo, int M WLX_TR_PARAM) {
+    WLX_TR_BEGIN();
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r < M) {
+        const float4* x4 = reinterpret_cast<const float4*>(X + (long)r * ldx) + lane;
+        const float4* g4 = reinterpret_cast<const float4*>(gamma) + lane;
+        const float4* b4 = reinterpret_cast<const float4*>(beta) + lane;
+        float4 x[LNV], gq[LNV], bq[LNV];
+#pragma unroll
+        for (int j = 0; j < LNV; ++j) { x[j] = x4[64 * j]; gq[j] = g4[64 * j]; bq[j] = b4[64 * j]; }
+        constexpr float invK = 1.0f / (256.0f * LNV);
+        float sm = 0.f;
+#pragma unroll
+        for (int j = 0; j < LNV; ++j) sm += (x[j].x + x[j].y) + (x[j].z + x[j].w);
+        const float mean = wave_sum_dpp(sm) * invK;
+        float q = 0.f;
+#pragma unroll
+        for (int j = 0; j < LNV; ++j) {
+            x[j].x -= mean; x[j].y -= mean; x[j].z -= mean; x[j].w -= mean;
+            q += (x[j].x * x[j].x + x[j].y * x[j].y) + (x[j].z * x[j].z + x[j].w * x[j].w);
+        }
+        const float rstd = rsqrtf(wave_sum_dpp(q) * invK + 1e-5f);
+        half_t* dst = out + (long)r * ldo + lane * 4;
+#pragma unroll
+        for (int j = 0; j < LNV; ++j) {
+            const f16x4 hv = {(half_t)(x[j].x * rstd * gq[j].x + bq[j].x), (half_t)(x[j].y * rstd * gq[j].y + bq[j].y),
+                              (half_t)(x[j].z * rstd * gq[j].z + bq[j].z), (half_t)(x[j].w * rstd * gq[j].w + bq[j].w)};
+            *reinterpret_cast<f16x4*>(dst + 256 * j) = hv;
+        }
+    }
+    WLX_TR_END(trc);
+}
+bool dec_ln_rows_ok(int d) { return d % 256 == 0 && d / 256 >= 2 && d / 256 <= 5; }
+void launch_dec_ln_rows(const float* X, long ldx, const float* gamma, const float* beta, half_t* out, long ldo, int M, int d, hipStream_t s) {
+    const dim3 grid((M + 3) / 4), block(256);
+    switch (d / 256) {
+        case 2: hipLaunchKernelGGL((dec_ln_rows_kernel<2>), grid, block, 0, s, X, ldx, gamma, beta, out, ldo, M WLX_TR_ARG("ln_rows")); break;
+        case 3: hipLaunchKernelGGL((dec_ln_rows_kernel<3>), grid, block, 0, s, X, ldx, gamma, beta, out, ldo, M WLX_TR_ARG("ln_rows")); break;
+        case 4: hipLaunchKernelGGL((dec_ln_rows_kernel<4>), grid, block, 0, s, X, ldx, gamma, beta, out, ldo, M WLX_TR_ARG("ln_rows")); break;
+        default: hipLaunchKernelGGL((dec_ln_rows_kernel<5>), grid, block, 0, s, X, ldx, gamma, beta, out, ldo, M WLX_TR_ARG("ln_rows")); break;
+    }
 }
 
 // ------------------------------------------------------------------ vocabulary projection: final LayerNorm + tied output projection

@@ -983,6 +983,18 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
     if (rows > 16 && rows <= 64 && !alt && !ks_batched) KS = 0;
     if (KS && !(dec_gemv_is_lean(qkv_params(0, GEMV_X_SLABS)) && dec_gemv_is_lean(oproj_params(0, GEMV_X_SLABS)))) KS = 0;
     const bool fold_embed = !no_fold && rows <= 64 && dec_gemv_is_lean(qkv_params(0, GEMV_X_EMBED));
+    // (A/B, round 4) batched rows: ONE LayerNorm launch per layer phase writing fp16 rows (into the attention-output rows, which are
+    // free at those three points), the projections behind it as fp16-rows-in launches. WLX_BATCHED_LN=1.
+    static const bool batched_ln_env = [] { const char* v = getenv("WLX_BATCHED_LN"); return v && v[0] == '1'; }();
+    const bool sep_ln = batched_ln_env && rows > 16 && rows <= 64 && !alt && !g_decode_v1 && dec_ln_rows_ok(d);
+    auto ln_to_f16 = [&](GemvParams& q) {       // q: a LayerNorm-fronted projection over the plain rows -> LayerNorm launch + fp16-rows-in projection
+        GemvParams t = q;
+        t.in_mode = GEMV_IN_F16; t.Xh = s.attnd; t.ldxh = d;
+        if (!dec_gemv_is_lean(t)) return false;
+        plaunch(s.base, "dec_ln_rows_kernel", 0.0, [&] { launch_dec_ln_rows(q.X, q.ldx, q.gamma, q.beta, s.attnd, d, rows, d, st); });
+        q = t;
+        return true;
+    };
     if (!fold_embed)
         plaunch(s.base, "dec_embed_kernel", (double)rows * d * (2 + 4), [&] { launch_dec_embed(e->tok_emb16, e->dec_pos, d, rt, rows, s.xd, done, st); });
     bool slabs_pending = false;             // the residual stream is xd + slabs until the next residual update writes the sum back
@@ -991,7 +1003,11 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
         half_t* kc = s->kc + (size_t)l * s->cache_rows * crs;
         half_t* vc = s->vc + (size_t)l * s->cache_rows * crs;
         // LN1 + QKV, K/V appended to the self-attention cache
-        pgemv(s.base, qkv_params(l, (l == 0 && fold_embed) ? GEMV_X_EMBED : (slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN)));
+        {
+            GemvParams pq = qkv_params(l, (l == 0 && fold_embed) ? GEMV_X_EMBED : (slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN));
+            if (sep_ln && pq.xsrc == GEMV_X_PLAIN) (void)ln_to_f16(pq);
+            pgemv(s.base, pq);
+        }
         plaunch(s.base, "dec_self_attn2_kernel", 4.0 * rows * d * (s->prof ? s->prof->t + 1 : 1), [&] { launch_dec_self_attn(s.qd, d, kc, vc, crs, d, H, rt, rows, s.attnd, d, done, s->anc_ident, st); });
         pgemv(s.base, oproj_params(l, slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN));
         slabs_pending = false;
@@ -1013,6 +1029,7 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
             p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_F16; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
             p.Wp = w.Wcq; p.bias = w.bcq; p.X = s.xd; p.ldx = d; p.gamma = w.ln2_g; p.beta = w.ln2_b;
             p.Yh = s.qd; p.ldyh = d; p.qscale = 0.125f; p.done = done;
+            if (sep_ln) (void)ln_to_f16(p);
             pgemv(s.base, p);
             if (s->align) {     // word alignment: raw q.k of this layer's alignment heads for the rows of this chunk
                 const Slot::AlignCapture& a = *s->align;
@@ -1041,6 +1058,7 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
         p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_GELU_F16; p.M = rows; p.K = d; p.KT = d / 32; p.N = F;
         p.Wp = w.W1; p.bias = w.b1; p.X = s.xd; p.ldx = d; p.gamma = w.ln3_g; p.beta = w.ln3_b;
         p.Yh = s.hd; p.ldyh = F; p.qscale = 1.f; p.done = done;
+        if (sep_ln) (void)ln_to_f16(p);
         pgemv(s.base, p);
         p = GemvParams{};
         p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = F; p.KT = F / 32; p.N = d;
