@@ -43,6 +43,7 @@ struct GemvParams {
     int M;                                   // live rows (of one row chunk: <= 48 on the lean kernel)
     int Mtot;                                // (lean kernel) 0, or the rows of the whole pass, walked in row chunks, see dec_gemv2_kernel
     int chunk;                               // (set by the launcher) rows per chunk: 48 (prompt prefill, grid.z) or 16 (batched decode steps)
+    int busy_device;                         // (set by the engine) three or more slots are live on this device: prefer work-saving launch shapes (gemv2_cfg)
     int rt_nz, rt_tiles, rt_magic;           // (set by the launcher) 16-row chunks folded into blockIdx.x: chunks, live n-tile workgroups, 65536 / rt_nz + 1
     int K, KT, N;                            // K real, KT = Kpad/32, N real outputs
     int KTW;                                 // (set by the launcher) k-tiles per wave, even

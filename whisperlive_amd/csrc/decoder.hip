@@ -1042,6 +1042,23 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     // round of workgroups and halve the redundant LayerNorm prologues. WLX_GELU_NTB2=0 keeps one tile (A/B).
     static const bool gelu_ntb2 = [] { const char* e = getenv("WLX_GELU_NTB2"); return !(e && e[0] == '0'); }();
     if (gelu_ntb2 && p.in_mode == GEMV_IN_LN && p.out_mode == GEMV_OUT_GELU_F16 && p.xsrc == GEMV_X_PLAIN && (p.N + 15) / 16 > 256 && ((p.N + 15) / 16) % 2 == 0) c.NTB = 2;
+    // row tiles of a batched step (round 4): every 16-column workgroup of a LayerNorm-fronted projection normalises its 16 rows again —
+    // at 60 rows ~90 % of its instructions. Two column tiles per workgroup halve that redundant work (and the workgroup count) for the
+    // wide projections (>= 128 tiles: QKV, first MLP projection). WLX_RT_NTB2=0 keeps one tile (A/B).
+    static const bool rt_ntb2 = [] { const char* e = getenv("WLX_RT_NTB2"); return !(e && e[0] == '0'); }();
+    if (rt_ntb2 && p.Mtot > 0 && p.rt_nz > 0 && p.in_mode == GEMV_IN_LN && p.xsrc == GEMV_X_PLAIN &&
+        (p.out_mode == GEMV_OUT_GELU_F16 || p.out_mode == GEMV_OUT_QKV) && (p.N + 15) / 16 >= 128 && ((p.N + 15) / 16) % 2 == 0) c.NTB = 2;
+    // ... four where the tile count allows (60 rows, Whisper-small: first projection 6.6 -> 6.1 us, first MLP projection 6.5 -> 5.9 us; the 4 x 12
+    // configuration +1.5 %, profiles/r4r_*). WLX_RT_NTB4=0 keeps two (A/B).
+    static const bool rt_ntb4 = [] { const char* e = getenv("WLX_RT_NTB4"); return !(e && e[0] == '0'); }();
+    if (rt_ntb4 && c.NTB == 2 && p.Mtot > 0 && p.rt_nz > 0 && ((p.N + 15) / 16) % 4 == 0 && p.M <= 16) c.NTB = 4;
+    // The row-tiled fp16-rows-in residual projections stage their 16 rows x K per 16-column workgroup as well. Two column tiles per
+    // workgroup cost a single slot latency (4.7 -> 5.3 us per launch: half as many workgroups for a launch of 192) but save work, and with
+    // three or more slots decoding on the device the GPU is work-bound: 4 x 12 windows +3 % (profiles/r4r_*). The engine
+    // passes that situation in as GemvParams::busy_device. WLX_RT_F16_NTB2=0 / 1 forces it off / on (A/B).
+    static const int rt_f16_ntb2 = [] { const char* e = getenv("WLX_RT_F16_NTB2"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    const bool f16_wide = rt_f16_ntb2 >= 0 ? rt_f16_ntb2 == 1 : p.busy_device != 0;
+    if (f16_wide && p.Mtot > 0 && p.rt_nz > 0 && p.in_mode == GEMV_IN_F16 && p.out_mode == GEMV_OUT_RESID && p.xsrc == GEMV_X_PLAIN && ((p.N + 15) / 16) % 2 == 0) c.NTB = 2;
     c.MT = (p.M + 15) / 16;
     c.shm = sizeof(float) * (size_t)c.nw * c.NTB * c.MT * 256;
     const size_t xs_bytes = (size_t)p.M * (KTf * 32 + 8) * sizeof(half_t);    // fp16 activation rows
@@ -1067,9 +1084,14 @@ template <int CH, int LNV, int MT>
 static bool gemv2_launch_ln(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, dim3 block, hipStream_t s) {
 #define WLX_G2(OUT_, NTB_, XS_) g2_launch<CH, LNV, GEMV_IN_LN, OUT_, NTB_, MT, XS_>(grid, block, c.shm, s, p)
     switch (p.out_mode) {
-        case GEMV_OUT_QKV: WLX_G2(GEMV_OUT_QKV, 1, GEMV_X_PLAIN); return true;
+        case GEMV_OUT_QKV:
+            if (c.NTB == 4 && MT == 1) { g2_launch<CH, LNV, GEMV_IN_LN, GEMV_OUT_QKV, 4, 1, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
+            if (c.NTB == 2) WLX_G2(GEMV_OUT_QKV, 2, GEMV_X_PLAIN);
+            else WLX_G2(GEMV_OUT_QKV, 1, GEMV_X_PLAIN);
+            return true;
         case GEMV_OUT_F16: WLX_G2(GEMV_OUT_F16, 1, GEMV_X_PLAIN); return true;
         case GEMV_OUT_GELU_F16:
+            if (c.NTB == 4 && MT == 1) { g2_launch<CH, LNV, GEMV_IN_LN, GEMV_OUT_GELU_F16, 4, 1, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
             if (c.NTB == 2) WLX_G2(GEMV_OUT_GELU_F16, 2, GEMV_X_PLAIN);
             else WLX_G2(GEMV_OUT_GELU_F16, 1, GEMV_X_PLAIN);
             return true;
@@ -1102,6 +1124,7 @@ static bool gemv2_launch_other(const GemvParams& p, const Gemv2Cfg& c, dim3 grid
         if (p.out_mode == GEMV_OUT_GELU_F16) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_GELU_F16, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
         if (p.out_mode == GEMV_OUT_SLAB) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_SLAB, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
         if (p.xsrc == GEMV_X_SLABS) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, MT, GEMV_X_SLABS>(grid, block, c.shm, s, p); return true; }
+        if (c.NTB == 2 && MT == 1) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 2, 1, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
         g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p);
     } else g2_launch<CH, 1, GEMV_IN_XATTN, GEMV_OUT_RESID, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p);
     return true;

@@ -908,7 +908,14 @@ static inline void plaunch(Slot* s, const char* name, double bytes, F&& f) {
     if (s->prof->only == name) f();
 }
 static double gemv_bytes(const GemvParams& p) { return 2.0 * (double)p.N * (double)p.K + (p.bias ? 4.0 * p.N : 0.0); }
-static void pgemv(Slot* s, const GemvParams& p) {
+// three or more live slots on the slot's device: the GPU is work-bound there and the decode projections pick work-saving
+// launch shapes (GemvParams::busy_device). Evaluated when a step graph is captured / looked up: the variant is part of the graph key.
+static bool device_is_busy(const Slot* s) {
+    return s->device_of >= 0 && s->device_of < 64 && g_slots_live[s->device_of].load(std::memory_order_relaxed) >= 3;
+}
+static void pgemv(Slot* s, const GemvParams& p0) {
+    GemvParams p = p0;
+    p.busy_device = s->busy_variant ? 1 : 0;
     if (!s->prof) { launch_dec_gemv(p, s->stream); return; }
     const std::string nm = dec_gemv_kernel_name(p);
     plaunch(s, nm.c_str(), gemv_bytes(p), [&] { launch_dec_gemv(p, s->stream); });
@@ -1185,7 +1192,8 @@ static void launch_search(Engine* e, Slot* s, int rows, int groups, bool samplin
 }
 
 static int get_step_graph(Engine* e, Slot* s, int rows, int R, int groups, bool sampling, hipGraphExec_t* out) {
-    StepGraphKey key{rows, R, groups * 2 + (sampling ? 1 : 0)};
+    s->busy_variant = device_is_busy(s);
+    StepGraphKey key{rows, R, groups * 4 + (s->busy_variant ? 2 : 0) + (sampling ? 1 : 0)};
     auto it = s->graphs.find(key);
     if (it != s->graphs.end()) { *out = it->second; return WLX_OK; }
     hipGraph_t graph;
@@ -1227,6 +1235,7 @@ static int run_step(Engine* e, Slot* s, int rows, int R, int groups, bool sampli
         CKR(get_step_graph(e, s, rows, R, groups, sampling, &exec));
         CK(hipGraphLaunch(exec, s->stream));
     } else {
+        s->busy_variant = device_is_busy(s);
         decoder_pass(e, s, rows, R, groups, true, true);
         launch_search(e, s, rows, groups, sampling);
         CK(hipGetLastError());
