@@ -1059,6 +1059,8 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     static const int rt_f16_ntb2 = [] { const char* e = getenv("WLX_RT_F16_NTB2"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     const bool f16_wide = rt_f16_ntb2 >= 0 ? rt_f16_ntb2 == 1 : p.busy_device != 0;
     if (f16_wide && p.Mtot > 0 && p.rt_nz > 0 && p.in_mode == GEMV_IN_F16 && p.out_mode == GEMV_OUT_RESID && p.xsrc == GEMV_X_PLAIN && ((p.N + 15) / 16) % 2 == 0) c.NTB = 2;
+    // (measured and dropped, profiles/r4t_*: two tiles for the N = d_model LayerNorm + query projection under a busy device — no change;
+    // four tiles for the residual projections — spills at their 1024-thread launch bound, -17 %)
     c.MT = (p.M + 15) / 16;
     c.shm = sizeof(float) * (size_t)c.nw * c.NTB * c.MT * 256;
     const size_t xs_bytes = (size_t)p.M * (KTf * 32 + 8) * sizeof(half_t);    // fp16 activation rows
@@ -1089,7 +1091,8 @@ static bool gemv2_launch_ln(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, d
             if (c.NTB == 2) WLX_G2(GEMV_OUT_QKV, 2, GEMV_X_PLAIN);
             else WLX_G2(GEMV_OUT_QKV, 1, GEMV_X_PLAIN);
             return true;
-        case GEMV_OUT_F16: WLX_G2(GEMV_OUT_F16, 1, GEMV_X_PLAIN); return true;
+        case GEMV_OUT_F16:
+            WLX_G2(GEMV_OUT_F16, 1, GEMV_X_PLAIN); return true;
         case GEMV_OUT_GELU_F16:
             if (c.NTB == 4 && MT == 1) { g2_launch<CH, LNV, GEMV_IN_LN, GEMV_OUT_GELU_F16, 4, 1, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
             if (c.NTB == 2) WLX_G2(GEMV_OUT_GELU_F16, 2, GEMV_X_PLAIN);
