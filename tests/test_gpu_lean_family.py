@@ -197,3 +197,35 @@ def test_twelve_items_batched_equal_singles(fam):
             os.environ["WLX_PREFILL_ROWS"] = old
     ref = oracle.decode_logits(enc, toks[None])[0].numpy()
     print(name, 60, _check(got, ref, f"{name} logits n=60"))
+
+
+def test_busy_device_launch_shapes_give_identical_results(fam):
+    """With three or more live slots on the device the engine captures a second step graph per slot whose row-tiled residual projections
+    take two 16-column tiles per workgroup (work-saving shapes for a work-bound GPU: engine.hip device_is_busy, decoder.hip gemv2_cfg). The
+    tile grouping does not touch any summation order: an 8-item batched beam-5 decode must give the SAME tokens and bit-identical scores
+    with and without the extra live slots."""
+    name, spec, eng, oracle, slot, enc = fam
+    ids = H.token_ids_for(spec.vocab)
+    kw = dict(beam_size=5, max_length=1 + 8, suppress_tokens=H.default_suppress(ids))
+    clips = [olm.speech_like_pcm(2.0 + 0.3 * i, seed=220 + i) for i in range(8)]
+    sb = eng.create_slot(8, 5)                 # live slots: the fixture's + this one = 2 -> lone-slot shapes
+    extra = []
+    try:
+        Ts = [sb.logmel(c, item=i) for i, c in enumerate(clips)]
+        sb.encode(8, seek=[0] * 8, seg=[t - 1 for t in Ts])
+        lone = sb.generate([[ids.sot]] * 8, H.engine_ids(ids), **kw)
+        extra = [eng.create_slot(1, 5) for _ in range(2)]          # 4 live slots: the busy-device variant from the next call on
+        busy = sb.generate([[ids.sot]] * 8, H.engine_ids(ids), **kw)
+        names = [k["name"] for k in sb.debug_profile_step(40, 4, 2)]
+        for i in range(8):
+            assert busy[i].sequences_ids == lone[i].sequences_ids, (name, i)
+            assert busy[i].scores[0] == lone[i].scores[0], (name, i, busy[i].scores[0], lone[i].scores[0])
+        # the profile of a 40-row step taken now lists a two-tile fp16-rows-in residual projection (template arguments ..., IN 1, OUT 3, NTB 2, MT 1, XS 0)
+        assert any(n.startswith("dec_gemv2_kernel<") and n.endswith(", 1, 3, 2, 1, 0>") for n in names), names
+    finally:
+        for x in extra:
+            x.close()
+        sb.close()
+    # restore the fixture's encoder state (item 0 of the shared slot)
+    pcm = olm.speech_like_pcm(5.0, seed=21)
+    T = slot.logmel(pcm); slot.encode(1, seek=[0], seg=[T - 1])

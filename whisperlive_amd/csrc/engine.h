@@ -49,6 +49,8 @@ struct Slot {
     bool counted = false;               // in the per-device live-slot count
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_poll0 = nullptr, ev_poll1 = nullptr;
     hipEvent_t ev_lm0 = nullptr, ev_lm1 = nullptr;   // the last log-mel launch (its time is read lazily: wlx_logmel_resident does not wait)
+    hipEvent_t ev_en0 = nullptr, ev_en1 = nullptr;   // the last encoder pass (wlx_encode does not wait either)
+    bool en_pending = false;
     bool lm_pending = false;
     bool busy_variant = false;          // the decode launches of this slot use the work-saving shapes (three or more live slots on the device; engine.hip device_is_busy)
     std::vector<void*> allocs;

@@ -402,6 +402,8 @@ static void slot_free(Slot* s) {
     if (s->ev_poll1) (void)hipEventDestroy(s->ev_poll1);
     if (s->ev_lm0) (void)hipEventDestroy(s->ev_lm0);
     if (s->ev_lm1) (void)hipEventDestroy(s->ev_lm1);
+    if (s->ev_en0) (void)hipEventDestroy(s->ev_en0);
+    if (s->ev_en1) (void)hipEventDestroy(s->ev_en1);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -582,6 +584,7 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         CK(hipEventCreateWithFlags(&s->ev_poll0, hipEventDisableTiming));
         CK(hipEventCreateWithFlags(&s->ev_poll1, hipEventDisableTiming));
         CK(hipEventCreate(&s->ev_lm0)); CK(hipEventCreate(&s->ev_lm1));
+        CK(hipEventCreate(&s->ev_en0)); CK(hipEventCreate(&s->ev_en1));
         CKR(slot_grow_audio(e, s, 480000));
         CKR(dalloc(s->allocs, &s->gmax, (size_t)B));
         s->featT_stride = (long)(WLX_N_FRAMES + 2) * sp.n_mels + 64;
@@ -719,6 +722,12 @@ extern "C" int32_t wlx_timings_get(wlx_engine* e, int32_t slot, wlx_timings* out
     CKR(slot_acquire(e, slot, sg_));
     Slot* s = sg_.s;
     if (!out) return fail(WLX_ERR_ARG, "null out");
+    if (s->en_pending) {                      // the last encoder pass
+        CK(hipSetDevice(e->device));
+        CK(hipEventSynchronize(s->ev_en1));
+        CK(hipEventElapsedTime(&s->tm.encode_ms, s->ev_en0, s->ev_en1));
+        s->en_pending = false;
+    }
     if (s->lm_pending) {                      // the last log-mel launch: waited for here, not in wlx_logmel_resident
         CK(hipSetDevice(e->device));
         CK(hipEventSynchronize(s->ev_lm1));
@@ -822,7 +831,7 @@ extern "C" int32_t wlx_encode(wlx_engine* e, int32_t slot, int32_t batch, const 
     const int d = sp.d_model, F = sp.ffn, nm = sp.n_mels, H = e->H, T = WLX_T_AUDIO;
     CK(hipSetDevice(e->device));
     hipStream_t st = s->stream;
-    CK(hipEventRecord(s->ev0, st));
+    CK(hipEventRecord(s->ev_en0, st));
     for (int b = 0; b < batch; ++b) {
         const int sk = seek ? seek[b] : 0;
         int sg = seg ? seg[b] : (s->nframes[b] - sk);
@@ -878,9 +887,11 @@ extern "C" int32_t wlx_encode(wlx_engine* e, int32_t slot, int32_t batch, const 
     g.kv_layer_stride_k = (long)s->B * WLX_T_AUDIO_PAD * d; g.kv_layer_stride_v = (long)s->B * d * WLX_T_AUDIO_PAD;
     launch_gemm(g, 1, st);
     CK(hipGetLastError());
-    CK(hipEventRecord(s->ev1, st));
-    CK(hipStreamSynchronize(st));
-    CK(hipEventElapsedTime(&s->tm.encode_ms, s->ev0, s->ev1));
+    CK(hipEventRecord(s->ev_en1, st));
+    // No host wait (round 4): everything that consumes the encoder output is ordered on the slot's stream, and the time is read lazily
+    // by wlx_timings_get. The caller's next call — wlx_generate's host-side set-up, ~0.3 ms of staging and copies — now overlaps the
+    // encoder on the GPU instead of following it.
+    s->en_pending = true;
     s->enc_batch = batch;
     return WLX_OK;
 }
@@ -1798,6 +1809,7 @@ extern "C" int32_t wlx_debug_time_decode_step(wlx_engine* e, int32_t slot, int32
         return fail(WLX_ERR_ARG, "bad arguments");
     if (rows > 16 && (rows % s->R != 0 || rows / s->R > s->B)) return fail(WLX_ERR_ARG, "more than 16 rows: a multiple of the slot's rows per item");
     if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "decode before encode");
+    s->busy_variant = device_is_busy(s);     // (the launch shapes a step captured now would use)
     CK(hipSetDevice(e->device));
     hipStream_t st = s->stream;
     // one item, `rows` beams all at position t with identity history (timing only: cache content is whatever is there);
@@ -1905,6 +1917,7 @@ extern "C" int32_t wlx_debug_profile_step(wlx_engine* e, int32_t slot, int32_t r
         return fail(WLX_ERR_ARG, "bad arguments");
     if (rows > 16 && (rows % s->R != 0 || rows / s->R > s->B)) return fail(WLX_ERR_ARG, "more than 16 rows: a multiple of the slot's rows per item");
     if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "decode before encode");
+    s->busy_variant = device_is_busy(s);     // (the launch shapes a step captured now would use)
     CK(hipSetDevice(e->device));
     hipStream_t st = s->stream;
     // up to 16 rows: one item with `rows` beams; more: rows / R items of R beams each, as a batched decode has them
