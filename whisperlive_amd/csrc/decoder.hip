@@ -1058,7 +1058,7 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     // passes that situation in as GemvParams::busy_device. WLX_RT_F16_NTB2=0 / 1 forces it off / on (A/B).
     static const int rt_f16_ntb2 = [] { const char* e = getenv("WLX_RT_F16_NTB2"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     const bool f16_wide = rt_f16_ntb2 >= 0 ? rt_f16_ntb2 == 1 : p.busy_device != 0;
-    if (f16_wide && p.Mtot > 0 && p.rt_nz > 0 && p.in_mode == GEMV_IN_F16 && p.out_mode == GEMV_OUT_RESID && p.xsrc == GEMV_X_PLAIN && ((p.N + 15) / 16) % 2 == 0) c.NTB = 2;
+    if (f16_wide && p.Mtot > 0 && p.rt_nz > 0 && p.M <= 16 && p.in_mode == GEMV_IN_F16 && p.out_mode == GEMV_OUT_RESID && p.xsrc == GEMV_X_PLAIN && ((p.N + 15) / 16) % 2 == 0) c.NTB = 2;   // (one row tile per chunk: the only two-tile instantiation)
     // (measured and dropped, profiles/r4t_*: two tiles for the N = d_model LayerNorm + query projection under a busy device — no change;
     // four tiles for the residual projections — spills at their 1024-thread launch bound, -17 %)
     c.MT = (p.M + 15) / 16;
