@@ -82,6 +82,38 @@ def test_logmel_silence_and_128(micro128):
         slot.close()
 
 
+def test_logmel_ragged_items_one_launch(tiny):
+    """The log-mel requests of a slot's items are recorded and launched together in front of the first consumer (engine.hip
+    flush_logmel): ragged lengths in one launch (blockIdx.y = item, short items' surplus tiles exit), an audio-buffer growth in the
+    middle of the recorded batch, a pending item whose PCM is replaced, and 18 items (> the 16-entry launch table) — each item against
+    the oracle AND bit-identical to the same clip computed alone."""
+    spec, eng, _ = tiny
+    lens = [480000, 41, 17777, 176000, 16000, 200, 300000, 479999, 8000, 160, 161, 4000, 99999, 250000, 31999, 32000, 32001, 123456]
+    clips = [(_pcm(n, 100 + i) if n > 400 else np.random.default_rng(n).standard_normal(n).astype(np.float32) * 0.1) for i, n in enumerate(lens)]
+    one = eng.create_slot(1, 5)
+    slot = eng.create_slot(len(lens), 1)
+    try:
+        alone = []
+        for c in clips:
+            one.logmel(c)
+            alone.append(one.features().copy())
+        order = sorted(range(len(lens)), key=lambda i: lens[i])       # shortest first: the audio buffers grow while requests are recorded
+        for i in order:
+            assert slot.logmel(clips[i], item=i) == (lens[i] + 160) // 160
+        slot.logmel(clips[3], item=2)                                  # item 2 is pending: its PCM is replaced, then requested again
+        for i in range(len(lens)):
+            want = alone[3] if i == 2 else alone[i]
+            got = slot.features(i)
+            assert got.shape == want.shape
+            assert np.array_equal(got, want), ("item", i, H.err_stats(got, want))
+            ref = olm.log_mel_spectrogram(clips[3] if i == 2 else clips[i], spec.n_mels)
+            st = H.err_stats(got, ref)
+            assert st["max_abs"] <= 2e-4, (i, st)
+    finally:
+        slot.close()
+        one.close()
+
+
 def _check_close(got, ref, what):
     st = H.err_stats(got, ref)
     ok = st["rel_rms"] <= 2e-2 and st["max_abs"] <= 6e-2 * st["ref_rms"] + 2e-2 and np.isfinite(got).all()

@@ -52,6 +52,7 @@ struct Slot {
     hipEvent_t ev_en0 = nullptr, ev_en1 = nullptr;   // the last encoder pass (wlx_encode does not wait either)
     bool en_pending = false;
     bool lm_pending = false;
+    std::vector<int> lm_items;          // items whose log-mel was requested and not launched yet (engine.hip flush_logmel)
     bool busy_variant = false;          // the decode launches of this slot use the work-saving shapes (three or more live slots on the device; engine.hip device_is_busy)
     std::vector<void*> allocs;
     // features

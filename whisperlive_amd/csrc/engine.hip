@@ -708,11 +708,37 @@ extern "C" int32_t wlx_slot_destroy(wlx_engine* e, int32_t slot) {
     return WLX_OK;
 }
 
+// Log-mel requests are collected and launched together (round 4): wlx_logmel_resident only records the item; the launches — ONE set of
+// three kernels for all recorded items — go out in front of the first consumer of the features (wlx_encode, wlx_features_get), of a
+// timing read, or of anything that overwrites what a recorded item depends on (its PCM, the audio buffers).
+static int flush_logmel(Engine* e, Slot* s) {
+    if (s->lm_items.empty()) return WLX_OK;
+    CK(hipSetDevice(e->device));
+    CK(hipEventRecord(s->ev_lm0, s->stream));
+    for (size_t i0 = 0; i0 < s->lm_items.size(); i0 += WLX_LM_MAXB) {
+        LogmelBatch lb{};
+        for (size_t i = i0; i < s->lm_items.size() && i < i0 + WLX_LM_MAXB; ++i) {
+            const int item = s->lm_items[i], k = lb.n_items++;
+            const int64_t n = s->npcm[item];
+            lb.pcm[k] = s->pcm + (size_t)item * s->pcm_cap; lb.n[k] = (long)n;
+            lb.feats[k] = s->feats + (size_t)item * e->spec.n_mels * s->feat_ld; lb.T[k] = (int)((n + 160) / 160);
+            lb.gmax[k] = s->gmax + item;
+        }
+        launch_logmel_batch(lb, e->spec.n_mels, e->lm, s->feat_ld, s->stream);
+    }
+    s->lm_items.clear();
+    CK(hipGetLastError());
+    CK(hipEventRecord(s->ev_lm1, s->stream));
+    s->lm_pending = true;
+    return WLX_OK;
+}
+
 extern "C" int32_t wlx_sync(wlx_engine* e, int32_t slot) {
     SlotGuard sg_;
     CKR(slot_acquire(e, slot, sg_));
     Slot* s = sg_.s;
     CK(hipSetDevice(e->device));
+    CKR(flush_logmel(e, s));
     CK(hipStreamSynchronize(s->stream));
     return WLX_OK;
 }
@@ -722,6 +748,7 @@ extern "C" int32_t wlx_timings_get(wlx_engine* e, int32_t slot, wlx_timings* out
     CKR(slot_acquire(e, slot, sg_));
     Slot* s = sg_.s;
     if (!out) return fail(WLX_ERR_ARG, "null out");
+    CKR(flush_logmel(e, s));
     if (s->en_pending) {                      // the last encoder pass
         CK(hipSetDevice(e->device));
         CK(hipEventSynchronize(s->ev_en1));
@@ -748,6 +775,8 @@ extern "C" int32_t wlx_pcm_put(wlx_engine* e, int32_t slot, int32_t item, const 
     if (item < 0 || item >= s->B) return fail(WLX_ERR_ARG, "bad item %d", item);
     if (n > 16000LL * 3600) return fail(WLX_ERR_ARG, "audio chunk too long");
     CK(hipSetDevice(e->device));
+    if ((size_t)n > s->pcm_cap || std::find(s->lm_items.begin(), s->lm_items.end(), (int)item) != s->lm_items.end())
+        CKR(flush_logmel(e, s));            // a recorded log-mel request reads this item's PCM (or the buffers are about to be re-allocated)
     CKR(slot_grow_audio(e, s, (size_t)n));
     float* dp = s->pcm + (size_t)item * s->pcm_cap;
     CK(hipMemcpyAsync(dp, pcm, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s->stream));
@@ -767,14 +796,11 @@ extern "C" int32_t wlx_logmel_resident(wlx_engine* e, int32_t slot, int32_t item
     const int T = (int)((n + 160) / 160);
     float* dp = s->pcm + (size_t)item * s->pcm_cap;
     float* df = s->feats + (size_t)item * e->spec.n_mels * s->feat_ld;
-    // No host wait (round 4): the frame count is a function of the sample count, everything downstream (features_get, encode) is
-    // ordered on the slot's stream, and the launch's time is read lazily by wlx_timings_get. A batch of 12 windows used to pay 12
-    // launch -> wait round trips (~100 us each) in front of its encoder.
-    CK(hipEventRecord(s->ev_lm0, s->stream));
-    launch_logmel(dp, (long)n, e->spec.n_mels, e->lm, df, s->feat_ld, T, s->gmax + item, s->stream);
-    CK(hipGetLastError());
-    CK(hipEventRecord(s->ev_lm1, s->stream));
-    s->lm_pending = true;
+    // No launch and no host wait here (round 4): the frame count is a function of the sample count; the request is recorded and goes out
+    // together with the other items' (flush_logmel) in front of the first consumer. A batch of 12 windows used to be 36 launches and 12
+    // launch -> wait round trips in front of its encoder; the launch's time is read lazily by wlx_timings_get.
+    (void)dp; (void)df;
+    if (std::find(s->lm_items.begin(), s->lm_items.end(), (int)item) == s->lm_items.end()) s->lm_items.push_back(item);
     s->nframes[item] = T;
     if (n_frames_out) *n_frames_out = T;
     return WLX_OK;
@@ -795,6 +821,7 @@ extern "C" int32_t wlx_features_get(wlx_engine* e, int32_t slot, int32_t item, f
     const int T = s->nframes[item], nm = e->spec.n_mels;
     if (n_frames_out) *n_frames_out = T;
     if (!out) return WLX_OK;
+    CKR(flush_logmel(e, s));
     if ((int64_t)T * nm > cap_floats) return fail(WLX_ERR_ARG, "output buffer too small");
     CK(hipSetDevice(e->device));
     const float* df = s->feats + (size_t)item * nm * s->feat_ld;
@@ -811,6 +838,7 @@ extern "C" int32_t wlx_features_set(wlx_engine* e, int32_t slot, int32_t item, c
     if (item < 0 || item >= s->B || !feats) return fail(WLX_ERR_ARG, "bad item / null");
     if (n_mels != e->spec.n_mels || n_frames < 1) return fail(WLX_ERR_ARG, "features must be [%d, T>=1]", e->spec.n_mels);
     CK(hipSetDevice(e->device));
+    CKR(flush_logmel(e, s));                // (a recorded request for this item must not overwrite the features set here)
     CKR(slot_grow_audio(e, s, (size_t)n_frames * 160));
     float* df = s->feats + (size_t)item * n_mels * s->feat_ld;
     CK(hipMemcpy2DAsync(df, (size_t)s->feat_ld * 4, feats, (size_t)n_frames * 4, (size_t)n_frames * 4, n_mels,
@@ -831,6 +859,7 @@ extern "C" int32_t wlx_encode(wlx_engine* e, int32_t slot, int32_t batch, const 
     const int d = sp.d_model, F = sp.ffn, nm = sp.n_mels, H = e->H, T = WLX_T_AUDIO;
     CK(hipSetDevice(e->device));
     hipStream_t st = s->stream;
+    CKR(flush_logmel(e, s));                // the recorded log-mel requests of the batch: one launch of each kernel
     CK(hipEventRecord(s->ev_en0, st));
     for (int b = 0; b < batch; ++b) {
         const int sk = seek ? seek[b] : 0;
@@ -1000,7 +1029,11 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
     static const bool ks_batched = [] { const char* v = getenv("WLX_FC2_KS_BATCHED"); return v && v[0] == '1'; }();
     if (rows > 16 && rows <= 64 && !alt && !ks_batched) KS = 0;
     if (KS && !(dec_gemv_is_lean(qkv_params(0, GEMV_X_SLABS)) && dec_gemv_is_lean(oproj_params(0, GEMV_X_SLABS)))) KS = 0;
-    const bool fold_embed = !no_fold && rows <= 64 && dec_gemv_is_lean(qkv_params(0, GEMV_X_EMBED));
+    // (batched steps, 17..64 rows: the folded form gathers ONE row per wave and trip — two trips per 16-row tile, the second behind the
+    // weight stream — and has no four-tile instantiation: 13.6 us at 60 rows against 2.4 + 5.9 us for the embedding launch + the plain
+    // four-tile projection, profiles/r4s_decode_step.txt. WLX_EMBED_FOLD_BATCHED=1 folds there too (A/B).)
+    static const bool fold_batched = [] { const char* v = getenv("WLX_EMBED_FOLD_BATCHED"); return v && v[0] == '1'; }();
+    const bool fold_embed = !no_fold && rows <= 64 && (rows <= 16 || alt != nullptr || fold_batched) && dec_gemv_is_lean(qkv_params(0, GEMV_X_EMBED));
     // (A/B, round 4) batched rows: ONE LayerNorm launch per layer phase writing fp16 rows (into the attention-output rows, which are
     // free at those three points), the projections behind it as fp16-rows-in launches. WLX_BATCHED_LN=1.
     static const bool batched_ln_env = [] { const char* v = getenv("WLX_BATCHED_LN"); return v && v[0] == '1'; }();

@@ -20,6 +20,13 @@ struct LogmelConsts {          // device pointers, built once per engine
     const float* filters;      // [n_mels][201] Slaney mel filterbank
     const int*   frange;       // [n_mels][2] first/last+1 non-zero bin
 };
+// up to WLX_LM_MAXB items per launch (blockIdx.y = item): per item the PCM, its length, the feature matrix, T = (n+160)/160 and a uint scratch
+#define WLX_LM_MAXB 16
+struct LogmelBatch {
+    int n_items;
+    const float* pcm[WLX_LM_MAXB]; long n[WLX_LM_MAXB]; float* feats[WLX_LM_MAXB]; int T[WLX_LM_MAXB]; unsigned* gmax[WLX_LM_MAXB];
+};
+void launch_logmel_batch(const LogmelBatch& lb, int n_mels, const LogmelConsts& c, long ld, hipStream_t s);
 // pcm [n] f32 device -> feats [n_mels][ld] f32 device (T = (n+160)/160 columns valid); gmax: 1 uint scratch
 void launch_logmel(const float* pcm, long n, int n_mels, const LogmelConsts& c, float* feats, long ld,
                    int T, unsigned* gmax, hipStream_t s);
