@@ -861,15 +861,16 @@ extern "C" int32_t wlx_encode(wlx_engine* e, int32_t slot, int32_t batch, const 
     hipStream_t st = s->stream;
     CKR(flush_logmel(e, s));                // the recorded log-mel requests of the batch: one launch of each kernel
     CK(hipEventRecord(s->ev_en0, st));
+    PrepWindows pw{};                       // the windows of the batch: one launch (blockIdx.y = item)
     for (int b = 0; b < batch; ++b) {
         const int sk = seek ? seek[b] : 0;
         int sg = seg ? seg[b] : (s->nframes[b] - sk);
         if (sk < 0 || sg < 0 || sk + sg > s->nframes[b])
             return fail(WLX_ERR_ARG, "item %d: window [%d,%d) outside %d feature frames", b, sk, sk + sg, s->nframes[b]);
         if (sg > WLX_N_FRAMES) sg = WLX_N_FRAMES;
-        launch_prep_window(s->feats + (size_t)b * nm * s->feat_ld, s->feat_ld, nm, sk, sg,
-                           s->featT + (size_t)b * s->featT_stride, st);
+        pw.seek[b] = sk; pw.seg[b] = sg;
     }
+    launch_prep_windows(s->feats, s->feat_ld, nm, (long)nm * s->feat_ld, pw, batch, s->featT, (long)s->featT_stride, st);
     GemmParams g{};
     // conv1 (k=3, s=1, p=1) + GELU: K-row of frame t = featT rows t..t+2 (row 0 / 3001 are the zero pad)
     g.A = s->featT; g.lda = nm; g.strideA = s->featT_stride; g.Wp = e->conv1_w; g.KT = e->conv1_KT;

@@ -770,6 +770,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
 static bool gemm3_ok(const GemmParams& p, int zbatch) {
     static const int mode = [] { const char* e = getenv("WLX_GEMM3"); return e ? atoi(e) : 1; }();   // 0 = off (A/B), 2 = any M
     if (mode == 0 || zbatch != 1 || (p.N & 255) || (p.KT & 3) || p.KT < 8) return false;
+    static const bool resid_off = [] { const char* e = getenv("WLX_GEMM3_RESID"); return e && e[0] == '0'; }();   // (A/B) residual GEMMs (N = d_model) on the second form
+    if (resid_off && p.mode == GEMM_RESID_F32) return false;
     if ((long)p.M * p.lda * 2 >= (1L << 31) || (long)p.N * p.KT * 64 >= (1L << 31)) return false;   // 32-bit buffer offsets
     // measured (profiles/r4k_encode_shape_times.txt, Whisper-small): 2 windows (M = 3000) 2.77 ms here vs 2.60 on the 64 x 96 tile, 3 windows
     // (M = 4500) 3.10 vs 3.64, 12 windows 7.75 vs 11.8
@@ -788,7 +790,9 @@ static void gemm3_go(const GemmParams& p0, hipStream_t s) {
     // one workgroup per CU (the kernel holds 128 KiB of LDS and 256 registers); fewer when there are fewer tiles. A multiple of 8:
     // workgroup id % 8 is the XCD
     static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount; return n; }();
-    const int nwg = std::min((n_cu / 8) * 8, ((p.g3_tiles + 7) / 8) * 8);   // (workgroups past the end of their XCD's run leave at once)
+    static const int cu_cap = [] { const char* e = getenv("WLX_GEMM3_CUS"); return e ? atoi(e) : 0; }();   // (A/B) leave CUs to other streams: this kernel fills a CU alone
+    const int cus = (cu_cap >= 8 && cu_cap < n_cu) ? cu_cap : n_cu;
+    const int nwg = std::min((cus / 8) * 8, ((p.g3_tiles + 7) / 8) * 8);   // (workgroups past the end of their XCD's run leave at once)
     hipLaunchKernelGGL(gemm3_kernel, dim3(nwg), dim3(512), G3_LDS_BYTES, s, p);
 }
 
@@ -850,7 +854,9 @@ static int gemm2_pick(const GemmParams& p, int zbatch) {
     static const int forced = [] { const char* e = getenv("WLX_GEMM2_SHAPE"); return e ? atoi(e) : -1; }();
     const int n_shapes = (int)(sizeof(kGemm2Shapes) / sizeof(kGemm2Shapes[0]));
     if (forced >= 0 && forced < n_shapes) return forced;
-    (void)p; (void)zbatch;
+    static const int large = [] { const char* e = getenv("WLX_GEMM2_LARGE_SHAPE"); return e ? atoi(e) : 3; }();   // (A/B) shape for M >= 4000 launches that do not take the third form
+    (void)zbatch;
+    if (p.M >= 4000 && large >= 0 && large < n_shapes) return large;
     return 3;
 }
 int gemm_prepare_device() {      // once per engine, on the engine's device (wlx_engine_create)

@@ -31,7 +31,9 @@ void launch_logmel_batch(const LogmelBatch& lb, int n_mels, const LogmelConsts& 
 void launch_logmel(const float* pcm, long n, int n_mels, const LogmelConsts& c, float* feats, long ld,
                    int T, unsigned* gmax, hipStream_t s);
 // feats window [seek, seek+seg) -> time-major fp16 featT rows 1..3000 (row stride n_mels), zero beyond seg
-void launch_prep_window(const float* feats, long ld, int n_mels, int seek, int seg, half_t* featT, hipStream_t s);
+struct PrepWindows { int seek[64]; int seg[64]; };     // per item of a slot (wlx_slot_create: max_batch <= 64)
+void launch_prep_windows(const float* feats0, long ld, int n_mels, long item_stride, const PrepWindows& w, int items,
+                         half_t* featT0, long featT_stride, hipStream_t s);
 
 // ---------------------------------------------------------------- gemm.hip
 enum GemmMode : int {
