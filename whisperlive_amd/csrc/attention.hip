@@ -328,20 +328,38 @@ __global__ __launch_bounds__(64) void attn_encoder_pf_kernel(const half_t* __res
 // pieces (the second form needed two 8-byte loads per fragment, which LDS-DMA cannot express).
 typedef __attribute__((address_space(3))) void wlx_lds_void_a;
 
+// XCD-aware workgroup -> (query block, head, item) map of the LDS forms (round 4). Workgroup ids are dealt round-robin over the 8 XCDs, each
+// with its own 4 MiB L2; with the query block as the fastest grid index the 24 workgroups that share one (head, item)'s K / V (384 KiB) were
+// spread over all eight L2s, and at 12 windows every L2 saw the K / V of all ~32 (head, item) pairs in flight: 26 % of the L2 requests missed
+// (TCC counters, profiles/r4g_*: 520 MB per launch from beyond L2 for 55 MB of K / V). Here XCD x owns the contiguous range
+// [x * chunk, (x + 1) * chunk) of the (pair, query block) list — its workgroups, dispatched in order, share ~4 pairs (1.5 MiB) at a time.
+struct AttnMap { int nq, H, total, chunk; };               // query blocks per pair; heads; pairs * nq; ceil(total / 8), or 0 = plain order
+__device__ __forceinline__ bool attn_map(const AttnMap& am, int& qb, int& h, int& item) {
+    const int L = (int)blockIdx.x;
+    const int G = am.chunk > 0 ? (L & 7) * am.chunk + (L >> 3) : L;
+    if (G >= am.total || (am.chunk > 0 && (L >> 3) >= am.chunk)) return false;
+    const int pair = G / am.nq;
+    qb = G - pair * am.nq;
+    item = pair / am.H;
+    h = pair - item * am.H;
+    return true;
+}
+
 template <int DEPTH, int NW>
 __global__ __launch_bounds__(NW * 64) void attn_encoder_lds_kernel(const half_t* __restrict__ Q, long ldq,
                                                                const half_t* __restrict__ K, long ldk,
                                                                const half_t* __restrict__ Vt, long ldvt,
                                                                half_t* __restrict__ O, long ldo, int T,
-                                                               long isq, long isk, long isv, long iso) {
+                                                               long isq, long isk, long isv, long iso, AttnMap am) {
     constexpr int NL = 8 / NW;                              // LDS-DMA pieces (vmcnt events) per wave per tile
     static_assert((NW == 4 || NW == 8) && DEPTH >= 3 && NL * (DEPTH - 2) <= 63, "8 pieces per tile over 4 or 8 waves; vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) f16x8 aring[];      // [DEPTH][8 fragments][64 lanes] x 16 B — the ONLY LDS object
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, g = lane >> 4;
-    const int h = blockIdx.y, item = blockIdx.z;
-    const int q0 = blockIdx.x * (NW * 16) + wave * 16;
+    int qb, h, item;
+    if (!attn_map(am, qb, h, item)) return;                 // (whole workgroup, before any barrier)
+    const int q0 = qb * (NW * 16) + wave * 16;
     Q += (long)item * isq + h * WLX_HEAD_DIM;
     K += (long)item * isk + h * WLX_HEAD_DIM;
     Vt += (long)item * isv + (long)h * WLX_HEAD_DIM * ldvt;
@@ -480,6 +498,177 @@ __global__ __launch_bounds__(NW * 64) void attn_encoder_lds_kernel(const half_t*
     }
 }
 
+// Fourth form (round 4): the third form's ring, SOFTWARE-PIPELINED inside the wave. The third form's tile is one dependent chain per wave —
+// barrier -> 8 LDS reads -> 4 score MFMAs -> softmax (~55 VALU + 9 quarter-rate exponentials) -> 4 output MFMAs — and with ~1 wave per SIMD
+// resident (SQ counters at 12 windows, profiles/r4g_pmc_sq_encoder_b12.csv: waves issue in 24 % of their cycles and sit at waits in 51 %) nothing
+// fills the LDS and MFMA latencies: 740 cycles per 16-query x 32-key tile against ~330 cycles of VALU issue. Here a wave keeps TWO tiles in
+// flight: iteration ti requests tile ti+1's K / V fragments from LDS, runs tile ti's softmax on the scores computed one iteration earlier
+// (the LDS latency passes under it), then issues tile ti+1's score MFMAs and tile ti's output MFMAs back to back — they execute under the next
+// iteration's barrier, LDS requests and the first softmax instructions. Same instructions per tile, same operand order: results are
+// bit-identical to the third form's. Two register sets (scores 8, V fragments 16) alternate, the loop is unrolled by two.
+template <int DEPTH, int NW>
+__global__ __launch_bounds__(NW * 64) void attn_encoder_lds2_kernel(const half_t* __restrict__ Q, long ldq,
+                                                                const half_t* __restrict__ K, long ldk,
+                                                                const half_t* __restrict__ Vt, long ldvt,
+                                                                half_t* __restrict__ O, long ldo, int T,
+                                                                long isq, long isk, long isv, long iso, AttnMap am) {
+    constexpr int NL = 8 / NW;
+    static_assert((NW == 4 || NW == 8) && DEPTH >= 3 && NL * (DEPTH - 2) <= 63, "8 pieces per tile over 4 or 8 waves; vmcnt is a 6-bit counter");
+    extern __shared__ __attribute__((aligned(16))) f16x8 aring[];      // [DEPTH][8 fragments][64 lanes] x 16 B + the query area
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, g = lane >> 4;
+    int qb, h, item;
+    if (!attn_map(am, qb, h, item)) return;                 // (whole workgroup, before any barrier)
+    const int q0 = qb * (NW * 16) + wave * 16;
+    Q += (long)item * isq + h * WLX_HEAD_DIM;
+    K += (long)item * isk + h * WLX_HEAD_DIM;
+    Vt += (long)item * isv + (long)h * WLX_HEAD_DIM * ldvt;
+    O += (long)item * iso + h * WLX_HEAD_DIM;
+    const int NT = (T + 31) >> 5;
+    const int f0 = NL * wave;
+    const bool frag_is_k = f0 < 4;
+    const half_t* src0;
+    long step_h, frag_step;
+    const int ks = (f0 >> 1) & 1, kkt = f0 & 1;
+    if (frag_is_k) {
+        const int krow = (c >> 2) * 8 + ks * 4 + (c & 3);
+        src0 = K + (long)krow * ldk + kkt * 32 + g * 8;
+        step_h = 32 * ldk; frag_step = 32;
+    } else {
+        const int dt = f0 - 4;
+        src0 = Vt + (long)(dt * 16 + c) * ldvt + g * 8;
+        step_h = 32; frag_step = 16 * ldvt;
+    }
+    const long kclamp = (long)(T - 1) * ldk;
+    auto issue = [&](int ti, int buf) {
+        f16x8* dst = aring + ((long)buf * 8 + f0) * 64;
+        const half_t* a0 = src0 + (long)ti * step_h;
+        if (frag_is_k) {
+            const long row = (long)ti * 32 + (c >> 2) * 8 + ks * 4 + (c & 3);
+            if (row >= T) a0 = K + kclamp + kkt * 32 + g * 8;
+        }
+        __builtin_amdgcn_global_load_lds((const void*)a0, (wlx_lds_void_a*)dst, 16, 0, 0);
+        if constexpr (NL == 2) __builtin_amdgcn_global_load_lds((const void*)(a0 + frag_step), (wlx_lds_void_a*)(dst + 64), 16, 0, 0);
+    };
+    f16x8* qarea = aring + (long)DEPTH * 8 * 64 + wave * 2 * 64;
+    {
+        int row = q0 + c;
+        if (row >= T) row = T - 1;
+        const half_t* qsrc = Q + (long)row * ldq + g * 8;
+        __builtin_amdgcn_global_load_lds((const void*)qsrc, (wlx_lds_void_a*)qarea, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((const void*)(qsrc + 32), (wlx_lds_void_a*)(qarea + 64), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < DEPTH - 1; ++i)
+        if (i < NT) issue(i, i);
+    __builtin_amdgcn_s_waitcnt(((NL * (DEPTH - 1)) & 15) | (((NL * (DEPTH - 1)) >> 4) << 14) | 0x0F70);
+    f16x8 qf[2];
+    qf[0] = qarea[lane];
+    qf[1] = qarea[64 + lane];
+    f32x4 acc[4];
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrun = WLX_NEG_INF, lrun = 0.f;
+    constexpr float LOG2E = 1.4426950408889634f;
+    int rbuf = 0, wbuf = DEPTH - 1;
+
+    // LDS side of tile tl: landed (this wave's pieces: counted vmcnt; everyone's: the barrier, which also says every wave has READ the
+    // buffer refilled next — its reads of tile tl-1 were waited for, lgkmcnt(0), before that tile's score MFMAs), refill, fragment requests
+    auto request = [&](int tl, f16x8 (&kfr)[4], f16x8 (&vfr)[4]) {
+        if (tl + DEPTH - 2 < NT) __builtin_amdgcn_s_waitcnt(((NL * (DEPTH - 2)) & 15) | (((NL * (DEPTH - 2)) >> 4) << 14) | 0x0F70);
+        else __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();
+        if (tl + DEPTH - 1 < NT) issue(tl + DEPTH - 1, wbuf);
+        const f16x8* src = aring + (long)rbuf * 8 * 64 + lane;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) kfr[f] = src[f * 64];
+#pragma unroll
+        for (int f = 0; f < 4; ++f) vfr[f] = src[(4 + f) * 64];
+        rbuf = (rbuf + 1 == DEPTH) ? 0 : rbuf + 1;
+        wbuf = (wbuf + 1 == DEPTH) ? 0 : wbuf + 1;
+    };
+    auto scores = [&](const f16x8 (&kfr)[4], f32x4 (&st)[2]) {
+        __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): K AND V fragments (see request: nothing of this wave may still read the ring at the next barrier)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            st[s] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) st[s] = mfma16(kfr[s * 2 + kt], qf[kt], st[s]);
+        }
+    };
+    // tile ti: softmax of its scores sc, output MFMAs with its V fragments vc; in between (has_next) tile ti+1's requests and score MFMAs
+    auto step = [&](int ti, f32x4 (&sc)[2], f16x8 (&vc)[4], f32x4 (&sn)[2], f16x8 (&vn)[4], auto masked_tag) {
+        constexpr bool MASKED = decltype(masked_tag)::value;
+        const bool has_next = ti + 1 < NT;                  // (uniform over the workgroup: every wave meets the same barriers)
+        f16x8 kfr[4];
+        if (has_next) request(ti + 1, kfr, vn);
+        __builtin_amdgcn_sched_barrier(0);
+        float p[8];
+        float tmax = WLX_NEG_INF;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = sc[s][r];
+                if (MASKED) { const int key = ti * 32 + g * 8 + s * 4 + r; v = (key < T) ? v : WLX_NEG_INF; }
+                p[s * 4 + r] = v;
+                tmax = fmaxf(tmax, v);
+            }
+        tmax = rows4_max(tmax) * LOG2E;
+        const float mnew = fmaxf(mrun, tmax);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+        float psum = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { p[i] = __builtin_amdgcn_exp2f(__builtin_fmaf(p[i], LOG2E, -mnew)); psum += p[i]; }
+        lrun = lrun * alpha + psum;
+        mrun = mnew;
+        const f16x8 pf = {(half_t)p[0], (half_t)p[1], (half_t)p[2], (half_t)p[3],
+                          (half_t)p[4], (half_t)p[5], (half_t)p[6], (half_t)p[7]};
+        if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+            float al = alpha;
+            asm volatile("" : "+v"(al));
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { acc[dt][0] *= al; acc[dt][1] *= al; acc[dt][2] *= al; acc[dt][3] *= al; }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (has_next) scores(kfr, sn);
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma16(vc[dt], pf, acc[dt]);
+    };
+    f32x4 sA[2], sB[2];
+    f16x8 vA[4], vB[4];
+    {
+        f16x8 kfr[4];
+        request(0, kfr, vA);
+        scores(kfr, sA);
+    }
+    const int NTfull = T >> 5;                              // tiles entirely below T
+    int ti = 0;
+#pragma unroll 1
+    for (; ti + 2 <= NTfull; ti += 2) {
+        step(ti, sA, vA, sB, vB, std::false_type{});
+        step(ti + 1, sB, vB, sA, vA, std::false_type{});
+    }
+    if (ti < NT) {                                          // at most two more: a last full tile and / or the tile that crosses T
+        step(ti, sA, vA, sB, vB, std::true_type{});
+        if (ti + 1 < NT) step(ti + 1, sB, vB, sA, vA, std::true_type{});
+    }
+    float l = lrun;
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int row = q0 + c;
+    if (row < T) {
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) {
+            const f16x4 o = {(half_t)(acc[dt][0] * inv), (half_t)(acc[dt][1] * inv),
+                             (half_t)(acc[dt][2] * inv), (half_t)(acc[dt][3] * inv)};
+            *reinterpret_cast<f16x4*>(O + (long)row * ldo + dt * 16 + g * 4) = o;
+        }
+    }
+}
+
 // (Measured and dropped, profiles/r2z: a fourth form with TWO key tiles per ring stage — half the waits and barriers, the same
 // bytes in flight — runs at the third form's speed (1.58-1.61 ms per encoder for both), as do a ring of 7 and eight waves per
 // workgroup: the 47 % of wave cycles the SQ counters show parked are not the per-tile barrier or the fill latency. A fifth
@@ -494,13 +683,30 @@ void launch_attn_encoder(const half_t* Q, long ldq, const half_t* K, long ldk, c
                          long isq, long isk, long isv, long iso, hipStream_t s) {
     constexpr int QT = 2;   // measured on Whisper-small: QT = 1 fills every SIMD but doubles the K/V re-reads from L2: 2.64 vs 2.35 ms per encoder
     dim3 grid((T + QT * 16 - 1) / (QT * 16), H, items);
-    static const int form = [] { const char* e = getenv("WLX_ENC_ATTN"); return e ? atoi(e) : 3; }();   // 1 / 2 = earlier forms (A/B)
+    // default: one window = the third form (4 waves per workgroup); batched encodes (>= 4000 rows) = the fourth form with EIGHT waves sharing
+    // a K / V tile (12 windows 7.41 -> 7.05 ms per encoder, large-v3 x 8 24.8 -> 24.1 ms; one window 1.63 vs 1.66 ms, profiles/r4attn2_*)
+    static const int form_env = [] { const char* e = getenv("WLX_ENC_ATTN"); return e ? atoi(e) : 0; }();   // 1 / 2 = earlier forms, 3..8 = one LDS form everywhere (A/B)
+    const int form = form_env > 0 ? form_env : ((long)items * T >= 4000 ? 8 : 3);
     if (form >= 3) {      // 3: 4 waves, ring of 4; 4: 4 waves, ring of 7 (56 KiB); 5: 8 waves (128 rows), ring of 7
-#define WLX_ATTN_LDS(DEPTH_, NW_) hipLaunchKernelGGL((attn_encoder_lds_kernel<DEPTH_, NW_>), dim3((T + NW_ * 16 - 1) / (NW_ * 16), H, items), \
-                                                     dim3(NW_ * 64), DEPTH_ * 8 * 1024 + NW_ * 2048, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, T, isq, isk, isv, iso)
+        static const bool xcd_map = [] { const char* e = getenv("WLX_ENC_ATTN_XCD"); return !(e && e[0] == '0'); }();   // 0 = plain order (A/B)
+        auto amap = [&](int nw) {
+            AttnMap am;
+            am.nq = (T + nw * 16 - 1) / (nw * 16); am.H = H; am.total = am.nq * H * items;
+            am.chunk = xcd_map ? (am.total + 7) / 8 : 0;
+            return am;
+        };
+        auto agrid = [&](const AttnMap& am) { return dim3(am.chunk > 0 ? 8 * am.chunk : am.total); };
+#define WLX_ATTN_LDS(DEPTH_, NW_) do { const AttnMap am = amap(NW_); hipLaunchKernelGGL((attn_encoder_lds_kernel<DEPTH_, NW_>), agrid(am), \
+                                                     dim3(NW_ * 64), DEPTH_ * 8 * 1024 + NW_ * 2048, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, T, isq, isk, isv, iso, am); } while (0)
+#define WLX_ATTN_LDS2(DEPTH_, NW_) do { const AttnMap am = amap(NW_); hipLaunchKernelGGL((attn_encoder_lds2_kernel<DEPTH_, NW_>), agrid(am), \
+                                                      dim3(NW_ * 64), DEPTH_ * 8 * 1024 + NW_ * 2048, s, Q, ldq, K, ldk, Vt, ldvt, O, ldo, T, isq, isk, isv, iso, am); } while (0)
         if (form == 3) WLX_ATTN_LDS(4, 4);
         else if (form == 4) WLX_ATTN_LDS(7, 4);
-        else WLX_ATTN_LDS(7, 8);
+        else if (form == 5) WLX_ATTN_LDS(7, 8);
+        else if (form == 6) WLX_ATTN_LDS2(4, 4);            // software-pipelined (round 4)
+        else if (form == 7) WLX_ATTN_LDS2(3, 4);            // ... ring of 3 (32 KiB: five workgroups per CU)
+        else WLX_ATTN_LDS2(4, 8);                           // ... eight waves
+#undef WLX_ATTN_LDS2
 #undef WLX_ATTN_LDS
         return;
     }
