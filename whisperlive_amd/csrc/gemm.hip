@@ -26,10 +26,55 @@
 
 namespace wlx {
 
+#ifndef WLX_RESID_BATCHED
+#define WLX_RESID_BATCHED 1      // -DWLX_RESID_BATCHED=0 (_lib.build_variant): tile-by-tile residual update (A/B)
+#endif
+
 // ---------------- epilogue shared by both GEMM forms: lane owns columns n..n+3 of row m (WNT x WMT accumulator tiles of
 // the wave whose first n-tile is nt0 and first row m0)
 template <int WNT, int WMT, int MODE>
 __device__ __forceinline__ void gemm_epilogue_m(const GemmParams& p, f32x4 (&acc)[WNT][WMT], int nt0, int m0, int z, int c, int g) {
+    if constexpr (MODE == GEMM_RESID_F32) {
+        // The residual update reads and writes X through one pointer: written tile by tile (load, add, store) every load had to stay behind
+        // the previous tile's store — hipcc cannot tell the rows apart (runtime ldx) — so a wave's WNT x WMT tiles were as many DEPENDENT
+        // memory round trips. Here the WMT row tiles of an n-tile are requested together (rows past M clamped: no branch around a load), then
+        // updated and stored. Measured on one box (profiles/r4resid_residual_epilogue_ab.txt): one window 1.636 -> 1.618 ms per encoder; the
+        // large-M form (WMT = 8, every CU in its epilogue at the same time) is FASTER tile by tile — 12 windows 7.28 vs 7.54 ms, large-v3 x 8
+        // 25.7 vs 26.5 ms: its dependent round trips pace the 110 MB read-modify-write — and keeps that.
+        if (WLX_RESID_BATCHED && WMT < 8) {
+            float* xb = p.X + (long)z * p.strideX;
+            float4 bvs[WNT];
+#pragma unroll
+            for (int ni = 0; ni < WNT; ++ni) {
+                int n = (nt0 + ni) * 16 + g * 4;
+                if (n >= p.N) n = 0;                 // (clamped: unused)
+                bvs[ni] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int ni = 0; ni < WNT; ++ni) {
+                const int n = (nt0 + ni) * 16 + g * 4;
+                if (n >= p.N) continue;
+                const float4 bv = bvs[ni];
+                float4 r[WMT];
+#pragma unroll
+                for (int mi = 0; mi < WMT; ++mi) {
+                    int m = m0 + mi * 16 + c;
+                    if (m >= p.M) m = p.M - 1;
+                    r[mi] = *reinterpret_cast<const float4*>(xb + (long)m * p.ldx + n);
+                }
+                asm volatile("" ::: "memory");      // (keeps the stores below the LAST load of the batch)
+#pragma unroll
+                for (int mi = 0; mi < WMT; ++mi) {
+                    const int m = m0 + mi * 16 + c;
+                    if (m >= p.M) continue;
+                    const float4 o = make_float4(r[mi].x + (acc[ni][mi][0] + bv.x), r[mi].y + (acc[ni][mi][1] + bv.y),
+                                                 r[mi].z + (acc[ni][mi][2] + bv.z), r[mi].w + (acc[ni][mi][3] + bv.w));
+                    *reinterpret_cast<float4*>(xb + (long)m * p.ldx + n) = o;
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int ni = 0; ni < WNT; ++ni) {
         const int n = (nt0 + ni) * 16 + g * 4;
