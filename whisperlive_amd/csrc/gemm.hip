@@ -29,6 +29,10 @@ namespace wlx {
 #ifndef WLX_RESID_BATCHED
 #define WLX_RESID_BATCHED 1      // -DWLX_RESID_BATCHED=0 (_lib.build_variant): tile-by-tile residual update (A/B)
 #endif
+#ifndef WLX_RESID_LN
+#define WLX_RESID_LN 4           // residual batches of the large-M form: n-tiles x m-tiles requested together (0 = tile by tile)
+#define WLX_RESID_LM 1
+#endif
 
 // ---------------- epilogue shared by both GEMM forms: lane owns columns n..n+3 of row m (WNT x WMT accumulator tiles of
 // the wave whose first n-tile is nt0 and first row m0)
@@ -38,10 +42,15 @@ __device__ __forceinline__ void gemm_epilogue_m(const GemmParams& p, f32x4 (&acc
         // The residual update reads and writes X through one pointer: written tile by tile (load, add, store) every load had to stay behind
         // the previous tile's store — hipcc cannot tell the rows apart (runtime ldx) — so a wave's WNT x WMT tiles were as many DEPENDENT
         // memory round trips. Here the WMT row tiles of an n-tile are requested together (rows past M clamped: no branch around a load), then
-        // updated and stored. Measured on one box (profiles/r4resid_residual_epilogue_ab.txt): one window 1.636 -> 1.618 ms per encoder; the
-        // large-M form (WMT = 8, every CU in its epilogue at the same time) is FASTER tile by tile — 12 windows 7.28 vs 7.54 ms, large-v3 x 8
-        // 25.7 vs 26.5 ms: its dependent round trips pace the 110 MB read-modify-write — and keeps that.
-        if (WLX_RESID_BATCHED && WMT < 8) {
+        // updated and stored. Measured on one box (profiles/r4resid_residual_epilogue_ab.txt): one window 1.636 -> 1.618 ms per encoder. On the
+        // large-M form (WMT = 8, every CU in its epilogue at the same time, 110 MB read-modify-write per launch) WHICH tiles go together
+        // matters: the 8 row tiles of an n-tile (128 rows x 64 B) are SLOWER than tile by tile (12 windows 7.54 vs 7.28 ms), the 4 n-tiles of a
+        // row tile (16 rows x 256 contiguous bytes) faster (7.12 vs 7.24 ms, large-v3 x 8 25.1 vs 25.5 ms): DRAM page locality.
+        // (the large-M form: WLX_RESID_LN x WLX_RESID_LM tiles per batch, -D A/B; 0 = tile by tile)
+        constexpr int BN0 = (WMT < 8) ? 1 : WLX_RESID_LN, BM0 = (WMT < 8) ? WMT : WLX_RESID_LM;
+        constexpr int BN = BN0 > 0 ? BN0 : 1, BM = BM0 > 0 ? BM0 : 1;
+        if constexpr (WLX_RESID_BATCHED && BN0 > 0 && BM0 > 0) {
+            static_assert(WNT % BN == 0 && WMT % BM == 0, "batch shape must divide the wave tile");
             float* xb = p.X + (long)z * p.strideX;
             float4 bvs[WNT];
 #pragma unroll
@@ -51,27 +60,34 @@ __device__ __forceinline__ void gemm_epilogue_m(const GemmParams& p, f32x4 (&acc
                 bvs[ni] = p.bias ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int ni = 0; ni < WNT; ++ni) {
-                const int n = (nt0 + ni) * 16 + g * 4;
-                if (n >= p.N) continue;
-                const float4 bv = bvs[ni];
-                float4 r[WMT];
+            for (int ni0 = 0; ni0 < WNT; ni0 += BN)
 #pragma unroll
-                for (int mi = 0; mi < WMT; ++mi) {
-                    int m = m0 + mi * 16 + c;
-                    if (m >= p.M) m = p.M - 1;
-                    r[mi] = *reinterpret_cast<const float4*>(xb + (long)m * p.ldx + n);
-                }
-                asm volatile("" ::: "memory");      // (keeps the stores below the LAST load of the batch)
+                for (int mi0 = 0; mi0 < WMT; mi0 += BM) {
+                    float4 r[BN][BM];
 #pragma unroll
-                for (int mi = 0; mi < WMT; ++mi) {
-                    const int m = m0 + mi * 16 + c;
-                    if (m >= p.M) continue;
-                    const float4 o = make_float4(r[mi].x + (acc[ni][mi][0] + bv.x), r[mi].y + (acc[ni][mi][1] + bv.y),
-                                                 r[mi].z + (acc[ni][mi][2] + bv.z), r[mi].w + (acc[ni][mi][3] + bv.w));
-                    *reinterpret_cast<float4*>(xb + (long)m * p.ldx + n) = o;
+                    for (int a = 0; a < BN; ++a)
+#pragma unroll
+                        for (int b = 0; b < BM; ++b) {
+                            int n = (nt0 + ni0 + a) * 16 + g * 4;
+                            if (n >= p.N) n = 0;
+                            int m = m0 + (mi0 + b) * 16 + c;
+                            if (m >= p.M) m = p.M - 1;
+                            r[a][b] = *reinterpret_cast<const float4*>(xb + (long)m * p.ldx + n);
+                        }
+                    asm volatile("" ::: "memory");      // (keeps the stores below the LAST load of the batch)
+#pragma unroll
+                    for (int a = 0; a < BN; ++a)
+#pragma unroll
+                        for (int b = 0; b < BM; ++b) {
+                            const int ni = ni0 + a, mi = mi0 + b;
+                            const int n = (nt0 + ni) * 16 + g * 4, m = m0 + mi * 16 + c;
+                            if (n >= p.N || m >= p.M) continue;
+                            const float4 bv = bvs[ni];
+                            const float4 o = make_float4(r[a][b].x + (acc[ni][mi][0] + bv.x), r[a][b].y + (acc[ni][mi][1] + bv.y),
+                                                         r[a][b].z + (acc[ni][mi][2] + bv.z), r[a][b].w + (acc[ni][mi][3] + bv.w));
+                            *reinterpret_cast<float4*>(xb + (long)m * p.ldx + n) = o;
+                        }
                 }
-            }
             return;
         }
     }
