@@ -916,8 +916,7 @@ static int gemm2_pick(const GemmParams& p, int zbatch) {
     const int n_shapes = (int)(sizeof(kGemm2Shapes) / sizeof(kGemm2Shapes[0]));
     if (forced >= 0 && forced < n_shapes) return forced;
     static const int large = [] { const char* e = getenv("WLX_GEMM2_LARGE_SHAPE"); return e ? atoi(e) : 3; }();   // (A/B) shape for M >= 4000 launches that do not take the third form
-    (void)zbatch;
-    if (p.M >= 4000 && large >= 0 && large < n_shapes) return large;
+    if ((long)p.M * zbatch >= 4000 && large >= 0 && large < n_shapes) return large;   // (batched conv front end: 12 x 3000 / 1500 rows)
     return 3;
 }
 int gemm_prepare_device() {      // once per engine, on the engine's device (wlx_engine_create)
