@@ -142,7 +142,11 @@ int32_t wlx_logmel(wlx_engine* e, int32_t slot, int32_t item, const float* pcm, 
 /* The same in two halves, for callers that keep the stream's PCM resident in HBM (the device-side
  * counterpart of the session buffer of whisper_live/backend/base.py:173-234): wlx_pcm_put copies
  * `n` host samples into the item's device PCM buffer; wlx_logmel_resident computes the features of
- * whatever is resident. wlx_logmel == wlx_pcm_put + wlx_logmel_resident. */
+ * whatever is resident. wlx_logmel == wlx_pcm_put + wlx_logmel_resident.
+ * Neither waits for the device, and the feature launches of a slot's items are RECORDED and issued together — one launch of each
+ * kernel for all requested items — in front of the first call that consumes them (wlx_encode, wlx_features_get, wlx_features_set,
+ * wlx_timings_get, wlx_sync) or that replaces a requested item's PCM: n_frames_out is a function of n alone, errors of the launch
+ * itself surface at that later call. */
 int32_t wlx_pcm_put(wlx_engine* e, int32_t slot, int32_t item, const float* pcm, int64_t n);
 int32_t wlx_logmel_resident(wlx_engine* e, int32_t slot, int32_t item, int32_t* n_frames_out);
 /* Copy an item's device features to host / replace them from host (float32 [n_mels, n_frames]). */
