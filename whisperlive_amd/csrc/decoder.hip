@@ -1211,8 +1211,15 @@ static GemvParams gemv_chunked(const GemvParams& p) {
     // Which projections: measured per kernel at 20 / 40 / 60 rows (profiles/r4a-c_*): row tiles win wherever the launch has few
     // column tiles (N = d_model: 7.1 -> 4.2 us at 60 rows, large-v3 6.7 -> 4.8 us at 40) and for Whisper-small's wide ones
     // (first MLP projection 10.3 -> 6.9 us); large-v3's N = 3 d / 4 d projections (10-13 MB of weights re-read per row tile
-    // through L2) are faster as three-tile workgroups (8.7 vs 11.8 us, 9.1 vs 9.8 us).
-    const bool rt_shape = p.N <= 1536 || (long)p.N * p.K <= 3200000L;
+    // through L2) were faster as three-tile workgroups (8.7 vs 11.8 us, 9.1 vs 9.8 us) — with ONE column tile per workgroup. With the four
+    // column tiles per workgroup the row-tiled LayerNorm projections got later in the round they are not (large-v3, 40 rows: first
+    // projection 8.8 -> 7.7 us, first MLP projection 9.2 -> 7.6 us, step 2183 -> 2087 us; profiles/r4lv3rt_decode_step.txt): every
+    // LayerNorm-fronted projection whose tile count divides by four is cut too from three row tiles up (60 rows: 3157 -> 2857 us; 20 rows,
+    // two row tiles: 1845 -> 1905 us, left as it was). WLX_ROWTILE_WIDE=0 = the earlier policy (A/B).
+    static const bool rt_wide = [] { const char* e = getenv("WLX_ROWTILE_WIDE"); return !(e && e[0] == '0'); }();
+    const bool ln_wide4 = rt_wide && rt_chunk == 16 && p.M > 32 && p.in_mode == GEMV_IN_LN && p.xsrc == GEMV_X_PLAIN && (p.out_mode == GEMV_OUT_QKV || p.out_mode == GEMV_OUT_GELU_F16) &&
+                          (p.N & 15) == 0 && ((p.N >> 4) & 3) == 0;
+    const bool rt_shape = p.N <= 1536 || (long)p.N * p.K <= 3200000L || ln_wide4;
     if (rt_on && !g_decode_v1 && p.M > rt_chunk && p.M <= rt_max && p.N <= rt_nmax && (rt_shape || rt_nmax != (1 << 30))) { q.Mtot = p.M; q.M = rt_chunk; q.chunk = rt_chunk; q.rt_nz = (p.M + rt_chunk - 1) / rt_chunk; }
     else if (p.M > 48 && p.xsrc != GEMV_X_EMBED) { q.Mtot = p.M; q.M = 48; q.chunk = 48; }
     return q;
