@@ -304,9 +304,10 @@ def test_engine_slots_are_pooled_across_client_threads():
 
 
 def test_wide_batches_decode_in_lean_groups_over_the_same_encoder_output():
-    """12 items x 5 beams = 60 rows exceed what one launch of the lean decode kernels covers (48 = three 16-row tiles): the
-    batch is decoded as groups of 9 + 3 items over the SAME encoder output (item maps), one result per prompt, in order;
-    the batch worker's default of 8 items (40 rows) is ONE decode."""
+    """One decode step of the lean kernels covers 64 beam rows (16-row tiles; 48 until round 4, when a 12-item beam-5 batch was split
+    9 + 3 — the reason `--batch_max_size 12` measured slower than 8 through the worker): 12 items x 5 beams = 60 rows are ONE decode;
+    a batch past 64 rows (12 items x 7 rows) is decoded as groups of 9 + 3 items over the SAME encoder output (item maps), one result
+    per prompt, in order."""
     eng = FakeEngine()
     tb = eng.spec.vocab - 1501
     seen = []
@@ -315,17 +316,23 @@ def test_wide_batches_decode_in_lean_groups_over_the_same_encoder_output():
         seen.append((len(prompts), kw.get("enc_items")))
         return [GenerationResult([[tb, 300 + i, tb + 50]], [-0.1], 0.01) for i in range(len(prompts))]
 
-    eng.generate_script = [script, script]
+    eng.generate_script = [script]
     m = WhisperModelHIP("fake", engine=eng, hf_tokenizer=synthetic_tokenizer(V), max_batch=12, vad_model=EnergyGateModel())
     enc = m.encode(np.zeros((12, 80, 3000), np.float32))
     tk = Tokenizer(m.hf_tokenizer, False)
     res = m.model.generate(enc, [[tk.sot]] * 12, beam_size=5)
+    assert seen == [(12, None)] and len(res) == 12    # fits one decode: no item map needed
+    seen.clear()
+    eng.generate_script = [script, script]
+    enc = m.encode(np.zeros((12, 80, 3000), np.float32))
+    res = m.model.generate(enc, [[tk.sot]] * 12, beam_size=7)
     assert seen == [(9, list(range(9))), (3, [9, 10, 11])] and len(res) == 12
+    assert [r.sequences_ids[0][1] for r in res] == [300 + i for i in range(9)] + [300 + i for i in range(3)]
     seen.clear()
     eng.generate_script = [script]
     enc8 = m.encode(np.zeros((8, 80, 3000), np.float32))
     m.model.generate(enc8, [[tk.sot]] * 8, beam_size=5)
-    assert seen == [(8, None)]                       # fits one launch: no item map needed
+    assert seen == [(8, None)]
 
 
 def test_vad_unavailable_from_a_factory_built_transcriber_downgrades_once(monkeypatch):

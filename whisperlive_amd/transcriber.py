@@ -159,7 +159,7 @@ class FeatureExtractorHIP:
 class _EngineModel:
     """The ctranslate2.models.Whisper surface the reference calls."""
 
-    MAX_LEAN_ROWS = 48      # rows one launch of the lean decode kernels covers (csrc/decoder.hip gemv2_cfg: three 16-row tiles)
+    MAX_LEAN_ROWS = 64      # rows one decode step of the lean kernels covers (csrc/decoder.hip gemv_chunked: 16-row tiles up to 64 rows since round 4; was 48)
 
     def __init__(self, owner: "WhisperModelHIP"):
         self._o = owner
@@ -196,10 +196,10 @@ class _EngineModel:
             sup = [t for t in sup if t >= 0] + list(o._base_tokenizer.non_speech_tokens)
         # CT2's generate defaults: beam_size > 1 -> beam search; beam_size == 1 -> sampling with top-k / temperature.
         temp = 0.0 if beam_size > 1 else (float(sampling_temperature) if sampling_topk != 1 else 0.0)
-        # The lean decode kernels (decoder.hip dec_gemv2_kernel) cover 48 beam rows per launch (three 16-row MFMA tiles); a wider batch (e.g. the batch
-        # worker's default of 8 items x 5 beams = 40 rows) would fall back to the general first-generation kernels, ~3x
-        # slower per step. Decode such a batch as consecutive groups over the SAME resident encoder output (item maps):
-        # identical results, every launch on the fast path.
+        # The lean decode kernels (decoder.hip dec_gemv2_kernel) cover 64 beam rows per step (16-row tiles; 48 until round 4 — a 12-item
+        # beam-5 batch was then decoded as 9 + 3 items, which is what made `--batch_max_size 12` slower than 8 through the worker); a wider
+        # batch would fall back to the general first-generation kernels, ~3x slower per step. Decode such a batch as consecutive groups
+        # over the SAME resident encoder output (item maps): identical results, every launch on the fast path.
         rows_per_item = max(1, beam_size if (beam_size > 1 and temp == 0.0) else num_hypotheses)
         group = max(1, self.MAX_LEAN_ROWS // rows_per_item)
         items = encoder_output.items if encoder_output.items is not None else list(range(encoder_output.batch))
