@@ -96,7 +96,7 @@ def test_backend_type():
         BackendType("nope")
 
 
-def test_server_defaults_and_run_validation(tmp_path):
+def test_server_defaults_and_run_validation(tmp_path, caplog):
     s = TranscriptionServer()
     assert s.client_manager is None and s.use_vad is True and s.single_model is False and s.batch_config is None
     assert s.raw_pcm_input is False and s.RATE == 16000
@@ -116,6 +116,12 @@ def test_server_defaults_and_run_validation(tmp_path):
         s.run("127.0.0.1", port=0, enable_rest=True)
     assert s.configure(batch_enabled=True, batch_max_size=4, batch_window_ms=20) == BackendType.HIP
     assert s.single_model is True and s.batch_config == {"max_batch_size": 4, "batch_window_ms": 20}
+    # a slot decodes at most 64 beam rows per step = 12 clips x beam 5: a wider batch is clamped with a WARNING instead of building
+    # slots on which every beam-5 decode would be refused
+    with caplog.at_level("WARNING"):
+        s.configure(batch_enabled=True, batch_max_size=16, batch_window_ms=20)
+    assert s.batch_config == {"max_batch_size": 12, "batch_window_ms": 20}
+    assert any("--batch_max_size 16" in r.getMessage() for r in caplog.records)
     s.configure(devices=[2, 3])
     assert [s._next_device() for _ in range(5)] == [2, 3, 2, 3, 2]
 

@@ -306,8 +306,8 @@ def test_engine_slots_are_pooled_across_client_threads():
 def test_wide_batches_decode_in_lean_groups_over_the_same_encoder_output():
     """One decode step of the lean kernels covers 64 beam rows (16-row tiles; 48 until round 4, when a 12-item beam-5 batch was split
     9 + 3 — the reason `--batch_max_size 12` measured slower than 8 through the worker): 12 items x 5 beams = 60 rows are ONE decode;
-    a batch past 64 rows (12 items x 7 rows) is decoded as groups of 9 + 3 items over the SAME encoder output (item maps), one result
-    per prompt, in order."""
+    a batch past the limit is decoded as groups (here 9 + 3 items at the old 48-row limit) over the SAME encoder output (item maps), one
+    result per prompt, in order; more rows per item than the slot was built for is refused with the limit spelled out."""
     eng = FakeEngine()
     tb = eng.spec.vocab - 1501
     seen = []
@@ -325,8 +325,12 @@ def test_wide_batches_decode_in_lean_groups_over_the_same_encoder_output():
     seen.clear()
     eng.generate_script = [script, script]
     enc = m.encode(np.zeros((12, 80, 3000), np.float32))
-    res = m.model.generate(enc, [[tk.sot]] * 12, beam_size=7)
+    m.model.MAX_LEAN_ROWS = 48                         # (the grouping itself, at the pre-round-4 limit: a slot never holds more than 64 rows)
+    res = m.model.generate(enc, [[tk.sot]] * 12, beam_size=5)
+    m.model.MAX_LEAN_ROWS = 64
     assert seen == [(9, list(range(9))), (3, [9, 10, 11])] and len(res) == 12
+    with pytest.raises(ValueError, match="5 decoder rows per audio item"):
+        m.model.generate(enc, [[tk.sot]] * 12, beam_size=7)          # more rows per item than the slot holds: refused with the limit spelled out
     assert [r.sequences_ids[0][1] for r in res] == [300 + i for i in range(9)] + [300 + i for i in range(3)]
     seen.clear()
     eng.generate_script = [script]

@@ -45,6 +45,8 @@ from .serve_client import ServeClientBase, ServeClientHIP
 from .sharding import assign_gpu
 from .ws import ConnectionClosed
 
+MAX_BEAM5_BATCH = 12        # clips per batched decode: 64 beam rows per engine slot / 5 beams (include/wlx.h wlx_slot_create)
+
 END_OF_AUDIO = b"END_OF_AUDIO"      # whisper_live/server.py:376, client.py:23
 AUDIO_FORMATS = ("float32", "int16", "uint8")
 
@@ -356,6 +358,12 @@ class TranscriptionServer:
             single_model = True                       # batching needs the shared per-GPU transcriber
             if batch_lanes < 1:
                 raise ValueError(f"batch_lanes must be >= 1, got {batch_lanes}")
+            if batch_max_size > MAX_BEAM5_BATCH:
+                # one engine slot decodes at most 64 beam rows per step (include/wlx.h wlx_slot_create): 12 clips x beam 5. A wider
+                # slot would hold fewer than 5 rows per clip and every beam-5 decode on it would be refused.
+                logging.warning(f"--batch_max_size {batch_max_size}: a batch decodes at most {MAX_BEAM5_BATCH} clips x 5 beams per step on this "
+                                f"backend; using {MAX_BEAM5_BATCH} (more lanes, --batch_lanes, are how further clips overlap)")
+                batch_max_size = MAX_BEAM5_BATCH
             self.batch_config = {"max_batch_size": batch_max_size, "batch_window_ms": batch_window_ms}   # (the reference's two keys)
             self.batch_lanes = int(batch_lanes)
             logging.info(f"Batch inference enabled (max_batch={batch_max_size}, window={batch_window_ms}ms, lanes={batch_lanes})")
@@ -440,8 +448,8 @@ def main(argv=None):
     ap.add_argument("--batch_window_ms", type=int, default=50)
     ap.add_argument("--batch_lanes", type=int, default=2, help="worker lanes per GPU in --batch_inference mode (each lane: own engine slot and hardware "
                                                                 "queue). Measured THROUGH the worker, 64 clips of 30 s, Whisper-large-v3 shapes, one MI355X, "
-                                                                "--batch_max_size 8: 1086 / 1513 / 1618 / 1708x real time at 1 / 2 / 3 / 4 lanes (profiles/r3k_*, "
-                                                                "r3d_*); --batch_max_size 12 is slower there (1444x, profiles/r3v_*)")
+                                                                "--batch_max_size 8: 1436x real time on one lane, 2215x on four; --batch_max_size 12: 1473x / 2261x "
+                                                                "(profiles/r4lv3rt_*, r4lv3b_*)")
     ap.add_argument("--raw_pcm_input", action="store_true")
     ap.add_argument("--metrics_port", type=int, default=0)
     ap.add_argument("--api_key", default=os.environ.get("WHISPERLIVE_API_KEY"))

@@ -201,6 +201,10 @@ class _EngineModel:
         # batch would fall back to the general first-generation kernels, ~3x slower per step. Decode such a batch as consecutive groups
         # over the SAME resident encoder output (item maps): identical results, every launch on the fast path.
         rows_per_item = max(1, beam_size if (beam_size > 1 and temp == 0.0) else num_hypotheses)
+        slot_rows = getattr(slot, "rows", None)
+        if isinstance(slot_rows, int) and rows_per_item > slot_rows:
+            raise ValueError(f"this transcriber's slots hold {slot_rows} decoder rows per audio item (max_batch={o.max_batch}: 64 rows per slot), "
+                             f"the decode asks for {rows_per_item} (beam_size / num_hypotheses): use max_batch <= {64 // rows_per_item}")
         group = max(1, self.MAX_LEAN_ROWS // rows_per_item)
         items = encoder_output.items if encoder_output.items is not None else list(range(encoder_output.batch))
         res = []
