@@ -165,3 +165,36 @@ def test_hip_engine_transcribes_the_widened_checkpoint_through_the_lean_kernels(
     finally:
         model.close()
         model.engine.close()
+
+
+@pytest.mark.gpu
+def test_twelve_utterances_in_one_worker_batch_are_one_60_row_decode(gpu, widened):
+    """The batching worker at `max_batch_size` 12 on the widened (Whisper-small-width) learned model: the 12 held-out utterances as ONE
+    batch — per-item log-mel recorded and launched together, one batched encode, ONE beam-5 decode of 60 rows (the transcriber split
+    batches at 48 rows until round 4: 9 + 3 clips) through the row-tiled lean kernels — every transcript word-exact."""
+    from whisperlive_amd.batching import BatchInferenceWorker, BatchRequest
+    from whisperlive_amd.transcriber import WhisperModelHIP
+    model = WhisperModelHIP(widened(6), device="cuda", device_index=0, max_batch=12)
+    try:
+        cases = _expected()["cases"][:12]
+        assert len(cases) == 12
+        slot = model._slot()
+        calls, orig = [], slot.generate
+
+        def counted(prompts, *a, **k):
+            calls.append(len(prompts))
+            return orig(prompts, *a, **k)
+        slot.generate = counted
+        worker = BatchInferenceWorker(model, max_batch_size=12, batch_window_ms=10)
+        worker.TEMPERATURES = (0.0,)
+        reqs = [BatchRequest(audio=utterance(c["seed"])[0], language="en", use_vad=False) for c in cases]
+        worker._process_multi(reqs)
+        assert calls == [12], calls
+        for c, r in zip(cases, reqs):
+            assert r.error is None and r.future.is_set(), r.error
+            said = " ".join(s.text.strip() for s in r.result).split()
+            assert said == [f"w{300 + w}" for w in c["words"]], (c["seed"], said, c["words"])
+        print("MI355X (libwlx.so), widened to d_model 768: 12 utterances in one worker batch = one 60-row decode, word error rate 0")
+    finally:
+        model.close()
+        model.engine.close()
