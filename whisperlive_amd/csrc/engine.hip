@@ -1029,6 +1029,7 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
     // slabs, 7.0 us without; large-v3 at 40 rows: 11.4 -> 8.7 us). WLX_FC2_KS_BATCHED=1 keeps the split (A/B).
     static const bool ks_batched = [] { const char* v = getenv("WLX_FC2_KS_BATCHED"); return v && v[0] == '1'; }();
     if (rows > 16 && rows <= 64 && !alt && !ks_batched) KS = 0;
+    if (alt != nullptr && rows > 48 && [] { const char* v = getenv("WLX_PREFILL_LN"); return v && v[0] == '1'; }()) KS = 0;   // (the separate LayerNorm launch reads plain rows)
     if (KS && !(dec_gemv_is_lean(qkv_params(0, GEMV_X_SLABS)) && dec_gemv_is_lean(oproj_params(0, GEMV_X_SLABS)))) KS = 0;
     // (batched steps, 17..64 rows: the folded form gathers ONE row per wave and trip — two trips per 16-row tile, the second behind the
     // weight stream — and has no four-tile instantiation: 13.6 us at 60 rows against 2.4 + 5.9 us for the embedding launch + the plain
@@ -1038,7 +1039,12 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
     // (A/B, round 4) batched rows: ONE LayerNorm launch per layer phase writing fp16 rows (into the attention-output rows, which are
     // free at those three points), the projections behind it as fp16-rows-in launches. WLX_BATCHED_LN=1.
     static const bool batched_ln_env = [] { const char* v = getenv("WLX_BATCHED_LN"); return v && v[0] == '1'; }();
-    const bool sep_ln = batched_ln_env && rows > 16 && rows <= 64 && !alt && !g_decode_v1 && dec_ln_rows_ok(d);
+    // (A/B, not measured yet — written at the end of round 4 without GPU minutes) the same for the prompt-prefill pass: its LayerNorm
+    // projections run as 48-row chunks whose every 16-column workgroup normalises its 48 rows again (23-27 us per launch at 224 rows,
+    // profiles/r4pf_conditioned_window_kernel_table.txt; estimated ~13 us as LayerNorm launch + fp16-rows-in projection). WLX_PREFILL_LN=1.
+    static const bool prefill_ln_env = [] { const char* v = getenv("WLX_PREFILL_LN"); return v && v[0] == '1'; }();
+    const bool sep_ln = !g_decode_v1 && dec_ln_rows_ok(d) &&
+                        ((batched_ln_env && rows > 16 && rows <= 64 && !alt) || (prefill_ln_env && alt != nullptr && rows > 48));
     auto ln_to_f16 = [&](GemvParams& q) {       // q: a LayerNorm-fronted projection over the plain rows -> LayerNorm launch + fp16-rows-in projection
         GemvParams t = q;
         t.in_mode = GEMV_IN_F16; t.Xh = s.attnd; t.ldxh = d;
