@@ -131,7 +131,10 @@ int32_t wlx_engine_spec(const wlx_engine* e, wlx_spec* out);
 
 /* A slot = one unit of concurrency: its own HIP stream plus every device buffer a call needs
  * (feature ring, encoder activations, cross-attention K/V, self-attention KV cache, beam state),
- * sized for `max_batch` audio items and `max_rows_per_item` decoder rows (beams) per item. */
+ * sized for `max_batch` audio items (<= 64) and `max_rows_per_item` decoder rows (beams, <= 16) per item;
+ * max_batch * max_rows_per_item <= 320 decoder rows per step (64 clips x beam 5: the reference's worker takes any
+ * max_batch_size, whisper_live/batch_inference.py:113-121 — wider batches than a slot holds are decoded as consecutive
+ * groups over the same resident encoder output by the host side). */
 int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max_rows_per_item, int32_t* slot_out);
 int32_t wlx_slot_destroy(wlx_engine* e, int32_t slot);
 

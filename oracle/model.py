@@ -40,19 +40,75 @@ def sinusoids(length: int, channels: int, max_timescale: float = 10000.0) -> tor
     return torch.cat([scaled.sin(), scaled.cos()], dim=1)
 
 
+def quantize_rows_int8(w: torch.Tensor):
+    """Per-output-row symmetric int8: q[n, :] = round(w[n, :] * s[n]), s[n] = 127 / max|w[n, :]| — the weight scheme CTranslate2's
+    converter applies for compute_type int8 (the reference's CPU default, whisper_live/backend/faster_whisper_backend.py:88-93; CT2 is
+    un-vendored: restated from its published quantisation description). Returns (integer-valued float32 [N, K], scale [N])."""
+    amax = w.abs().amax(dim=1).clamp_min(1e-12)
+    s = 127.0 / amax
+    return torch.round(w * s[:, None]).clamp_(-127, 127), s
+
+
 class WhisperOracle:
-    def __init__(self, spec: Spec, weights: Dict[str, np.ndarray], dtype=torch.float32):
+    """int8 = None   fp32 arithmetic (the parity oracle of the HIP path);
+       int8 = "ct2"  every linear layer (and the tied output projection) in CTranslate2's CPU int8 arithmetic: weights per-output-row
+                     symmetric int8, activations quantised dynamically per row (s = 127 / max|x_row|, round to nearest), integer
+                     accumulation, one dequantisation per output — convolutions, LayerNorm, softmax, GELU and the embedding gather stay
+                     float. Used to BOUND the distance between the HIP fp16 path and the arithmetic of the reference's CPU backend
+                     (tests/test_int8_gap.py);
+       int8 = "fbgemm" the same layers as torch's dynamic-quantised Linear (per-tensor activation scale): bench.py's `port-int8`
+                     timing leg only."""
+
+    def __init__(self, spec: Spec, weights: Dict[str, np.ndarray], dtype=torch.float32, int8: Optional[str] = None):
         self.spec = spec
         self.w = {k: torch.as_tensor(np.asarray(v)).to(dtype) for k, v in weights.items()}
         self.dtype = dtype
         self.H = spec.n_heads
+        self.int8 = int8
+        self.q: Dict[str, tuple] = {}
+        self.qmod: Dict[str, object] = {}
+        if int8 not in (None, "ct2", "fbgemm"):
+            raise ValueError(f"int8 mode {int8!r}")
+        if int8:
+            lin = [k[: -len(".weight")] for k, v in self.w.items()
+                   if k.endswith(".weight") and v.ndim == 2 and "embed_positions" not in k and "layer_norm" not in k]
+            for pre in lin:
+                W = self.w[pre + ".weight"].float()
+                if int8 == "ct2":
+                    self.q[pre] = quantize_rows_int8(W)
+                else:
+                    import warnings
+                    import torch.nn as nn
+                    m = nn.Linear(W.shape[1], W.shape[0], bias=True)
+                    with torch.no_grad():
+                        m.weight.copy_(W)
+                        b = self.w.get(pre + ".bias")
+                        m.bias.copy_(b.float() if b is not None else torch.zeros(W.shape[0]))
+                    with warnings.catch_warnings():
+                        warnings.simplefilter("ignore")
+                        self.qmod[pre] = torch.ao.quantization.quantize_dynamic(nn.Sequential(m), {nn.Linear}, dtype=torch.qint8)[0]
 
     # ------------------------------------------------------------------ helpers
     def _ln(self, x, prefix):
         return F.layer_norm(x, (x.shape[-1],), self.w[prefix + ".weight"], self.w[prefix + ".bias"], 1e-5)
 
     def _lin(self, x, prefix, bias=True):
-        return F.linear(x, self.w[prefix + ".weight"], self.w.get(prefix + ".bias") if bias else None)
+        b = self.w.get(prefix + ".bias") if bias else None
+        if self.int8 == "ct2":
+            Wq, ws = self.q[prefix]
+            xs = 127.0 / x.abs().amax(dim=-1, keepdim=True).clamp_min(1e-12)
+            xq = torch.round(x * xs).clamp_(-127, 127)
+            y = (xq @ Wq.T) / (xs * ws)              # integer-valued operands: the float product IS the int32 accumulation (|sum| << 2^31)
+            return y if b is None else y + b
+        if self.int8 == "fbgemm":
+            return self.qmod[prefix](x)              # (k_proj: its module carries a zero bias)
+        return F.linear(x, self.w[prefix + ".weight"], b)
+
+    def _logits(self, x):
+        """tied output projection h . tok_emb^T (modeling_whisper.py:965-970)"""
+        if self.int8:
+            return self._lin(x, "model.decoder.embed_tokens", bias=False)
+        return x @ self.w["model.decoder.embed_tokens.weight"].T
 
     def _heads(self, x):  # [B, T, d] -> [B, H, T, 64]
         B, T, d = x.shape
@@ -118,7 +174,7 @@ class WhisperOracle:
             h = self._ln(x, p + "final_layer_norm")
             x = x + self._lin(F.gelu(self._lin(h, p + "fc1")), p + "fc2")
         x = self._ln(x, "model.decoder.layer_norm")
-        return x @ self.w["model.decoder.embed_tokens.weight"].T
+        return self._logits(x)
 
 
 class StepDecoder:
@@ -167,4 +223,4 @@ class StepDecoder:
             x = x + m._lin(F.gelu(m._lin(h, p + "fc1")), p + "fc2")
         self.t = total
         x = m._ln(x, "model.decoder.layer_norm")
-        return x @ m.w["model.decoder.embed_tokens.weight"].T
+        return m._logits(x)

@@ -65,10 +65,10 @@ class OracleSlot:
 
 
 class OracleEngine:
-    def __init__(self, spec, weights_f16_rounded):
+    def __init__(self, spec, weights_f16_rounded, int8=None):
         self.spec, self.device = spec, 0
         self.oracle = omodel.WhisperOracle(omodel.Spec(spec.n_mels, spec.d_model, spec.n_heads, spec.enc_layers,
-                                                       spec.dec_layers, spec.ffn, spec.vocab), weights_f16_rounded)
+                                                       spec.dec_layers, spec.ffn, spec.vocab), weights_f16_rounded, int8=int8)
 
     def create_slot(self, max_batch=1, rows=5):
         return OracleSlot(self, max_batch, rows)

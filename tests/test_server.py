@@ -116,12 +116,17 @@ def test_server_defaults_and_run_validation(tmp_path, caplog):
         s.run("127.0.0.1", port=0, enable_rest=True)
     assert s.configure(batch_enabled=True, batch_max_size=4, batch_window_ms=20) == BackendType.HIP
     assert s.single_model is True and s.batch_config == {"max_batch_size": 4, "batch_window_ms": 20}
-    # a slot decodes at most 64 beam rows per step = 12 clips x beam 5: a wider batch is clamped with a WARNING instead of building
-    # slots on which every beam-5 decode would be refused
+    # the reference takes any max_batch_size (batch_inference.py:113-121): 16 and 24 pass through unclamped (round 5; a slot used to hold
+    # 64 beam rows = 12 clips); only past the engine's 64 clips x 5 beams per slot is the size clamped, with a WARNING
     with caplog.at_level("WARNING"):
         s.configure(batch_enabled=True, batch_max_size=16, batch_window_ms=20)
-    assert s.batch_config == {"max_batch_size": 12, "batch_window_ms": 20}
-    assert any("--batch_max_size 16" in r.getMessage() for r in caplog.records)
+        assert s.batch_config == {"max_batch_size": 16, "batch_window_ms": 20}
+        s.configure(batch_enabled=True, batch_max_size=24, batch_window_ms=20)
+        assert s.batch_config == {"max_batch_size": 24, "batch_window_ms": 20}
+        assert not any("--batch_max_size" in r.getMessage() for r in caplog.records)
+        s.configure(batch_enabled=True, batch_max_size=100, batch_window_ms=20)
+    assert s.batch_config == {"max_batch_size": 64, "batch_window_ms": 20}
+    assert any("--batch_max_size 100" in r.getMessage() for r in caplog.records)
     s.configure(devices=[2, 3])
     assert [s._next_device() for _ in range(5)] == [2, 3, 2, 3, 2]
 

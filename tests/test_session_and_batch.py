@@ -303,11 +303,11 @@ def test_engine_slots_are_pooled_across_client_threads():
     assert len(eng.slots) == 3 and seen[-1].sid >= 0
 
 
-def test_wide_batches_decode_in_lean_groups_over_the_same_encoder_output():
-    """One decode step of the lean kernels covers 64 beam rows (16-row tiles; 48 until round 4, when a 12-item beam-5 batch was split
-    9 + 3 — the reason `--batch_max_size 12` measured slower than 8 through the worker): 12 items x 5 beams = 60 rows are ONE decode;
-    a batch past the limit is decoded as groups (here 9 + 3 items at the old 48-row limit) over the SAME encoder output (item maps), one
-    result per prompt, in order; more rows per item than the slot was built for is refused with the limit spelled out."""
+def test_wide_batches_decode_in_groups_over_the_same_encoder_output():
+    """One decode step covers every row the slot holds (round 5: max_batch x 5 rows, up to 320; it was 64 rows = 12 clips at beam 5, and
+    48 until round 4, when a 12-item beam-5 batch was split 9 + 3): 12 and 24 items x 5 beams are ONE decode each; a call past the step
+    limit is decoded as groups (here 9 + 3 items at a 48-row limit) over the SAME encoder output (item maps), one result per prompt, in
+    order; more rows per item than the slot was built for is refused with the limit spelled out."""
     eng = FakeEngine()
     tb = eng.spec.vocab - 1501
     seen = []
@@ -322,12 +322,13 @@ def test_wide_batches_decode_in_lean_groups_over_the_same_encoder_output():
     tk = Tokenizer(m.hf_tokenizer, False)
     res = m.model.generate(enc, [[tk.sot]] * 12, beam_size=5)
     assert seen == [(12, None)] and len(res) == 12    # fits one decode: no item map needed
+    assert eng.slots[-1].max_batch == 12 and eng.slots[-1].rows == 5
     seen.clear()
     eng.generate_script = [script, script]
     enc = m.encode(np.zeros((12, 80, 3000), np.float32))
-    m.model.MAX_LEAN_ROWS = 48                         # (the grouping itself, at the pre-round-4 limit: a slot never holds more than 64 rows)
+    m.model.MAX_DEC_ROWS = 48                          # (the grouping itself, at the pre-round-4 step limit)
     res = m.model.generate(enc, [[tk.sot]] * 12, beam_size=5)
-    m.model.MAX_LEAN_ROWS = 64
+    m.model.MAX_DEC_ROWS = 320
     assert seen == [(9, list(range(9))), (3, [9, 10, 11])] and len(res) == 12
     with pytest.raises(ValueError, match="5 decoder rows per audio item"):
         m.model.generate(enc, [[tk.sot]] * 12, beam_size=7)          # more rows per item than the slot holds: refused with the limit spelled out
@@ -337,6 +338,15 @@ def test_wide_batches_decode_in_lean_groups_over_the_same_encoder_output():
     enc8 = m.encode(np.zeros((8, 80, 3000), np.float32))
     m.model.generate(enc8, [[tk.sot]] * 8, beam_size=5)
     assert seen == [(8, None)]
+    # a 24-clip transcriber (the reference's worker takes any max_batch_size, batch_inference.py:113-121): slots of 24 items x 5 rows,
+    # the whole batch in ONE decode
+    seen.clear()
+    eng.generate_script = [script]
+    m24 = WhisperModelHIP("fake", engine=eng, hf_tokenizer=synthetic_tokenizer(V), max_batch=24, vad_model=EnergyGateModel())
+    enc24 = m24.encode(np.zeros((24, 80, 3000), np.float32))
+    res = m24.model.generate(enc24, [[tk.sot]] * 24, beam_size=5)
+    assert seen == [(24, None)] and len(res) == 24
+    assert eng.slots[-1].max_batch == 24 and eng.slots[-1].rows == 5
 
 
 def test_vad_unavailable_from_a_factory_built_transcriber_downgrades_once(monkeypatch):

@@ -4,7 +4,8 @@
 
 namespace wlx {
 
-#define WLX_MAX_MT 4          // decoder rows are processed in up to 4 MFMA row tiles (64 rows)
+#define WLX_MAX_MT 4          // the first-generation kernel holds up to 4 MFMA row tiles (64 rows) per launch; wider passes run as row chunks
+#define WLX_MAX_DEC_ROWS 320  // decoder rows of one step (items x beams): 64 items x 5 beams (round 5: was 64 rows — a slot decoded at most 12 clips per step)
 #define WLX_XSPLIT 8          // key splits of the decode cross-attention (flash-decoding)
 #define WLX_MAX_CAND 32       // 2*beam candidates per row
 #define WLX_MAX_HYP 32        // finished hypotheses kept per item

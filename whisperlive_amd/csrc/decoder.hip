@@ -1202,7 +1202,7 @@ static bool gemv2_ok(const GemvParams& p, Gemv2Cfg* out) {
 // dec_gemv2_kernel). WLX_ROWTILE=0 restores the 48-row form (A/B).
 static GemvParams gemv_chunked(const GemvParams& p) {
     static const bool rt_on = [] { const char* e = getenv("WLX_ROWTILE"); return !(e && e[0] == '0'); }();
-    static const int rt_max = [] { const char* e = getenv("WLX_ROWTILE_MAX"); const int v = e ? atoi(e) : 64; return v < 16 ? 16 : v; }();
+    static const int rt_max = [] { const char* e = getenv("WLX_ROWTILE_MAX"); const int v = e ? atoi(e) : WLX_MAX_DEC_ROWS; return v < 16 ? 16 : v; }();
     // (experiments: WLX_ROWTILE_NMAX = widest N that is cut into row tiles, WLX_ROWTILE_CHUNK = rows per tile: 16 / 32 / 48)
     static const int rt_nmax = [] { const char* e = getenv("WLX_ROWTILE_NMAX"); return e ? atoi(e) : (1 << 30); }();
     static const int rt_chunk = [] { const char* e = getenv("WLX_ROWTILE_CHUNK"); const int v = e ? atoi(e) : 16; return (v == 32 || v == 48) ? v : 16; }();
@@ -1241,10 +1241,11 @@ int dec_gemv_slab_split(int M, int K, int N) {
 }
 
 static bool vocab2_ok(const GemvParams& p);   // (dec_vocab_kernel, below)
+static int vocab2_chunk_rows(int K);
 const char* dec_gemv_kernel_name(const GemvParams& p_any) {
     static thread_local char buf[64];
     if (vocab2_ok(p_any)) {
-        snprintf(buf, sizeof(buf), "dec_vocab_kernel<%d, %d, %d>", p_any.KT, p_any.KT == 24 ? 6 : p_any.KT == 40 ? 5 : 4, (p_any.M + 15) / 16);
+        snprintf(buf, sizeof(buf), "dec_vocab_kernel<%d, %d, %d>", p_any.KT, p_any.KT == 24 ? 6 : p_any.KT == 40 ? 5 : 4, (std::min(p_any.M, vocab2_chunk_rows(p_any.K)) + 15) / 16);
         return buf;
     }
     const GemvParams p = gemv_chunked(p_any);
@@ -1460,7 +1461,11 @@ static void vocab_go(const VocabParams& p, hipStream_t s) {
         if (dev >= 0 && dev < 64 && granted[dev].load(std::memory_order_acquire) == 0) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_vocab_kernel<KT, KC, MT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     WLX_G2_LDS_MAX) == hipSuccess) granted[dev].store(1, std::memory_order_release);
-            else (void)hipGetLastError();
+            else {                  // this launch fails with the runtime's own error (reported for THIS call); later calls take the general kernel (vocab2_ok)
+                (void)hipGetLastError();
+                g_lds_optin_refused.store(true);
+                fprintf(stderr, "[wlx] device %d refused %d KiB of dynamic LDS: the batched vocabulary projection falls back to the general kernel\n", dev, WLX_G2_LDS_MAX / 1024);
+            }
         }
     }
     const int pairs = (p.NT + 1) / 2;
@@ -1480,26 +1485,40 @@ static int vocab2_mode() {
     static const int m = [] { const char* e = getenv("WLX_VOCAB2"); return e ? atoi(e) : 2; }();
     return m;
 }
+// rows one launch of dec_vocab_kernel takes: its fp16 LayerNorm rows must fit the workgroup's LDS (152 KiB: d_model <= 1024 64 rows,
+// large-v3 60 -> 48 = three whole row tiles). A wider pass (round 5: up to WLX_MAX_DEC_ROWS rows per step) runs as consecutive row
+// chunks, each streaming the weights again (Whisper-small 80 MB = ~25 us per 64 rows of a ~1 ms step).
+static int vocab2_chunk_rows(int K) {
+    int r = 64;
+    while (r > 16 && (size_t)r * (K + 8) * sizeof(half_t) > WLX_G2_LDS_MAX) r -= 16;
+    return r;
+}
 static bool vocab2_ok(const GemvParams& p) {
     if (g_decode_v1 || p.in_mode != GEMV_IN_LN || p.out_mode != GEMV_OUT_F32 || p.bias || p.xsrc != GEMV_X_PLAIN || p.Mtot != 0) return false;
     const int mode = vocab2_mode();
     if (mode == 0 || (mode == 1 && p.M <= 16)) return false;
-    if (p.M < 1 || p.M > 64 || p.K != p.KT * 32 || p.N < 256) return false;
+    if (p.M < 1 || p.M > WLX_MAX_DEC_ROWS || p.K != p.KT * 32 || p.N < 256) return false;
     if (!(p.KT == 16 || p.KT == 24 || p.KT == 32 || p.KT == 40)) return false;
-    return (size_t)p.M * (p.K + 8) * sizeof(half_t) <= WLX_G2_LDS_MAX;       // (large-v3: up to 59 rows)
+    const int rows = std::min(p.M, vocab2_chunk_rows(p.K));
+    const size_t shm = (size_t)rows * (p.K + 8) * sizeof(half_t);
+    if (shm > 64 * 1024 && g_lds_optin_refused.load(std::memory_order_relaxed)) return false;   // the device refused the raised LDS limit once: general kernel
+    return shm <= WLX_G2_LDS_MAX;
 }
 static void vocab2_launch(const GemvParams& g, hipStream_t s) {
-    VocabParams p{};
-    p.X = g.X; p.ldx = g.ldx; p.gamma = g.gamma; p.beta = g.beta; p.Wp = g.Wp; p.M = g.M; p.N = g.N; p.NT = (g.N + 15) / 16;
-    p.Y = g.Y; p.ldy = g.ldy;
+    const int CH = vocab2_chunk_rows(g.K);
+    for (int r0 = 0; r0 < g.M; r0 += CH) {
+        VocabParams p{};
+        p.X = g.X + (long)r0 * g.ldx; p.ldx = g.ldx; p.gamma = g.gamma; p.beta = g.beta; p.Wp = g.Wp; p.M = std::min(CH, g.M - r0); p.N = g.N; p.NT = (g.N + 15) / 16;
+        p.Y = g.Y + (long)r0 * g.ldy; p.ldy = g.ldy;
 #ifdef WLX_TRACE
-    p.trc = trace_next("vocab2");
+        p.trc = trace_next("vocab2");
 #endif
-    switch (g.KT) {
-        case 16: vocab_go_mt<16, 4>(p, s); break;
-        case 24: vocab_go_mt<24, 6>(p, s); break;
-        case 32: vocab_go_mt<32, 4>(p, s); break;
-        default: vocab_go_mt<40, 5>(p, s); break;
+        switch (g.KT) {
+            case 16: vocab_go_mt<16, 4>(p, s); break;
+            case 24: vocab_go_mt<24, 6>(p, s); break;
+            case 32: vocab_go_mt<32, 4>(p, s); break;
+            default: vocab_go_mt<40, 5>(p, s); break;
+        }
     }
 }
 
@@ -1517,6 +1536,29 @@ void launch_dec_gemv(const GemvParams& p_any, hipStream_t s) {
     Gemv2Cfg c2;
     const GemvParams pc = gemv_chunked(p_any);
     if (gemv2_ok(pc, &c2) && gemv2_launch(pc, c2, s)) return;
+    if (p_any.M > 16 * WLX_MAX_MT) {
+        // the general kernel holds WLX_MAX_MT row tiles per launch: a wider pass (round 5) runs as consecutive row chunks on rebased row
+        // pointers (64 rows; the split-combine prologue indexes its partials by (item, row in item), so its chunks are whole items)
+        const int CHK = (p_any.in_mode == GEMV_IN_XATTN && p_any.R > 0) ? (16 * WLX_MAX_MT / p_any.R) * p_any.R : 16 * WLX_MAX_MT;
+        for (int r0 = 0; r0 < p_any.M; r0 += CHK) {
+            GemvParams q = p_any;
+            q.M = std::min(CHK, p_any.M - r0);
+            if (q.X) q.X += (long)r0 * q.ldx;
+            if (q.Xh) q.Xh += (long)r0 * q.ldxh;
+            if (q.Yh) q.Yh += (long)r0 * q.ldyh;
+            if (q.Y) q.Y += (long)r0 * q.ldy;
+            if (q.Xres) q.Xres += (long)r0 * q.ldxres;
+            if (q.row_cache) q.row_cache += r0;
+            if (q.row_pos) q.row_pos += r0;
+            if (q.in_mode == GEMV_IN_XATTN) {
+                const int items0 = r0 / q.R;
+                q.part_o += (long)items0 * q.H * WLX_XSPLIT * 16 * 64;
+                q.part_ml += (long)items0 * q.H * 16 * WLX_XSPLIT * 2;
+            }
+            launch_dec_gemv(q, s);
+        }
+        return;
+    }
     const GemvParams& p0 = p_any;
     const GemvParams& p = p0;
     const int MT = (p.M + 15) / 16;

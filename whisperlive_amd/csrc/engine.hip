@@ -561,12 +561,12 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
     if (!e || !slot_out) return fail(WLX_ERR_ARG, "null argument");
     if (max_batch < 1 || max_batch > 64) return fail(WLX_ERR_ARG, "max_batch out of range");
     if (max_rows_per_item < 1 || max_rows_per_item > 16) return fail(WLX_ERR_ARG, "max_rows_per_item must be 1..16");
-    if (max_batch * max_rows_per_item > 64) return fail(WLX_ERR_ARG, "max_batch*max_rows_per_item must be <= 64");
+    if (max_batch * max_rows_per_item > WLX_MAX_DEC_ROWS) return fail(WLX_ERR_ARG, "max_batch*max_rows_per_item must be <= %d", WLX_MAX_DEC_ROWS);
     CK(hipSetDevice(e->device));
     const wlx_spec& sp = e->spec;
     const int d = sp.d_model, F = sp.ffn, L = sp.dec_layers, B = max_batch, R = max_rows_per_item;
     Slot* s = new Slot();
-    s->B = B; s->R = R; s->cache_rows = B * R; s->rows_cap = 64; s->groups_cap = std::max(B, 4);
+    s->B = B; s->R = R; s->cache_rows = B * R; s->rows_cap = std::max(64, B * R); s->groups_cap = std::max(B, 4);
     s->nframes.assign(B, 0);
     s->npcm.assign(B, 0);
     int rc = [&]() -> int {
@@ -1028,14 +1028,14 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
     // workgroup — and those launches are bound by load instructions per CU (60 rows, small.en: first projection 9.8 us with
     // slabs, 7.0 us without; large-v3 at 40 rows: 11.4 -> 8.7 us). WLX_FC2_KS_BATCHED=1 keeps the split (A/B).
     static const bool ks_batched = [] { const char* v = getenv("WLX_FC2_KS_BATCHED"); return v && v[0] == '1'; }();
-    if (rows > 16 && rows <= 64 && !alt && !ks_batched) KS = 0;
+    if (rows > 16 && !alt && !ks_batched) KS = 0;
     if (alt != nullptr && rows > 48 && [] { const char* v = getenv("WLX_PREFILL_LN"); return v && v[0] == '1'; }()) KS = 0;   // (the separate LayerNorm launch reads plain rows)
     if (KS && !(dec_gemv_is_lean(qkv_params(0, GEMV_X_SLABS)) && dec_gemv_is_lean(oproj_params(0, GEMV_X_SLABS)))) KS = 0;
     // (batched steps, 17..64 rows: the folded form gathers ONE row per wave and trip — two trips per 16-row tile, the second behind the
     // weight stream — and has no four-tile instantiation: 13.6 us at 60 rows against 2.4 + 5.9 us for the embedding launch + the plain
     // four-tile projection, profiles/r4s_decode_step.txt. WLX_EMBED_FOLD_BATCHED=1 folds there too (A/B).)
     static const bool fold_batched = [] { const char* v = getenv("WLX_EMBED_FOLD_BATCHED"); return v && v[0] == '1'; }();
-    const bool fold_embed = !no_fold && rows <= 64 && (rows <= 16 || alt != nullptr || fold_batched) && dec_gemv_is_lean(qkv_params(0, GEMV_X_EMBED));
+    const bool fold_embed = !no_fold && (rows <= 16 || alt != nullptr || (fold_batched && rows <= 64)) && dec_gemv_is_lean(qkv_params(0, GEMV_X_EMBED));
     // (A/B, round 4) batched rows: ONE LayerNorm launch per layer phase writing fp16 rows (into the attention-output rows, which are
     // free at those three points), the projections behind it as fp16-rows-in launches. WLX_BATCHED_LN=1.
     static const bool batched_ln_env = [] { const char* v = getenv("WLX_BATCHED_LN"); return v && v[0] == '1'; }();
@@ -1044,7 +1044,7 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
     // profiles/r4pf_conditioned_window_kernel_table.txt; estimated ~13 us as LayerNorm launch + fp16-rows-in projection). WLX_PREFILL_LN=1.
     static const bool prefill_ln_env = [] { const char* v = getenv("WLX_PREFILL_LN"); return v && v[0] == '1'; }();
     const bool sep_ln = !g_decode_v1 && dec_ln_rows_ok(d) &&
-                        ((batched_ln_env && rows > 16 && rows <= 64 && !alt) || (prefill_ln_env && alt != nullptr && rows > 48));
+                        ((batched_ln_env && rows > 16 && !alt) || (prefill_ln_env && alt != nullptr && rows > 48));
     auto ln_to_f16 = [&](GemvParams& q) {       // q: a LayerNorm-fronted projection over the plain rows -> LayerNorm launch + fp16-rows-in projection
         GemvParams t = q;
         t.in_mode = GEMV_IN_F16; t.Xh = s.attnd; t.ldxh = d;
@@ -1430,41 +1430,47 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
         // repeat the item's last prompt row: the same K / V written to the same cache position again) — instead of one full
         // pass per item, each of which streams every decoder weight (large-v3: 1.3 ms per item, 8 items per batch).
         static const bool joint = [] { const char* v = getenv("WLX_PREFILL_JOINT"); return !(v && v[0] == '0'); }();
-        if (joint && batch > 1 && with_prompt > 1 && longest <= 16 && s->pf_ok && !s->align && !s->prof && !g_decode_v1 && 16 * batch <= WLX_T_TEXT) {
-            const int prow = 16 * batch;
-            if ((size_t)(4 * prow + batch) > s->h_stage_ints - 8) return fail(WLX_ERR_ARG, "batch too large");
-            CK(hipStreamSynchronize(st));                        // the shared staging may still feed an earlier pass's copies
-            int* h = s->h_stage;
-            for (int b = 0; b < batch; ++b) {
-                const int32_t* pr = prompts + (size_t)b * pstride;
-                const int np_ = pl[b] - 1;                          // prompt rows of this item (0: a lone start token — the group idles on row 0's token at position 0... of a valid cache row)
-                for (int i = 0; i < 16; ++i) {
-                    const int j = np_ > 0 ? std::min(i, np_ - 1) : 0;
-                    h[b * 16 + i] = pr[j]; h[prow + b * 16 + i] = j; h[2 * prow + b * 16 + i] = b * R; h[3 * prow + b * 16 + i] = b * R;
-                }
-                h[4 * prow + b] = enc_items ? enc_items[b] : b;
-            }
+        if (joint && batch > 1 && with_prompt > 1 && longest <= 16 && s->pf_ok && !s->align && !s->prof && !g_decode_v1) {
+            // (the prefill working set holds WLX_T_TEXT rows = 28 items of 16 rows: a wider batch, round 5, goes in blocks of 28 items)
+            const int IB = WLX_T_TEXT / 16;
             const Slot::DecBufs& pb = s->pf;
-            CK(hipMemcpyAsync(pb.d_token, h, prow * 4, hipMemcpyHostToDevice, st));
-            CK(hipMemcpyAsync(pb.d_pos, h + prow, prow * 4, hipMemcpyHostToDevice, st));
-            CK(hipMemcpyAsync(pb.d_cache, h + 2 * prow, prow * 4, hipMemcpyHostToDevice, st));
-            CK(hipMemcpyAsync(pb.d_ancrow, h + 3 * prow, prow * 4, hipMemcpyHostToDevice, st));
-            CK(hipMemcpyAsync(pb.d_group_item, h + 4 * prow, batch * 4, hipMemcpyHostToDevice, st));
-            s->anc_ident = false;
-            decoder_pass(e, s, prow, 16, batch, false, false, &pb);
-            CK(hipGetLastError());
             const int d = e->spec.d_model;
-            for (int b = 0; b < batch; ++b) {
-                if (!(sot_at[b] >= 0 && sot_at[b] < pl[b] - 1)) continue;
-                GemvParams p{};
-                p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_F32; p.M = 1; p.K = d; p.KT = d / 32; p.N = V;
-                p.Wp = e->Wvocab; p.bias = nullptr; p.X = pb.xd + (size_t)(b * 16 + sot_at[b]) * d; p.ldx = d; p.gamma = e->dec_ln_g; p.beta = e->dec_ln_b;
-                p.Y = s->logits; p.ldy = s->ldl; p.qscale = 1.f; p.xsrc = GEMV_X_PLAIN;
-                launch_dec_gemv(p, st);
-                launch_token_prob(s->logits, s->ldl, V, 1, o->ids.no_speech, s->d_tokprob, st);
-                CK(hipMemcpyAsync(S.no_speech + b, s->d_tokprob, 4, hipMemcpyDeviceToDevice, st));
+            for (int b0 = 0; b0 < batch; b0 += IB) {
+                const int nb = std::min(IB, batch - b0), prow = 16 * nb;
+                if ((size_t)(4 * prow + nb) > s->h_stage_ints - 8) return fail(WLX_ERR_ARG, "batch too large");
+                CK(hipStreamSynchronize(st));                        // the shared staging may still feed an earlier pass's copies
+                int* h = s->h_stage;
+                for (int bi = 0; bi < nb; ++bi) {
+                    const int b = b0 + bi;
+                    const int32_t* pr = prompts + (size_t)b * pstride;
+                    const int np_ = pl[b] - 1;                          // prompt rows of this item (0: a lone start token — the group idles on row 0's token at position 0... of a valid cache row)
+                    for (int i = 0; i < 16; ++i) {
+                        const int j = np_ > 0 ? std::min(i, np_ - 1) : 0;
+                        h[bi * 16 + i] = pr[j]; h[prow + bi * 16 + i] = j; h[2 * prow + bi * 16 + i] = b * R; h[3 * prow + bi * 16 + i] = b * R;
+                    }
+                    h[4 * prow + bi] = enc_items ? enc_items[b] : b;
+                }
+                CK(hipMemcpyAsync(pb.d_token, h, prow * 4, hipMemcpyHostToDevice, st));
+                CK(hipMemcpyAsync(pb.d_pos, h + prow, prow * 4, hipMemcpyHostToDevice, st));
+                CK(hipMemcpyAsync(pb.d_cache, h + 2 * prow, prow * 4, hipMemcpyHostToDevice, st));
+                CK(hipMemcpyAsync(pb.d_ancrow, h + 3 * prow, prow * 4, hipMemcpyHostToDevice, st));
+                CK(hipMemcpyAsync(pb.d_group_item, h + 4 * prow, nb * 4, hipMemcpyHostToDevice, st));
+                s->anc_ident = false;
+                decoder_pass(e, s, prow, 16, nb, false, false, &pb);
+                CK(hipGetLastError());
+                for (int bi = 0; bi < nb; ++bi) {
+                    const int b = b0 + bi;
+                    if (!(sot_at[b] >= 0 && sot_at[b] < pl[b] - 1)) continue;
+                    GemvParams p{};
+                    p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_F32; p.M = 1; p.K = d; p.KT = d / 32; p.N = V;
+                    p.Wp = e->Wvocab; p.bias = nullptr; p.X = pb.xd + (size_t)(bi * 16 + sot_at[b]) * d; p.ldx = d; p.gamma = e->dec_ln_g; p.beta = e->dec_ln_b;
+                    p.Y = s->logits; p.ldy = s->ldl; p.qscale = 1.f; p.xsrc = GEMV_X_PLAIN;
+                    launch_dec_gemv(p, st);
+                    launch_token_prob(s->logits, s->ldl, V, 1, o->ids.no_speech, s->d_tokprob, st);
+                    CK(hipMemcpyAsync(S.no_speech + b, s->d_tokprob, 4, hipMemcpyDeviceToDevice, st));
+                }
+                CK(hipGetLastError());
             }
-            CK(hipGetLastError());
         } else {
             for (int b = 0; b < batch; ++b) {
                 const int32_t* pr = prompts + (size_t)b * pstride;
@@ -1845,7 +1851,7 @@ extern "C" int32_t wlx_debug_time_decode_step(wlx_engine* e, int32_t slot, int32
     SlotGuard sg_;
     CKR(slot_acquire(e, slot, sg_));
     Slot* s = sg_.s;
-    if (rows < 1 || rows > s->cache_rows || rows > 64 || t < 0 || t >= WLX_T_TEXT || iters < 1 || !avg_ms_out)
+    if (rows < 1 || rows > s->cache_rows || rows > s->rows_cap || t < 0 || t >= WLX_T_TEXT || iters < 1 || !avg_ms_out)
         return fail(WLX_ERR_ARG, "bad arguments");
     if (rows > 16 && (rows % s->R != 0 || rows / s->R > s->B)) return fail(WLX_ERR_ARG, "more than 16 rows: a multiple of the slot's rows per item");
     if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "decode before encode");
@@ -1893,7 +1899,7 @@ extern "C" int32_t wlx_debug_trace_step(wlx_engine* e, int32_t slot, int32_t row
     SlotGuard sg_;
     CKR(slot_acquire(e, slot, sg_));
     Slot* s = sg_.s;
-    if (rows < 1 || rows > s->cache_rows || rows > 64 || t < 0 || t >= WLX_T_TEXT || !out || !names || !n_launches_out)
+    if (rows < 1 || rows > s->cache_rows || rows > s->rows_cap || t < 0 || t >= WLX_T_TEXT || !out || !names || !n_launches_out)
         return fail(WLX_ERR_ARG, "bad arguments");
     if (rows > 16 && (rows % s->R != 0 || rows / s->R > s->B)) return fail(WLX_ERR_ARG, "more than 16 rows: a multiple of the slot's rows per item");
     if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "decode before encode");
@@ -1953,7 +1959,7 @@ extern "C" int32_t wlx_debug_profile_step(wlx_engine* e, int32_t slot, int32_t r
     SlotGuard sg_;
     CKR(slot_acquire(e, slot, sg_));
     Slot* s = sg_.s;
-    if (rows < 1 || rows > s->cache_rows || rows > 64 || t < 0 || t >= WLX_T_TEXT || iters < 1 || !out || !n_out || cap < 1)
+    if (rows < 1 || rows > s->cache_rows || rows > s->rows_cap || t < 0 || t >= WLX_T_TEXT || iters < 1 || !out || !n_out || cap < 1)
         return fail(WLX_ERR_ARG, "bad arguments");
     if (rows > 16 && (rows % s->R != 0 || rows / s->R > s->B)) return fail(WLX_ERR_ARG, "more than 16 rows: a multiple of the slot's rows per item");
     if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "decode before encode");

@@ -45,7 +45,7 @@ from .serve_client import ServeClientBase, ServeClientHIP
 from .sharding import assign_gpu
 from .ws import ConnectionClosed
 
-MAX_BEAM5_BATCH = 12        # clips per batched decode: 64 beam rows per engine slot / 5 beams (include/wlx.h wlx_slot_create)
+MAX_SLOT_BATCH = 64         # clips one engine slot encodes and decodes together (include/wlx.h wlx_slot_create: 64 items x 5 beams = 320 rows)
 
 END_OF_AUDIO = b"END_OF_AUDIO"      # whisper_live/server.py:376, client.py:23
 AUDIO_FORMATS = ("float32", "int16", "uint8")
@@ -358,12 +358,12 @@ class TranscriptionServer:
             single_model = True                       # batching needs the shared per-GPU transcriber
             if batch_lanes < 1:
                 raise ValueError(f"batch_lanes must be >= 1, got {batch_lanes}")
-            if batch_max_size > MAX_BEAM5_BATCH:
-                # one engine slot decodes at most 64 beam rows per step (include/wlx.h wlx_slot_create): 12 clips x beam 5. A wider
-                # slot would hold fewer than 5 rows per clip and every beam-5 decode on it would be refused.
-                logging.warning(f"--batch_max_size {batch_max_size}: a batch decodes at most {MAX_BEAM5_BATCH} clips x 5 beams per step on this "
-                                f"backend; using {MAX_BEAM5_BATCH} (more lanes, --batch_lanes, are how further clips overlap)")
-                batch_max_size = MAX_BEAM5_BATCH
+            if batch_max_size > MAX_SLOT_BATCH:
+                # the reference takes any max_batch_size (batch_inference.py:113-121); here one engine slot holds 64 clips x 5 beams
+                # (round 5: it was 12 clips). Beyond that further clips overlap through --batch_lanes.
+                logging.warning(f"--batch_max_size {batch_max_size}: one batch holds at most {MAX_SLOT_BATCH} clips on this backend; using "
+                                f"{MAX_SLOT_BATCH} (more lanes, --batch_lanes, are how further clips overlap)")
+                batch_max_size = MAX_SLOT_BATCH
             self.batch_config = {"max_batch_size": batch_max_size, "batch_window_ms": batch_window_ms}   # (the reference's two keys)
             self.batch_lanes = int(batch_lanes)
             logging.info(f"Batch inference enabled (max_batch={batch_max_size}, window={batch_window_ms}ms, lanes={batch_lanes})")

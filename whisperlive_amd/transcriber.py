@@ -159,7 +159,7 @@ class FeatureExtractorHIP:
 class _EngineModel:
     """The ctranslate2.models.Whisper surface the reference calls."""
 
-    MAX_LEAN_ROWS = 64      # rows one decode step of the lean kernels covers (csrc/decoder.hip gemv_chunked: 16-row tiles up to 64 rows since round 4; was 48)
+    MAX_DEC_ROWS = 320      # decoder rows one step covers (csrc/decoder.h WLX_MAX_DEC_ROWS: 16-row tiles; 64 until round 5, 48 until round 4)
 
     def __init__(self, owner: "WhisperModelHIP"):
         self._o = owner
@@ -196,16 +196,18 @@ class _EngineModel:
             sup = [t for t in sup if t >= 0] + list(o._base_tokenizer.non_speech_tokens)
         # CT2's generate defaults: beam_size > 1 -> beam search; beam_size == 1 -> sampling with top-k / temperature.
         temp = 0.0 if beam_size > 1 else (float(sampling_temperature) if sampling_topk != 1 else 0.0)
-        # The lean decode kernels (decoder.hip dec_gemv2_kernel) cover 64 beam rows per step (16-row tiles; 48 until round 4 — a 12-item
-        # beam-5 batch was then decoded as 9 + 3 items, which is what made `--batch_max_size 12` slower than 8 through the worker); a wider
-        # batch would fall back to the general first-generation kernels, ~3x slower per step. Decode such a batch as consecutive groups
-        # over the SAME resident encoder output (item maps): identical results, every launch on the fast path.
+        # One decode step covers every row the slot holds (max_batch x rows per item <= 320 since round 5; it was 64 rows — 12 clips at
+        # beam 5 — and wider batches were cut into groups). A call that brings more rows than the slot (a duck-typed slot, a decode with
+        # fewer rows per item than the slot was sized for) is still decoded as consecutive groups over the SAME resident encoder output
+        # (item maps): identical results.
         rows_per_item = max(1, beam_size if (beam_size > 1 and temp == 0.0) else num_hypotheses)
         slot_rows = getattr(slot, "rows", None)
         if isinstance(slot_rows, int) and rows_per_item > slot_rows:
-            raise ValueError(f"this transcriber's slots hold {slot_rows} decoder rows per audio item (max_batch={o.max_batch}: 64 rows per slot), "
-                             f"the decode asks for {rows_per_item} (beam_size / num_hypotheses): use max_batch <= {64 // rows_per_item}")
-        group = max(1, self.MAX_LEAN_ROWS // rows_per_item)
+            raise ValueError(f"this transcriber's slots hold {slot_rows} decoder rows per audio item (max_batch={o.max_batch}), "
+                             f"the decode asks for {rows_per_item} (beam_size / num_hypotheses)")
+        slot_items = getattr(slot, "max_batch", None)
+        cap_rows = slot_rows * slot_items if isinstance(slot_rows, int) and isinstance(slot_items, int) else 64
+        group = max(1, min(self.MAX_DEC_ROWS, max(cap_rows, rows_per_item)) // rows_per_item)
         items = encoder_output.items if encoder_output.items is not None else list(range(encoder_output.batch))
         res = []
         for a in range(0, len(prompts), group):
@@ -371,7 +373,8 @@ class WhisperModelHIP:
                 if s is not None:
                     s._owner = me
             if s is None:
-                s = self.engine.create_slot(self.max_batch, 5 if self.max_batch <= 12 else max(1, 64 // self.max_batch))
+                # (5 rows per item = the reference's beam_size / best_of; the engine takes up to 64 items x 5 rows per slot)
+                s = self.engine.create_slot(self.max_batch, 5)
                 s._enc_generation = 0
                 s._owner = me
                 with self._slots_lock:
