@@ -29,6 +29,8 @@ def usable_cpus(cap: int = 16) -> int:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # hermetic: artefact look-ups (whisperlive_amd/artifacts.py) may read caches but never start a download from inside the test suite
+    os.environ.setdefault("WLX_NO_DOWNLOAD", "1")
     try:                                   # the CPU oracle (torch fp32) on the cores this container really has
         import torch
         torch.set_num_threads(usable_cpus())

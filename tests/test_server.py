@@ -407,6 +407,9 @@ def test_e2e_four_clients_shard_over_devices_and_batch_workers(running_server):
         assert _recv_json(c)["message"] == "SERVER_READY"
         conns.append(c)
     assert sorted(made) == [0, 1]                              # one transcriber (one weights replica) per GPU
+    deadline = time.time() + 5                                 # (SERVER_READY leaves the session's constructor; the manager registers it right after)
+    while len(srv.client_manager.clients) < 4 and time.time() < deadline:
+        time.sleep(0.01)
     devs = sorted(cl.device_index for cl in srv.client_manager.clients.values())
     assert devs == [0, 0, 1, 1]
     for c in conns:

@@ -373,7 +373,7 @@ class ServeClientHIP(ServeClientBase):
     def create_model(model: str, device_index: int, max_batch: int = 1):
         from .transcriber import WhisperModelHIP
         return WhisperModelHIP(model, device="cuda", device_index=device_index, compute_type="float16",
-                               max_batch=max(1, min(int(max_batch), 12)))
+                               max_batch=max(1, min(int(max_batch), 64)))
 
     def set_language(self, info):
         if info.language_probability > 0.5:

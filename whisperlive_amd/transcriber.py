@@ -263,8 +263,9 @@ class _EngineModel:
 
 
 class WhisperModelHIP:
-    """See module docstring. `model_size_or_path`: a Hugging Face Whisper checkpoint directory (model.safetensors +
-    tokenizer.json [+ preprocessor_config.json]) or, with `weights=`/`hf_tokenizer=`, just an identifier."""
+    """See module docstring. `model_size_or_path`: a CTranslate2 / Hugging Face Whisper checkpoint directory (model.bin or
+    model.safetensors + tokenizer.json [+ preprocessor_config.json]), a size name or hub id resolved like the reference's
+    (whisperlive_amd/artifacts.py: cache first, download where allowed) or, with `weights=`/`hf_tokenizer=`, just an identifier."""
 
     def __init__(self, model_size_or_path: str = "small.en", device: str = "cuda", device_index: int = 0,
                  compute_type: str = "float16", *, weights: Optional[Dict[str, np.ndarray]] = None,
@@ -281,9 +282,12 @@ class WhisperModelHIP:
         else:
             if weights is None:
                 if not os.path.isdir(model_size_or_path):
-                    raise FileNotFoundError(
-                        f"'{model_size_or_path}' is not a model directory: no network in this deployment — pass a local "
-                        "CTranslate2 (model.bin) or Hugging Face (model.safetensors) Whisper directory, or weights=/spec=")
+                    # a size name or hub id, as the reference accepts them (transcriber_faster_whisper.py:620-632,
+                    # faster_whisper_backend.py:133-178): cache first, download where allowed — raises FileNotFoundError
+                    # (ArtifactNotFound) with every place looked at
+                    from .artifacts import resolve_model
+                    model_size_or_path = resolve_model(model_size_or_path, download_root=_ignored.get("download_root"),
+                                                       local_files_only=_ignored.get("local_files_only"))
                 from .weights import load_model_dir
                 weights = load_model_dir(model_size_or_path)      # CTranslate2 model.bin or Hugging Face safetensors
             self.spec = spec or spec_from_state_dict(weights)

@@ -204,24 +204,37 @@ def get_default_model(device: Optional[int] = None) -> Callable[[np.ndarray], np
         if dev in _device_models:
             return _device_models[dev]
         if _default_weights is None:
-            npz = os.environ.get("WLX_SILERO_VAD_NPZ")
-            path = os.environ.get("WLX_SILERO_VAD_ONNX")
-            if npz and os.path.isfile(npz):
-                _default_weights = load_silero_npz(npz)
-                logging.info("VAD: Silero (HIP) from %s", npz)
-            elif path and os.path.isfile(path):
-                from .silero_export import silero_weights_from_onnx
-                _default_weights = check_silero_weights(silero_weights_from_onnx(path))
-                logging.info("VAD: Silero (HIP) from %s", path)
-            elif os.environ.get("WLX_ALLOW_VAD_STANDIN") == "1":
+            # where the reference finds its detector (whisperlive_amd/artifacts.py): the two variables, the reference's own cache file
+            # ~/.cache/whisper-live/silero_vad.onnx (whisper_live/vad.py:112-128), the ONNX inside an installed faster-whisper wheel,
+            # then a first-use download to that cache path where the deployment allows one. A file that is not the Silero network
+            # (unknown layer stack) is skipped with a warning, not trusted.
+            from . import artifacts
+            cands = artifacts.silero_candidates()
+            if not cands and artifacts.downloads_allowed():
+                got = artifacts.download_silero()
+                if got:
+                    cands = [("onnx", got)]
+            for kind, path in cands:
+                try:
+                    if kind == "npz":
+                        _default_weights = load_silero_npz(path)
+                    else:
+                        from .silero_export import silero_weights_from_onnx
+                        _default_weights = check_silero_weights(silero_weights_from_onnx(path))
+                    logging.info("VAD: Silero (HIP) from %s", path)
+                    break
+                except Exception as e:  # noqa: BLE001 — an unreadable / different file: try the next place
+                    logging.warning("VAD: %s is not a usable Silero VAD file (%s: %s)", path, type(e).__name__, e)
+            if _default_weights is None and os.environ.get("WLX_ALLOW_VAD_STANDIN") == "1":
                 logging.warning("VAD: WLX_ALLOW_VAD_STANDIN=1 — using the energy-gate stand-in, which is NOT the reference's "
                                 "speech detector (set WLX_SILERO_VAD_ONNX / WLX_SILERO_VAD_NPZ or pass --vad_weights)")
                 _default_model = EnergyGateModel()
                 return _default_model
-            else:
+            if _default_weights is None:
                 raise VadUnavailable(
-                    "use_vad needs Silero VAD weights: set WLX_SILERO_VAD_ONNX (the silero_vad.onnx the reference downloads) or "
-                    "WLX_SILERO_VAD_NPZ, pass --vad_weights to the server, or opt into the energy-gate stand-in with "
+                    "use_vad needs Silero VAD weights: none found in WLX_SILERO_VAD_ONNX / WLX_SILERO_VAD_NPZ, "
+                    "~/.cache/whisper-live/silero_vad.onnx (the file the reference downloads) or an installed faster_whisper / silero_vad "
+                    "package, and no download was possible; pass --vad_weights to the server, or opt into the energy-gate stand-in with "
                     "WLX_ALLOW_VAD_STANDIN=1")
         _device_models[dev] = SileroHIPModel(_default_weights, dev)
         return _device_models[dev]
