@@ -65,56 +65,77 @@ def decode_step_bytes(spec, beams: int, t: int) -> int:
     return 2 * (L * (6 * d * d + 2 * d * F) + V * d) + 2 * L * 2 * T * d + 2 * L * 2 * t * d * beams
 
 
-def pmc_traffic(kernel_name: str):
-    """HBM bytes per launch of `kernel_name` from the newest committed rocprofv3 --pmc FETCH_SIZE pass
-    (profiles/*_pmc_fetch_summary.csv, scripts/gpu_round.sh; its own run, as the MI355X guide prescribes). FETCH_SIZE is
-    reported in KiB and, on gfx950, counts half the bytes of wide coalesced reads: x 1024 x 2. None if no pass is on file."""
-    import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_fetch_summary.csv")))
-    for path in reversed(files):
+class pinned_threads:
+    """torch on exactly `n` threads, the process pinned to the first `n` CPUs it may use (restored on exit): the 16-thread figure moved
+    2.5x between rounds with the host's other load (3.2 / 7.0 / 8.0 xRT for the same code) — unpinned threads migrate."""
+
+    def __init__(self, n: int):
+        self.n, self.old_aff, self.old_thr = n, None, None
+
+    def __enter__(self):
+        import torch
+        self.old_thr = torch.get_num_threads()
+        torch.set_num_threads(self.n)
         try:
-            with open(path, newline="") as f:
-                for row in csv.DictReader(f):
-                    if kernel_name in row["kernel"] and row["counter"] == "FETCH_SIZE":
-                        return float(row["mean_per_launch"]) * FETCH_KIB_TO_BYTES, os.path.relpath(path, ROOT)
-        except (OSError, KeyError, ValueError):
-            continue
-    return None, None
+            self.old_aff = os.sched_getaffinity(0)
+            os.sched_setaffinity(0, set(sorted(self.old_aff)[: self.n]))
+        except (AttributeError, OSError):
+            self.old_aff = None
+        return self
+
+    def __exit__(self, *exc):
+        import torch
+        if self.old_aff is not None:
+            try:
+                os.sched_setaffinity(0, self.old_aff)
+            except OSError:
+                pass
+        torch.set_num_threads(self.old_thr)
+        return False
 
 
-def cpu_baseline(spec, weights, pcm, ids, decode_steps: int, full_steps: int, threads: int):
-    """The CPU oracle (numpy log-mel + torch-fp32 network + numpy beam search) on a BOUNDED sample of the same
-    workload: the whole front-end and encoder of one 30 s window, but only `decode_steps` of the `full_steps`
-    beam-5 decode steps; the decode time is scaled to `full_steps` (per-step cost is flat in t at this length).
-    Evaluated on the engine's fp16-rounded weights, so its tokens are also the parity reference of the timed path
-    (`parity_prefix`). Returns (baseline dict, generated tokens of the bounded decode)."""
-    import torch
-
+def cpu_baseline(spec, weights, pcm, ids, decode_steps: int, full_steps: int, threads: int, repeats: int = 1, int8: str = None):
+    """The CPU oracle (numpy log-mel + torch network + numpy beam search) on a BOUNDED sample of the same workload: the whole
+    front-end and encoder of one 30 s window and `decode_steps` of the `full_steps` beam-5 decode steps (the decode time is scaled
+    to `full_steps` when fewer are run; per-step cost is flat in t at this length), `repeats` times on pinned threads — the
+    MEDIAN window time is reported. int8 = "fbgemm": every linear layer as torch's dynamic-quantised int8 Linear (kind
+    "port-int8": the arithmetic class of the reference's CPU default, CTranslate2 int8, faster_whisper_backend.py:93 — CT2 itself
+    cannot be installed offline). Evaluated on the engine's fp16-rounded weights, so the fp32 tokens are also the parity reference
+    of the timed path (`parity_prefix`). Returns (baseline dict, generated tokens of the last bounded decode)."""
     from oracle import decoding as odec
     from oracle import logmel as olm
     from oracle import model as omodel
     from oracle.provider import NetProvider
 
-    torch.set_num_threads(threads)
-    oracle = omodel.WhisperOracle(omodel.Spec(spec.n_mels, spec.d_model, spec.n_heads, spec.enc_layers, spec.dec_layers,
-                                              spec.ffn, spec.vocab), weights)
-    t0 = time.perf_counter()
-    feats = olm.log_mel_spectrogram(pcm, spec.n_mels, precise=False)
-    t1 = time.perf_counter()
-    enc = oracle.encode(olm.pad_or_trim(feats[:, :-1])[None])
-    t2 = time.perf_counter()
-    o = odec.GenOptions(ids=odec.TokenIds(**ids), beam_size=5, patience=1.0, max_length=1 + decode_steps,
-                        suppress_tokens=suppress_list(ids, True))
-    res = odec.generate(NetProvider(oracle, enc), [ids["sot"]], o)
-    t3 = time.perf_counter()
-    per_step = (t3 - t2) / max(1, res.steps)
-    est = (t1 - t0) + (t2 - t1) + per_step * full_steps
-    return dict(value=WINDOW_S / est, unit="xRT (audio s / wall s)", cores=threads, kind="port",
-                sample=f"one 30 s window: numpy log-mel {t1 - t0:.2f} s + torch-fp32 encoder {t2 - t1:.2f} s measured in full; "
-                       f"beam-5 decode measured for {res.steps} steps ({per_step * 1e3:.0f} ms/step) and scaled to {full_steps} steps; "
-                       f"{t3 - t0:.1f} s of CPU work on {threads} thread{'s' if threads != 1 else ''}. CTranslate2-int8 (the reference's "
-                       f"CPU backend) cannot be installed offline, so this is the repo's own fp32 port"), res.sequences_ids[0]
+    with pinned_threads(threads):
+        oracle = omodel.WhisperOracle(omodel.Spec(spec.n_mels, spec.d_model, spec.n_heads, spec.enc_layers, spec.dec_layers,
+                                                  spec.ffn, spec.vocab), weights, int8=int8)
+        ests, parts, res = [], [], None
+        for _ in range(max(1, repeats)):
+            t0 = time.perf_counter()
+            feats = olm.log_mel_spectrogram(pcm, spec.n_mels, precise=False)
+            t1 = time.perf_counter()
+            enc = oracle.encode(olm.pad_or_trim(feats[:, :-1])[None])
+            t2 = time.perf_counter()
+            o = odec.GenOptions(ids=odec.TokenIds(**ids), beam_size=5, patience=1.0, max_length=1 + decode_steps,
+                                suppress_tokens=suppress_list(ids, True))
+            res = odec.generate(NetProvider(oracle, enc), [ids["sot"]], o)
+            t3 = time.perf_counter()
+            per_step = (t3 - t2) / max(1, res.steps)
+            ests.append((t1 - t0) + (t2 - t1) + per_step * full_steps)
+            parts.append((t1 - t0, t2 - t1, per_step, res.steps, t3 - t0))
+    order = sorted(range(len(ests)), key=lambda i: ests[i])
+    mid = order[len(order) // 2]
+    lm, en, per_step, nst, tot = parts[mid]
+    arith = "torch-fp32" if int8 is None else "torch dynamic-int8 (fbgemm) linears, fp32 elsewhere"
+    scaled = "measured in full" if nst >= full_steps else f"measured for {nst} steps and scaled to {full_steps}"
+    return dict(value=WINDOW_S / ests[mid], unit="xRT (audio s / wall s)", cores=threads, kind="port" if int8 is None else "port-int8",
+                runs=len(ests), window_s_all_runs=[round(e, 3) for e in ests],
+                spread=(max(ests) - min(ests)) / ests[mid],
+                sample=f"one 30 s window, median of {len(ests)} run{'s' if len(ests) != 1 else ''} on {threads} pinned thread{'s' if threads != 1 else ''}: "
+                       f"numpy log-mel {lm:.2f} s + {arith} encoder {en:.2f} s measured in full; beam-5 decode {per_step * 1e3:.0f} ms/step, {scaled}; "
+                       f"{sum(p[4] for p in parts):.1f} s of CPU work in total. CTranslate2-int8 (the reference's CPU backend) cannot be installed "
+                       f"offline, so this is the repo's own port"), res.sequences_ids[0]
 
 
 def usable_cpus(cap: int = 16) -> int:
@@ -190,16 +211,60 @@ def measured_traffic(kernel_name: str, model: str, timeout_s: int = 300, child_a
         extra = {"raw_fetch_size_kib_per_launch": tot / n, "kib_to_bytes_factor_used": FETCH_KIB_TO_BYTES}
         from whisperlive_amd.specs import get_spec
         sp = get_spec(model)
-        # calibration: the largest-fetch DECODE projection of the pass is the vocabulary projection (V x d fp16, read once per
-        # launch; the other dec_gemv2 launches stream 1-13 MB)
-        gem = {k: v for k, v in per.items() if "dec_gemv2_kernel" in k} or per
-        big = max(gem.items(), key=lambda kv: kv[1][0] / kv[1][1])
+        # calibration inside the SAME pass: the vocabulary projection (dec_vocab_kernel since round 4) streams its V x d fp16 weight image
+        # exactly once per launch and nothing else of size, so known bytes / (raw KiB x 1024) must come out at ~2.0 for the
+        # x 1024 x 2 conversion to hold on this box. Outside [1.8, 2.2] the converted figure is NOT reported (traffic = null + why).
+        voc = {k: v for k, v in per.items() if "dec_vocab_kernel" in k}
+        if not voc:
+            extra["calibration"] = {"error": "no dec_vocab_kernel rows in the pass"}
+            return None, "FETCH_SIZE factor not calibrated: no dec_vocab_kernel launch in the counter pass", extra
+        big = max(voc.items(), key=lambda kv: kv[1][1])
         raw_big = big[1][0] / big[1][1]
-        extra["calibration"] = {"kernel": big[0][:80], "raw_kib_per_launch": raw_big, "known_bytes": 2.0 * sp.vocab * sp.d_model,
-                                "bytes_per_raw_kib_over_1024": 2.0 * sp.vocab * sp.d_model / (raw_big * 1024.0)}
+        known = 2.0 * sp.vocab * sp.d_model
+        factor = known / (raw_big * 1024.0)
+        extra["calibration"] = {"kernel": big[0][:80], "launches": big[1][1], "raw_kib_per_launch": raw_big, "known_bytes": known,
+                                "bytes_per_raw_kib_over_1024": factor, "accepted_range": [1.8, 2.2]}
+        if not 1.8 <= factor <= 2.2:
+            return None, (f"FETCH_SIZE factor calibrated at {factor:.2f} on {big[0][:40]} — outside [1.8, 2.2]: the x1024x2 conversion "
+                          f"does not hold in this pass, traffic withheld"), extra
         return tot / n * FETCH_KIB_TO_BYTES, f"rocprofv3 --pmc FETCH_SIZE pass of this run ({int(n)} launches)", extra
     except Exception as e:  # noqa: BLE001 — the headline line must survive a failed counter pass
         return None, f"{type(e).__name__}: {e}", {}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
+def rocprof_kernel_avg(kernel_name: str, model: str, timeout_s: int = 240, child_args=()):
+    """Average duration (us) of `kernel_name` from a `rocprofv3 --kernel-trace --stats` pass of the SAME child workload as
+    measured_traffic() (no counters in this pass), so that roofline.frac can be reproduced from a rocprofv3 summary without the
+    HIP-event vs. profiler ambiguity: returns (avg_us, calls, source) or (None, 0, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if rp is None:
+        return None, 0, "rocprofv3 not found"
+    d = tempfile.mkdtemp(prefix="wlx_kt_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [rp, "--kernel-trace", "--stats", "-d", d, "-o", "wlx", "--output-format", "csv", "--",
+           sys.executable, os.path.abspath(__file__), "--pmc-child", "--model", model] + list(child_args)
+    try:
+        proc = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+        for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
+            with open(f, newline="") as fh:
+                for r in csv.DictReader(fh):
+                    if kernel_name in r["Name"]:
+                        keep = os.path.join(ROOT, "gpurun_out")
+                        if os.path.isdir(keep):
+                            shutil.copy(f, os.path.join(keep, "bench_kernel_stats.csv"))
+                        return float(r["AverageNs"]) / 1e3, int(r["Calls"]), "rocprofv3 --kernel-trace --stats pass of this run"
+        return None, 0, f"no kernel_stats row for {kernel_name} (rocprofv3 rc {proc.returncode}: {proc.stderr[-200:]})"
+    except Exception as e:  # noqa: BLE001
+        return None, 0, f"{type(e).__name__}: {e}"
     finally:
         shutil.rmtree(d, ignore_errors=True)
 
@@ -423,7 +488,7 @@ def config5(args, rank, world, local, dist, torch):
     spec = get_spec(args.model)
     eng = HipWhisperEngine(spec, random_weights(spec, seed=0), device=local)
     ids = token_ids(spec.vocab)
-    MB = max(1, min(12, args.max_batch))
+    MB = max(1, min(64, args.max_batch))
     tr = make_bench_transcriber(eng, spec, ids, args.decode_steps, vad_model=None, max_batch=MB)
     BatchInferenceWorker.TEMPERATURES = (0.0,)
     worker = BatchInferenceWorker(tr, max_batch_size=MB, batch_window_ms=50, lanes=max(1, args.lanes))
@@ -518,12 +583,11 @@ def config5(args, rank, world, local, dist, torch):
         print(json.dumps(out))
 
 
-def throughput_leg(eng, spec, olm, torch, ids, eids, gen_kw, decode_steps):
+def throughput_leg(eng, spec, olm, torch, ids, eids, gen_kw, decode_steps, TS=4, TB=12, tsteps=3):
     """The throughput configuration of ONE GPU, timed by the same driver run (VERDICT r03 task 5): 4 slots on their own hardware
     queues x 12 windows batched into every decode — what a --batch_inference server with four lanes runs. Called after
     the headline's own slot is closed: a fifth live slot would send every slot back to the shared queue pool."""
     from concurrent.futures import ThreadPoolExecutor
-    TS, TB, tsteps = 4, 12, 3
     tslots = [eng.create_slot(TB, 5) for _ in range(TS)]
     try:
         for i, sl in enumerate(tslots):
@@ -552,8 +616,8 @@ def throughput_leg(eng, spec, olm, torch, ids, eids, gen_kw, decode_steps):
                     ms_per_step=1e3 * twall / tsteps, windows_per_step=TS * TB,
                     stage_ms_slot0=tm12, encode_ms_one_slot=enc12,
                     encoder_frac_of_mfma_peak=encoder_flops(spec) * TB / (enc12 * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
-                    decode_step_60rows_ms=step12,
-                    note="aggregate of 4 concurrent slots (own hardware queues) x 12 windows batched per decode, 64 tokens each; "
+                    decode_step_rows=5 * TB, decode_step_ms=step12,
+                    note=f"aggregate of {TS} concurrent slots (own hardware queues) x {TB} windows batched per decode, {decode_steps} tokens each; "
                          "engine-level (PCM resident in HBM), no server / VAD in this leg")
     finally:
         for sl in tslots:
@@ -584,10 +648,11 @@ def main():
                          "30 s clips, Whisper-large-v3 shapes, one BatchInferenceWorker(max_batch_size=8) per GPU, clips "
                          "sharded in contiguous blocks, ONE all_gather of 2 KiB result records over RCCL")
     ap.add_argument("--clips", type=int, default=64, help="--config 5: number of 30 s clips per step")
-    ap.add_argument("--max-batch", type=int, default=8, help="--config 5: max_batch_size of the BatchInferenceWorker (8 = the reference's default, batch_inference.py:100; up to 12 = 60 decoder rows)")
+    ap.add_argument("--max-batch", type=int, default=8, help="--config 5: max_batch_size of the BatchInferenceWorker (8 = the reference's default, batch_inference.py:100; up to 64 clips x 5 beams = 320 decoder rows since round 5)")
     ap.add_argument("--lanes", type=int, default=4, help="--config 5: lanes of the BatchInferenceWorker (1 = the reference's single worker thread, 2 = the library default; measured 1086 / 1513 / 1618 / 1708 xRT at 1 / 2 / 3 / 4 lanes, profiles/r3k_*, r3d_*)")
     ap.add_argument("--free-run", action="store_true", help="--streams S: every stream runs its steps back to back, started 1/S of a step apart, instead of a barrier per step")
-    ap.add_argument("--no-throughput", action="store_true", help="skip the 4-stream x 12-window throughput leg of the default run")
+    ap.add_argument("--no-throughput", action="store_true", help="skip the throughput leg of the default run")
+    ap.add_argument("--throughput-shape", default="4x12", help="throughput leg: SLOTSxWINDOWS batched per decode (4x12 = the round-4 shape; 2x24, 1x48 since the 64-row cap was lifted)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 FETCH_SIZE pass that fills roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--ws-client", default=None, help=argparse.SUPPRESS)
@@ -753,11 +818,11 @@ def main():
             roof["traffic"], roof["traffic_source"], roof["traffic_detail"] = measured_traffic(
                 dom["name"], args.model, child_args=["--batch", str(B)] if B > 1 else ())
             note(f"traffic: {roof['traffic']} ({roof['traffic_source']}) {roof['traffic_detail'].get('calibration')}")
-        if roof["traffic"] is None:
-            why = roof.get("traffic_source")
-            roof["traffic"], roof["traffic_source"] = pmc_traffic(dom["name"])
-            if roof["traffic"] is not None:
-                roof["traffic_source"] = f"committed pass {roof['traffic_source']} (live pass unavailable: {why})"
+            note("rocprofv3 --kernel-trace --stats pass")
+            ravg, rcalls, rsrc = rocprof_kernel_avg(dom["name"], args.model, child_args=["--batch", str(B)] if B > 1 else ())
+            roof["rocprof_avg_us"], roof["rocprof_calls"], roof["rocprof_source"] = ravg, rcalls, rsrc
+            if ravg:
+                roof["frac_rocprof"] = dom["bytes_per_launch"] / (ravg * 1e-6) / 1e9 / HBM_PEAK_GBS
         # the one launch of the step that is bandwidth- rather than latency-sized: the vocabulary projection (80 MB)
         big = max(prof, key=lambda k: k["bytes_per_launch"])
         roof["largest_launch"] = dict(kernel=big["name"], algorithmic_bytes=big["bytes_per_launch"], avg_us=big["avg_us"],
@@ -766,6 +831,10 @@ def main():
         step_us = sum(k["total_us"] for k in prof)
         step_graph_ms = slot.debug_time_decode_step(rows=prows, t=1 + args.decode_steps // 2, iters=50)
         sb = decode_step_bytes(spec, prows, 1 + args.decode_steps // 2) + 2 * spec.dec_layers * 2 * spec.n_audio_ctx * spec.d_model * (B - 1)
+        # the whole step next to its dominant kernel: algorithmic bytes of ALL launches of a step / the captured graph's replay time / peak
+        roof["step_frac"] = sb / (step_graph_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
+        roof["step_us"] = 1e3 * step_graph_ms
+        roof["step_algorithmic_bytes"] = sb
         out = {
             "metric": "real-time factor (xRT), Whisper-small 30 s window (p50 chunk latency in p50_chunk_latency_ms)",
             "value": xrt, "unit": "xRT (audio s / wall s)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -814,18 +883,23 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             # self-check first: the SAME bounded decode on the GPU (untimed), then on the CPU port; the common prefix of
             # the two token sequences travels with the line
-            kw32 = dict(gen_kw, max_length=1 + args.cpu_decode_steps)
             T0 = slot.logmel_resident(0)
             slot.encode(B, seek=[0] * B, seg=[min(T0 - 1, 3000)] * B)
-            gpu_toks = slot.generate([[ids["sot"]]] * B, eids, **kw32)[0].sequences_ids[0]
+            gpu_toks = slot.generate([[ids["sot"]]] * B, eids, **gen_kw)[0].sequences_ids[0]
             w16 = f16_rounded(weights)
             nproc = usable_cpus()
-            note(f"cpu baseline on {nproc} threads")
-            base, cpu_toks = cpu_baseline(spec, w16, pcm, ids, args.cpu_decode_steps, n_tok, threads=nproc)
+            note(f"cpu baseline on {nproc} threads (3 runs, {n_tok} steps each)")
+            base, cpu_toks = cpu_baseline(spec, w16, pcm, ids, n_tok, n_tok, threads=nproc, repeats=3)
             note("cpu baseline on 1 thread")
             one, _ = cpu_baseline(spec, w16, pcm, ids, max(4, args.cpu_decode_steps // 4), n_tok, threads=1)
             base["single_thread"] = {k: one[k] for k in ("value", "unit", "cores", "sample")}
             base["single_thread"]["note"] = "OMP_NUM_THREADS=1 is the reference server's default (run_server.py:36-39,118-119)"
+            note(f"cpu baseline, int8 linears, on {nproc} threads")
+            try:
+                q8, _ = cpu_baseline(spec, w16, pcm, ids, max(8, args.cpu_decode_steps // 2), n_tok, threads=nproc, int8="fbgemm")
+                base["int8"] = {k: q8[k] for k in ("value", "unit", "cores", "kind", "sample")}
+            except Exception as e:  # noqa: BLE001 — an extra figure; the fp32 port is the baseline of record
+                base["int8"] = {"error": f"{type(e).__name__}: {e}"}
             out["cpu_baseline"] = base
             n = 0
             while n < min(len(gpu_toks), len(cpu_toks)) and gpu_toks[n] == cpu_toks[n]:
@@ -838,9 +912,10 @@ def main():
     for sl in slots:
         sl.close()
     if rank == 0 and world == 1 and S == 1 and B == 1 and not args.no_throughput:
-        note("throughput leg (4 streams x 12 windows per decode)")
+        ts_, tb_ = (int(v) for v in args.throughput_shape.lower().split("x"))
+        note(f"throughput leg ({ts_} streams x {tb_} windows per decode)")
         try:
-            out["throughput"] = throughput_leg(eng, spec, olm, torch, ids, eids, gen_kw, args.decode_steps)
+            out["throughput"] = throughput_leg(eng, spec, olm, torch, ids, eids, gen_kw, args.decode_steps, TS=ts_, TB=tb_)
         except Exception as e:  # noqa: BLE001 — the headline line must survive a failure of this leg
             out["throughput"] = {"error": f"{type(e).__name__}: {e}"}
     eng.close()
