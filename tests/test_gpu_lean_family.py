@@ -199,6 +199,48 @@ def test_twelve_items_batched_equal_singles(fam):
     print(name, 60, _check(got, ref, f"{name} logits n=60"))
 
 
+def test_twentyfour_items_batched_equal_singles_and_120_rows(fam):
+    """Round 5 — the 64-row cap lifted (the reference's worker takes any max_batch_size, whisper_live/batch_inference.py:113-121): 24 clips x
+    5 beams = 120 decoder rows in ONE step — eight 16-row tiles per projection, the vocabulary projection in two row chunks (64 + 56),
+    item prompts prefilled in blocks — equal to each clip decoded alone; and 120 teacher-forced rows in one pass against the oracle."""
+    name, spec, eng, oracle, slot, enc = fam
+    ids = H.token_ids_for(spec.vocab)
+    kw = dict(beam_size=5, max_length=1 + 6, suppress_tokens=H.default_suppress(ids))
+    clips = [olm.speech_like_pcm(5.0, seed=21)] + [olm.speech_like_pcm(2.0 + 0.125 * i, seed=320 + i) for i in range(1, 24)]
+    singles = []
+    for c in clips:
+        T = slot.logmel(c); slot.encode(1, seek=[0], seg=[T - 1])
+        singles.append(slot.generate([[ids.sot]], H.engine_ids(ids), **kw)[0])
+    sb = eng.create_slot(24, 5)
+    try:
+        Ts = [sb.logmel(c, item=i) for i, c in enumerate(clips)]
+        sb.encode(24, seek=[0] * 24, seg=[t - 1 for t in Ts])
+        res = sb.generate([[ids.sot]] * 24, H.engine_ids(ids), **kw)
+        for i in range(24):
+            assert res[i].sequences_ids == singles[i].sequences_ids, (name, i)
+            assert abs(res[i].scores[0] - singles[i].scores[0]) < 2e-3
+        names = [k["name"] for k in sb.debug_profile_step(120, 4, 2)]
+        assert not any(n.startswith("dec_gemv_kernel<") for n in names), names          # every projection of the 120-row step on the lean kernels
+        # 120 teacher-forced rows of item 0 (= the fixture's clip) in ONE pass through the same row-tiled kernels
+        import os
+        old = os.environ.get("WLX_PREFILL_ROWS")
+        os.environ["WLX_PREFILL_ROWS"] = "120"
+        try:
+            toks = np.random.default_rng(120).integers(0, spec.vocab, size=120)
+            got = sb.debug_decode_logits(toks)
+        finally:
+            if old is None:
+                os.environ.pop("WLX_PREFILL_ROWS")
+            else:
+                os.environ["WLX_PREFILL_ROWS"] = old
+        ref = oracle.decode_logits(enc, toks[None])[0].numpy()
+        print(name, 120, _check(got, ref, f"{name} logits n=120"))
+    finally:
+        sb.close()
+    pcm = olm.speech_like_pcm(5.0, seed=21)
+    T = slot.logmel(pcm); slot.encode(1, seek=[0], seg=[T - 1])
+
+
 def test_busy_device_launch_shapes_give_identical_results(fam):
     """With three or more live slots on the device the engine captures a second step graph per slot whose row-tiled residual projections
     take two 16-column tiles per workgroup (work-saving shapes for a work-bound GPU: engine.hip device_is_busy, decoder.hip gemv2_cfg). The

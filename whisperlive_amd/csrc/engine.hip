@@ -342,6 +342,12 @@ static int engine_load(Engine* e, const wlx_tensor* weights, int n_weights) {
     return rc;
 }
 
+// The process holds device memory that PyTorch (or another runtime) manages — a weight tensor arrived with on_device = 1: the
+// embedder issues NULL-stream work of its own (engine.py itself converts weight tensors with torch on the device), and the CU-mask
+// constructor only builds BLOCKING streams, which synchronise implicitly with the NULL stream: a second engine loading while a slot
+// captures its step graph invalidates the capture (include/wlx.h). With no WLX_SLOT_CU_MASK in the environment such a process gets
+// ordinary non-blocking streams.
+static std::atomic<bool> g_embedded_device_memory{false};
 extern "C" int32_t wlx_engine_create(const wlx_spec* spec, const wlx_tensor* weights, int32_t n_weights,
                                      int32_t device, wlx_engine** out) {
     if (!spec || !weights || !out) return fail(WLX_ERR_ARG, "null argument");
@@ -362,6 +368,8 @@ extern "C" int32_t wlx_engine_create(const wlx_spec* spec, const wlx_tensor* wei
     e->spec = *spec;
     e->device = device;
     e->H = spec->n_heads;
+    for (int i = 0; i < n_weights; ++i)
+        if (weights[i].on_device) { g_embedded_device_memory.store(true); break; }
     const char* ng = getenv("WLX_NO_GRAPH");
     e->use_graph = !(ng && ng[0] == '1');
     const char* v1 = getenv("WLX_DECODE_V1");
@@ -385,11 +393,14 @@ static int max_dedicated_queues() {
 static std::atomic<int> g_dedicated_live[64];      // live slots with a hardware queue of their own, per device (create_slot_stream)
 static std::atomic<int> g_slots_live[64];          // live slots per device
 static std::atomic<bool> g_demote[64];             // more live slots than dedicated queues allowed: dedicated slots fall back at their next call
+static std::atomic<unsigned> g_promote_epoch[64];  // raised when g_demote falls: a shared-pool slot tries ONCE per epoch to take a queue of its own
 static void slot_free(Slot* s) {
     if (!s) return;
     if (s->device_of >= 0 && s->device_of < 64) {
         if (s->dedicated_queue) g_dedicated_live[s->device_of].fetch_sub(1);
-        if (s->counted && g_slots_live[s->device_of].fetch_sub(1) - 1 <= max_dedicated_queues()) g_demote[s->device_of].store(false);
+        if (s->counted && g_slots_live[s->device_of].fetch_sub(1) - 1 <= max_dedicated_queues()) {
+            if (g_demote[s->device_of].exchange(false)) g_promote_epoch[s->device_of].fetch_add(1);
+        }
     }
     if (s->align_scores) (void)hipFree(s->align_scores);
     for (auto& kv : s->graphs) (void)hipGraphExecDestroy(kv.second);
@@ -433,37 +444,48 @@ struct SlotGuard {
     ~SlotGuard() { if (s) s->call_mu.unlock(); }
 };
 static int create_slot_stream(int device, hipStream_t* out, bool* dedicated_out);
+static bool dedicated_streams_possible();
 static int slot_acquire(wlx_engine* e, int slot, SlotGuard& g) {
     if (!e) return fail(WLX_ERR_ARG, "null engine");
-    std::lock_guard<std::mutex> lk(e->mu);
-    if (slot < 0 || slot >= (int)e->slots.size() || !e->slots[slot]) return fail(WLX_ERR_ARG, "bad slot %d", slot);
-    Slot* s = e->slots[slot];
-    if (!s->call_mu.try_lock())
-        return fail(WLX_ERR_STATE, "slot %d is busy in another call (a slot serves one call at a time)", slot);
-    g.s = s;
+    Slot* s = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        if (slot < 0 || slot >= (int)e->slots.size() || !e->slots[slot]) return fail(WLX_ERR_ARG, "bad slot %d", slot);
+        s = e->slots[slot];
+        if (!s->call_mu.try_lock())
+            return fail(WLX_ERR_STATE, "slot %d is busy in another call (a slot serves one call at a time)", slot);
+        g.s = s;
+    }
+    // From here on the slot is ours (call_mu) and the engine mutex is released: a stream swap below waits for the slot's own
+    // stream, which must not keep other slots out of the library.
+    const int dv = s->device_of;
+    if (dv < 0 || dv >= 64) return WLX_OK;
     // more slots than dedicated hardware queues exist on this device now: give the queue back (see create_slot_stream: past
     // ~6 busy hardware queues everything collapses; eight ordinary streams over the shared pool run at 1883 xRT, eight with
     // four dedicated queues at 1145). The slot's captured graphs do not depend on the stream they were captured on.
-    if (s->dedicated_queue && s->device_of >= 0 && s->device_of < 64 && g_demote[s->device_of].load()) {
+    if (s->dedicated_queue && g_demote[dv].load()) {
         hipStream_t ns = nullptr;
-        if (hipSetDevice(s->device_of) == hipSuccess && hipStreamSynchronize(s->stream) == hipSuccess &&
+        if (hipSetDevice(dv) == hipSuccess && hipStreamSynchronize(s->stream) == hipSuccess &&
             hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) == hipSuccess) {
             (void)hipStreamDestroy(s->stream);
             s->stream = ns;
             s->dedicated_queue = false;
-            g_dedicated_live[s->device_of].fetch_sub(1);
+            g_dedicated_live[dv].fetch_sub(1);
         } else {
             (void)hipGetLastError();
         }
-    } else if (!s->dedicated_queue && s->counted && s->device_of >= 0 && s->device_of < 64 && !g_demote[s->device_of].load() &&
-               g_dedicated_live[s->device_of].load() < max_dedicated_queues()) {
+    } else if (!s->dedicated_queue && s->counted && !g_demote[dv].load() && dedicated_streams_possible() &&
+               s->promote_epoch != g_promote_epoch[dv].load() && g_dedicated_live[dv].load() < max_dedicated_queues()) {
         // ... and back: the device is down to <= WLX_DEDICATED_QUEUES live slots again (the fifth client left, a batch
         // lane was released) — a slot that was demoted, or created while the device was crowded, takes a queue of its own at its
-        // next call instead of staying on the shared pool for the rest of the process
+        // next call. ONE attempt per slot and per "crowd left" event (g_promote_epoch, raised where g_demote falls): with
+        // WLX_SLOT_CU_MASK=off, or where the dedicated constructor fails, the steady state costs nothing — the unconditional form
+        // synchronised the slot stream and created + destroyed a stream on EVERY call.
+        s->promote_epoch = g_promote_epoch[dv].load();
         hipStream_t ns = nullptr;
         bool ded = false;
-        if (hipSetDevice(s->device_of) == hipSuccess && hipStreamSynchronize(s->stream) == hipSuccess &&
-            create_slot_stream(s->device_of, &ns, &ded) == WLX_OK) {
+        if (hipSetDevice(dv) == hipSuccess && hipStreamSynchronize(s->stream) == hipSuccess &&
+            create_slot_stream(dv, &ns, &ded) == WLX_OK) {
             if (ded) { (void)hipStreamDestroy(s->stream); s->stream = ns; s->dedicated_queue = true; }
             else (void)hipStreamDestroy(ns);
         } else {
@@ -507,15 +529,22 @@ static int slot_grow_audio(Engine* e, Slot* s, size_t n_samples) {
 // Only the first WLX_DEDICATED_QUEUES (4 = the reference server's max_clients) live slots of a device get one: with 8 dedicated
 // queues (+ the null and utility streams' two) the same 8-stream workload drops from 1883 xRT (shared queues) to 1135 — past
 // some number of busy hardware queues the command processor time-slices them (profiles/r3c_bench_s8_default.json).
-static int create_slot_stream(int device, hipStream_t* out, bool* dedicated_out) {
+static std::string slot_stream_mode() {
     static const char* cu_mode = getenv("WLX_SLOT_CU_MASK");
+    if (cu_mode) return cu_mode;
+    return g_embedded_device_memory.load() ? "off" : "full";
+}
+static bool dedicated_streams_possible() { return slot_stream_mode() != "off" && max_dedicated_queues() > 0; }
+static int create_slot_stream(int device, hipStream_t* out, bool* dedicated_out) {
     const int max_dedicated = max_dedicated_queues();
     static std::atomic<int> slot_seq{0};
-    std::string m = cu_mode ? cu_mode : "full";
+    std::string m = slot_stream_mode();
     {   // once per process: which kind of stream the slots get (the default synchronises implicitly with the NULL stream)
         static std::atomic<bool> said{false};
         if (!said.exchange(true) && getenv("WLX_QUIET") == nullptr)
-            fprintf(stderr, "[wlx] slot streams: WLX_SLOT_CU_MASK=%s, up to %d hardware queues per device%s\n", m.c_str(), max_dedicated,
+            fprintf(stderr, "[wlx] slot streams: WLX_SLOT_CU_MASK=%s%s, up to %d hardware queues per device%s\n", m.c_str(),
+                    (!getenv("WLX_SLOT_CU_MASK") && g_embedded_device_memory.load()) ? " (chosen: weights were handed over as device pointers of another runtime)" : "",
+                    max_dedicated,
                     m == "off" ? "" : " (CU-mask streams are blocking streams: keep NULL-stream work of this process off the device, or set WLX_SLOT_CU_MASK=off)");
     }
     *dedicated_out = false;
@@ -573,6 +602,7 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         s->device_of = e->device;
         if (e->device >= 0 && e->device < 64) {
             s->counted = true;
+            s->promote_epoch = g_promote_epoch[e->device].load();
             if (g_slots_live[e->device].fetch_add(1) + 1 > max_dedicated_queues()) g_demote[e->device].store(true);
         }
         if (s->counted && g_demote[e->device].load()) {
@@ -859,8 +889,8 @@ extern "C" int32_t wlx_encode(wlx_engine* e, int32_t slot, int32_t batch, const 
     const int d = sp.d_model, F = sp.ffn, nm = sp.n_mels, H = e->H, T = WLX_T_AUDIO;
     CK(hipSetDevice(e->device));
     hipStream_t st = s->stream;
-    CKR(flush_logmel(e, s));                // the recorded log-mel requests of the batch: one launch of each kernel
-    CK(hipEventRecord(s->ev_en0, st));
+    // (every window validated BEFORE anything is recorded or launched: a refused call must leave the slot's timing events and
+    // `en_pending` of the previous encode untouched — ADVICE r04)
     PrepWindows pw{};                       // the windows of the batch: one launch (blockIdx.y = item)
     for (int b = 0; b < batch; ++b) {
         const int sk = seek ? seek[b] : 0;
@@ -870,6 +900,8 @@ extern "C" int32_t wlx_encode(wlx_engine* e, int32_t slot, int32_t batch, const 
         if (sg > WLX_N_FRAMES) sg = WLX_N_FRAMES;
         pw.seek[b] = sk; pw.seg[b] = sg;
     }
+    CKR(flush_logmel(e, s));                // the recorded log-mel requests of the batch: one launch of each kernel
+    CK(hipEventRecord(s->ev_en0, st));
     launch_prep_windows(s->feats, s->feat_ld, nm, (long)nm * s->feat_ld, pw, batch, s->featT, (long)s->featT_stride, st);
     GemmParams g{};
     // conv1 (k=3, s=1, p=1) + GELU: K-row of frame t = featT rows t..t+2 (row 0 / 3001 are the zero pad)
@@ -1197,8 +1229,9 @@ static int prefill_tokens(Engine* e, Slot* s, int item, int crow, const int* tok
         return WLX_OK;
     }
     // chunk size: 48 rows = three 16-row MFMA tiles = one launch of the lean projections per chunk (a 64-row chunk runs them as
-    // two row chunks in grid.z); WLX_PREFILL_ROWS=16..64 (A/B, tests)
-    const int chunk = [] { const char* v = getenv("WLX_PREFILL_ROWS"); const int c = v ? atoi(v) : 48; return (c >= 16 && c <= 64) ? c : 48; }();   // (read per call: tests toggle it)
+    // two row chunks in grid.z); WLX_PREFILL_ROWS=16..320 (A/B, tests)
+    // (read per call: tests toggle it; up to the slot's row capacity — 120 teacher-forced rows in one pass on a 24 x 5 slot)
+    const int chunk = std::min(s->rows_cap, [] { const char* v = getenv("WLX_PREFILL_ROWS"); const int c = v ? atoi(v) : 48; return (c >= 16 && c <= WLX_MAX_DEC_ROWS) ? c : 48; }());
     for (int c0 = 0; c0 < n; c0 += chunk) {
         const int rows = std::min(chunk, n - c0);
         const int groups = (rows + 15) / 16;
