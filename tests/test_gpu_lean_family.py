@@ -1,7 +1,8 @@
 """GPU parity (-m gpu) of the LEAN decode kernels (decoder.hip dec_gemv2_kernel and friends) at the d_model values of
-the Whisper family — 512 (base), 768 (small), 1024 (medium), 1280 (large-v3) — with reduced depth so the CPU oracle
-finishes in seconds. tiny (d_model 384) is not a multiple of 256 and runs the general first-generation GEMV, which is
-what tests/test_gpu_parity.py covers; this module is what pins the kernels bench.py times.
+the Whisper family — 384 (tiny, since round 5), 512 (base), 768 (small), 1024 (medium), 1280 (large-v3) — with reduced depth so
+the CPU oracle finishes in seconds: every size the reference lists (whisper_live/backend/faster_whisper_backend.py:74-79) decodes on
+the lean kernels; the first-generation GEMV (tests/test_gpu_parity.py: d_model 128) stays for shapes outside the family. This module
+is what pins the kernels bench.py times.
 
 Tolerances as at full depth (tests/test_gpu_full_depth.py): logits rel-rms <= 5e-3 and max-abs <= 2e-2 * rms + 1e-2 against the fp32 oracle on
 the same fp16-rounded weights; generated tokens equal up to the first fp16-vs-fp32 near-tie (>= 6 tokens)."""
@@ -17,6 +18,7 @@ pytestmark = pytest.mark.gpu
 
 FAMILY = {
     # name: (n_mels, d_model, heads, enc_layers, dec_layers, ffn, vocab)
+    "tiny-like": (80, 384, 6, 1, 2, 1536, 20000),       # round 5: d_model 384 = 1.5 x 256 on the lean kernels too (LNV = 15, six waves of two k-tiles)
     "base-like": (80, 512, 8, 1, 2, 2048, 20000),
     "small-like": (80, 768, 12, 1, 2, 3072, 51864),     # full vocabulary: the 2-tile vocabulary projection
     "medium-like": (80, 1024, 16, 1, 2, 4096, 20000),
@@ -71,6 +73,9 @@ def test_decoder_logits_rows_1_to_48(fam, n_tok):
 def test_beam_decode_steps(fam):
     """the captured decode-step graph (5 beam rows): lean GEMVs, self/cross attention, device-side beam search."""
     name, spec, eng, oracle, slot, enc = fam
+    names = [k["name"] for k in slot.debug_profile_step(5, 4, 2)]
+    assert any(n.startswith("dec_gemv2_kernel<") for n in names) and any(n.startswith("dec_vocab_kernel<") for n in names), names
+    assert not any(n.startswith("dec_gemv_kernel<") for n in names), (name, names)     # no family member on the first-generation kernel
     ids = H.token_ids_for(spec.vocab)
     kw = dict(beam_size=5, patience=1.0, max_length=1 + 16, suppress_tokens=H.default_suppress(ids))
     got = slot.generate([[ids.sot]], H.engine_ids(ids), **kw)[0]

@@ -485,6 +485,14 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
     const int nw = p.nwm;
     WLX_TR_BEGIN();
     constexpr int NP = NTB * MT;                                           // (n-tile, 16-row tile) pairs of this workgroup
+    // LayerNorm rows are held as NV float4 per lane, d_model = 256 NV. LNV == 15 stands for d_model 384 = 1.5 x 256 (tiny / tiny.en, round 5:
+    // they ran on the first-generation kernel): two units, the second live on lanes 0..31 only — the other lanes load a clamped address,
+    // hold zeros and store nothing. For every other LNV the masks below are compile-time constants and the code is what it was.
+    constexpr bool LNT = (LNV == 15);
+    constexpr int NV = LNT ? 2 : LNV;
+    const bool tail_on = !LNT || lane < 32;
+    const int tback = LNT ? (tail_on ? 0 : lane) : 0;                      // float4 units to step back in the last unit (inactive lanes read lane 0's)
+    (void)tail_on; (void)tback;
     float* accred = smem;                                                  // [nw][NP][64][4]
     half_t* xs = reinterpret_cast<half_t*>(smem + nw * NP * 256);          // fp16 activation rows
 
@@ -606,49 +614,49 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
         // wave w normalises rows w, w + nw, ...; a row = LNV float4 per lane (d_model = 256 LNV).
         const int nwl = nw;
         constexpr int NSL = (XS == GEMV_X_SLABS) ? WLX_FC2_KS : 1;
-        float4 x[LNV], sl[NSL][LNV];
-        f16x4 te[LNV];
+        float4 x[NV], sl[NSL][NV];
+        f16x4 te[NV];
         int tok0 = 0, pos0 = 0;
         // request the pieces of row r (wave-uniform, clamped by the caller): rows, + slabs, or embedding + position
-        auto request_row = [&](int r, float4 (&x)[LNV], float4 (&sl)[NSL][LNV], f16x4 (&te)[LNV], int& tok, int& pos) {
+        auto request_row = [&](int r, float4 (&x)[NV], float4 (&sl)[NSL][NV], f16x4 (&te)[NV], int& tok, int& pos) {
             if constexpr (XS == GEMV_X_EMBED) {
                 tok = p.emb_token[r];
                 // (position and cache row in one word: both are scalar loads here — a vector load inside the lane-0 store
                 // branch below would make hipcc drain the whole weight stream in front of it)
-                pos = p.row_pos[r] | (p.row_cache[r] << 16);               // position < 448, cache row < 64
+                pos = p.row_pos[r] | (p.row_cache[r] << 16);               // position < 448, cache row < 32768
                 const half_t* tp = p.tok_emb + (long)tok * p.K + lane * 4;
                 const float4* pp = reinterpret_cast<const float4*>(p.pos_emb + (long)(pos & 0xffff) * p.K) + lane;
 #pragma unroll
-                for (int j = 0; j < LNV; ++j) { te[j] = ld_f16x4(tp + 256 * j); x[j] = pp[64 * j]; }
+                for (int j = 0; j < NV; ++j) { const int tb = (j == NV - 1) ? tback : 0; te[j] = ld_f16x4(tp + 256 * j - 4 * tb); x[j] = pp[64 * j - tb]; }
             } else {
                 const float4* x4 = reinterpret_cast<const float4*>(p.X + (long)r * p.ldx) + lane;
 #pragma unroll
-                for (int j = 0; j < LNV; ++j) x[j] = x4[64 * j];
+                for (int j = 0; j < NV; ++j) x[j] = x4[64 * j - ((j == NV - 1) ? tback : 0)];
                 if constexpr (XS == GEMV_X_SLABS) {
 #pragma unroll
                     for (int q = 0; q < NSL; ++q) {
                         const float4* s4 = reinterpret_cast<const float4*>(p.slab + q * p.slab_stride + (long)r * p.ldx) + lane;
 #pragma unroll
-                        for (int j = 0; j < LNV; ++j) sl[q][j] = s4[64 * j];
+                        for (int j = 0; j < NV; ++j) sl[q][j] = s4[64 * j - ((j == NV - 1) ? tback : 0)];
                     }
                 }
             }
         };
         // the row itself from its pieces (same association as the residual epilogue: ((x + s0) + s1) ...)
-        auto combine_row = [&](int r, bool keep, float4 (&x)[LNV], const float4 (&sl)[NSL][LNV], const f16x4 (&te)[LNV], int tok, int pos) {
+        auto combine_row = [&](int r, bool keep, float4 (&x)[NV], const float4 (&sl)[NSL][NV], const f16x4 (&te)[NV], int tok, int pos) {
             if constexpr (XS == GEMV_X_SLABS) {
 #pragma unroll
                 for (int q = 0; q < NSL; ++q)
 #pragma unroll
-                    for (int j = 0; j < LNV; ++j) { x[j].x += sl[q][j].x; x[j].y += sl[q][j].y; x[j].z += sl[q][j].z; x[j].w += sl[q][j].w; }
+                    for (int j = 0; j < NV; ++j) { x[j].x += sl[q][j].x; x[j].y += sl[q][j].y; x[j].z += sl[q][j].z; x[j].w += sl[q][j].w; }
             }
             if constexpr (XS == GEMV_X_EMBED) {
 #pragma unroll
-                for (int j = 0; j < LNV; ++j) { x[j].x += (float)te[j][0]; x[j].y += (float)te[j][1]; x[j].z += (float)te[j][2]; x[j].w += (float)te[j][3]; }
+                for (int j = 0; j < NV; ++j) { x[j].x += (float)te[j][0]; x[j].y += (float)te[j][1]; x[j].z += (float)te[j][2]; x[j].w += (float)te[j][3]; }
                 if (tile == 0 && keep) {            // workgroup 0 (of its row chunk) leaves the rows where the residual updates expect them
                     float4* o4 = reinterpret_cast<float4*>(p.Xres + (long)r * p.ldxres) + lane;
 #pragma unroll
-                    for (int j = 0; j < LNV; ++j) o4[64 * j] = x[j];
+                    for (int j = 0; j < NV; ++j) if (j < NV - 1 || tail_on) o4[64 * j] = x[j];
                     if (lane == 0) p.intok[(long)(pos >> 16) * WLX_T_TEXT + (pos & 0xffff)] = tok;
                 }
             }
@@ -657,30 +665,32 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
         request_row(ra, x, sl, te, tok0, pos0);
         const float4* g4 = reinterpret_cast<const float4*>(p.gamma) + lane;
         const float4* b4 = reinterpret_cast<const float4*>(p.beta) + lane;
-        float4 gq[LNV], bq[LNV];
+        float4 gq[NV], bq[NV];
 #pragma unroll
-        for (int j = 0; j < LNV; ++j) { gq[j] = g4[64 * j]; bq[j] = b4[64 * j]; }
+        for (int j = 0; j < NV; ++j) { const int tb = (j == NV - 1) ? tback : 0; gq[j] = g4[64 * j - tb]; bq[j] = b4[64 * j - tb]; }
         if (WLX_X_FIRST) load_weights();
         const int ldxs = p.K + 8;
-        constexpr float invK = 1.0f / (256.0f * LNV);
-        auto ln_row = [&](float4 (&x)[LNV], int r, bool keep) {
+        constexpr float invK = LNT ? (1.0f / 384.0f) : 1.0f / (256.0f * NV);
+        auto ln_row = [&](float4 (&x)[NV], int r, bool keep) {
+            if constexpr (LNT) { if (!tail_on) x[NV - 1] = make_float4(0.f, 0.f, 0.f, 0.f); }
             float sm = 0.f;
 #pragma unroll
-            for (int j = 0; j < LNV; ++j) sm += (x[j].x + x[j].y) + (x[j].z + x[j].w);
+            for (int j = 0; j < NV; ++j) sm += (x[j].x + x[j].y) + (x[j].z + x[j].w);
             const float mean = wave_sum_dpp(sm) * invK;
             float q = 0.f;
 #pragma unroll
-            for (int j = 0; j < LNV; ++j) {
+            for (int j = 0; j < NV; ++j) {
                 x[j].x -= mean; x[j].y -= mean; x[j].z -= mean; x[j].w -= mean;
+                if constexpr (LNT) { if (j == NV - 1 && !tail_on) x[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
                 q += (x[j].x * x[j].x + x[j].y * x[j].y) + (x[j].z * x[j].z + x[j].w * x[j].w);
             }
             const float rstd = rsqrtf(wave_sum_dpp(q) * invK + 1e-5f);
             half_t* dst = xs + (long)r * ldxs + lane * 4;
 #pragma unroll
-            for (int j = 0; j < LNV; ++j) {
+            for (int j = 0; j < NV; ++j) {
                 const f16x4 hv = {(half_t)(x[j].x * rstd * gq[j].x + bq[j].x), (half_t)(x[j].y * rstd * gq[j].y + bq[j].y),
                                   (half_t)(x[j].z * rstd * gq[j].z + bq[j].z), (half_t)(x[j].w * rstd * gq[j].w + bq[j].w)};
-                if (keep) *reinterpret_cast<f16x4*>(dst + 256 * j) = hv;
+                if (keep && (j < NV - 1 || tail_on)) *reinterpret_cast<f16x4*>(dst + 256 * j) = hv;
             }
         };
         // first trip: straight-line and UNCONDITIONAL (a wave without a row normalises the clamped row it loaded and keeps
@@ -692,8 +702,8 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
         if constexpr (MT == 1) {
 #pragma unroll 1
             for (int r = wave + nwl; r < p.M; r += nwl) {                   // more rows than waves (9..16 rows)
-                float4 x2[LNV], sl2[NSL][LNV];
-                f16x4 te2[LNV];
+                float4 x2[NV], sl2[NSL][NV];
+                f16x4 te2[NV];
                 int tok2 = 0, pos2 = 0;
                 request_row(r, x2, sl2, te2, tok2, pos2);
                 combine_row(r, true, x2, sl2, te2, tok2, pos2);
@@ -706,8 +716,8 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
             for (int r = wave + nwl; r < p.M; r += 2 * nwl) {
                 const int r1 = r + nwl;
                 const bool has1 = r1 < p.M;
-                float4 x2[LNV], sl2[NSL][LNV], x3[LNV], sl3[NSL][LNV];
-                f16x4 te2[LNV], te3[LNV];
+                float4 x2[NV], sl2[NSL][NV], x3[NV], sl3[NSL][NV];
+                f16x4 te2[NV], te3[NV];
                 int tok2 = 0, pos2 = 0, tok3 = 0, pos3 = 0;
                 request_row(r, x2, sl2, te2, tok2, pos2);
                 request_row(has1 ? r1 : r, x3, sl3, te3, tok3, pos3);
@@ -728,40 +738,42 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
     } else if constexpr (IN == GEMV_IN_LN) {
         // wave w normalises rows w, w + nw, ...; a row = LNV float4 per lane (d_model = 256 LNV)
         // first trip's rows (this wave's row and the one nw below it) are requested before anything else
-        float4 x[LNV], y[LNV];
+        float4 x[NV], y[NV];
         {
             const int ra = (wave < p.M) ? wave : p.M - 1, rb = (wave + nw < p.M) ? wave + nw : ra;
             const float4* x4 = reinterpret_cast<const float4*>(p.X + (long)ra * p.ldx) + lane;
             const float4* y4 = reinterpret_cast<const float4*>(p.X + (long)rb * p.ldx) + lane;
 #pragma unroll
-            for (int j = 0; j < LNV; ++j) { x[j] = x4[64 * j]; y[j] = y4[64 * j]; }
+            for (int j = 0; j < NV; ++j) { const int tb = (j == NV - 1) ? tback : 0; x[j] = x4[64 * j - tb]; y[j] = y4[64 * j - tb]; }
         }
         const float4* g4 = reinterpret_cast<const float4*>(p.gamma) + lane;
         const float4* b4 = reinterpret_cast<const float4*>(p.beta) + lane;
-        float4 gq[LNV], bq[LNV];
+        float4 gq[NV], bq[NV];
 #pragma unroll
-        for (int j = 0; j < LNV; ++j) { gq[j] = g4[64 * j]; bq[j] = b4[64 * j]; }
+        for (int j = 0; j < NV; ++j) { const int tb = (j == NV - 1) ? tback : 0; gq[j] = g4[64 * j - tb]; bq[j] = b4[64 * j - tb]; }
         if (WLX_X_FIRST) load_weights();
         const int ldxs = p.K + 8;
-        constexpr float invK = 1.0f / (256.0f * LNV);
-        auto ln_row = [&](float4 (&x)[LNV], int r) {
+        constexpr float invK = LNT ? (1.0f / 384.0f) : 1.0f / (256.0f * NV);
+        auto ln_row = [&](float4 (&x)[NV], int r) {
+            if constexpr (LNT) { if (!tail_on) x[NV - 1] = make_float4(0.f, 0.f, 0.f, 0.f); }
             float sm = 0.f;
 #pragma unroll
-            for (int j = 0; j < LNV; ++j) sm += (x[j].x + x[j].y) + (x[j].z + x[j].w);
+            for (int j = 0; j < NV; ++j) sm += (x[j].x + x[j].y) + (x[j].z + x[j].w);
             const float mean = wave_sum_dpp(sm) * invK;
             float q = 0.f;
 #pragma unroll
-            for (int j = 0; j < LNV; ++j) {
+            for (int j = 0; j < NV; ++j) {
                 x[j].x -= mean; x[j].y -= mean; x[j].z -= mean; x[j].w -= mean;
+                if constexpr (LNT) { if (j == NV - 1 && !tail_on) x[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
                 q += (x[j].x * x[j].x + x[j].y * x[j].y) + (x[j].z * x[j].z + x[j].w * x[j].w);
             }
             const float rstd = rsqrtf(wave_sum_dpp(q) * invK + 1e-5f);
             half_t* dst = xs + (long)r * ldxs + lane * 4;
 #pragma unroll
-            for (int j = 0; j < LNV; ++j) {
+            for (int j = 0; j < NV; ++j) {
                 const f16x4 hv = {(half_t)(x[j].x * rstd * gq[j].x + bq[j].x), (half_t)(x[j].y * rstd * gq[j].y + bq[j].y),
                                   (half_t)(x[j].z * rstd * gq[j].z + bq[j].z), (half_t)(x[j].w * rstd * gq[j].w + bq[j].w)};
-                *reinterpret_cast<f16x4*>(dst + 256 * j) = hv;
+                if (j < NV - 1 || tail_on) *reinterpret_cast<f16x4*>(dst + 256 * j) = hv;
             }
         };
         // first trip, straight-line: its rows were requested at the top. (It must not share a loop with the later trips:
@@ -774,7 +786,7 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
             for (int u = 0; u < (has1 ? 2 : 1); ++u) {                      // rolled: one copy of the row code (code size is latency here)
                 if (u) {
 #pragma unroll
-                    for (int j = 0; j < LNV; ++j) x[j] = y[j];
+                    for (int j = 0; j < NV; ++j) x[j] = y[j];
                 }
                 ln_row(x, u ? wave + nw : wave);
             }
@@ -785,14 +797,14 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
             const bool has1 = r1 < p.M;
             const float4* x4 = reinterpret_cast<const float4*>(p.X + (long)r * p.ldx) + lane;
             const float4* y4 = reinterpret_cast<const float4*>(p.X + (long)(has1 ? r1 : r) * p.ldx) + lane;
-            float4 x2[LNV], y2[LNV];
+            float4 x2[NV], y2[NV];
 #pragma unroll
-            for (int j = 0; j < LNV; ++j) { x2[j] = x4[64 * j]; y2[j] = y4[64 * j]; }
+            for (int j = 0; j < NV; ++j) { const int tb = (j == NV - 1) ? tback : 0; x2[j] = x4[64 * j - tb]; y2[j] = y4[64 * j - tb]; }
 #pragma unroll 1
             for (int u = 0; u < (has1 ? 2 : 1); ++u) {
                 if (u) {
 #pragma unroll
-                    for (int j = 0; j < LNV; ++j) x2[j] = y2[j];
+                    for (int j = 0; j < NV; ++j) x2[j] = y2[j];
                 }
                 ln_row(x2, u ? r1 : r);
             }
@@ -1030,12 +1042,20 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
             break;
         }
     }
+    if (p.in_mode == GEMV_IN_LN && p.K == 384) {
+        // d_model 384 (tiny / tiny.en, round 5): 12 k-tiles as six waves of two, so that six waves share the LayerNorm of the rows
+        // (the general search above would pick two waves of six k-tiles: three LayerNorm trips for five rows)
+        best_nch = 1; c.nw = 6; c.CH = 2; c.NCH = 1;
+    }
     if (best_nch == (1 << 30)) return c;
     if (p.in_mode != GEMV_IN_F16 && c.NCH != 1) return c;
     c.LNV = 0;
     if (p.in_mode == GEMV_IN_LN) {
-        if (p.K % 256 || p.K / 256 < 2 || p.K / 256 > 5) return c;
-        c.LNV = p.K / 256;
+        if (p.K == 384) c.LNV = 15;                 // 1.5 x 256: see dec_gemv2_kernel
+        else {
+            if (p.K % 256 || p.K / 256 < 2 || p.K / 256 > 5) return c;
+            c.LNV = p.K / 256;
+        }
     }
     c.NTB = (p.out_mode == GEMV_OUT_F32 && p.N > 8192) ? 2 : 1;
     // more 16-column tiles than CUs (large-v3's first MLP projection: 320): two tiles per workgroup keep the launch to one
@@ -1159,6 +1179,7 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
         if (c.CH == 4 && c.LNV == 3) return gemv2_launch_qkv_xs<4, 3>(p, c, grid, block, s);
         if (c.CH == 3 && c.LNV == 3) return gemv2_launch_qkv_xs<3, 3>(p, c, grid, block, s);
         if (c.CH == 2 && c.LNV == 2) return gemv2_launch_qkv_xs<2, 2>(p, c, grid, block, s);
+        if (c.CH == 2 && c.LNV == 15) return c.MT == 1 ? gemv2_launch_qkv_xs_mt<2, 15, 1>(p, c, grid, block, s) : false;
         if (c.CH == 4 && c.LNV == 4) return gemv2_launch_qkv_xs<4, 4>(p, c, grid, block, s);
         if (c.CH == 5 && c.LNV == 5) return gemv2_launch_qkv_xs<5, 5>(p, c, grid, block, s);
         return false;
@@ -1168,6 +1189,7 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
         if (c.CH == 5 && c.LNV == 5) return WLX_G2_LN(5, 5);
         if (c.CH == 4 && c.LNV == 2) return WLX_G2_LN(4, 2);
         if (c.CH == 4 && c.LNV == 4) return WLX_G2_LN(4, 4);
+        if (c.CH == 2 && c.LNV == 15) return c.MT == 1 ? gemv2_launch_ln<2, 15, 1>(p, c, grid, block, s) : false;   // (one row tile: batched rows run as row tiles)
         return false;
     }
     if (p.in_mode == GEMV_IN_XATTN && c.CH < 4) {
@@ -1188,10 +1210,12 @@ static bool gemv2_ok(const GemvParams& p, Gemv2Cfg* out) {
     const Gemv2Cfg c = gemv2_cfg(p);
     if (!c.ok) return false;
     if (p.in_mode == GEMV_IN_LN && p.xsrc != GEMV_X_PLAIN) {
-        const bool pair = (c.CH == 4 && c.LNV == 3) || (c.CH == 3 && c.LNV == 3) || (c.CH == 2 && c.LNV == 2) || (c.CH == 4 && c.LNV == 4) || (c.CH == 5 && c.LNV == 5);
+        const bool pair = (c.CH == 4 && c.LNV == 3) || (c.CH == 3 && c.LNV == 3) || (c.CH == 2 && c.LNV == 2) || (c.CH == 4 && c.LNV == 4) || (c.CH == 5 && c.LNV == 5) ||
+                          (c.CH == 2 && c.LNV == 15 && c.MT == 1);
         if (!pair) return false;
     } else if (p.in_mode == GEMV_IN_LN) {
-        const bool pair = (c.CH == 6 && c.LNV == 3) || (c.CH == 5 && c.LNV == 5) || (c.CH == 4 && c.LNV == 2) || (c.CH == 4 && c.LNV == 4);
+        const bool pair = (c.CH == 6 && c.LNV == 3) || (c.CH == 5 && c.LNV == 5) || (c.CH == 4 && c.LNV == 2) || (c.CH == 4 && c.LNV == 4) ||
+                          (c.CH == 2 && c.LNV == 15 && c.MT == 1);
         if (!pair) return false;
     }
     if (out) *out = c;
@@ -1245,7 +1269,7 @@ static int vocab2_chunk_rows(int K);
 const char* dec_gemv_kernel_name(const GemvParams& p_any) {
     static thread_local char buf[64];
     if (vocab2_ok(p_any)) {
-        snprintf(buf, sizeof(buf), "dec_vocab_kernel<%d, %d, %d>", p_any.KT, p_any.KT == 24 ? 6 : p_any.KT == 40 ? 5 : 4, (std::min(p_any.M, vocab2_chunk_rows(p_any.K)) + 15) / 16);
+        snprintf(buf, sizeof(buf), "dec_vocab_kernel<%d, %d, %d>", p_any.KT, p_any.KT == 24 ? 6 : p_any.KT == 40 ? 5 : p_any.KT == 12 ? 3 : 4, (std::min(p_any.M, vocab2_chunk_rows(p_any.K)) + 15) / 16);
         return buf;
     }
     const GemvParams p = gemv_chunked(p_any);
@@ -1327,8 +1351,9 @@ struct VocabParams {
 };
 template <int KT, int KC, int MT>
 __global__ __launch_bounds__(512) void dec_vocab_kernel(VocabParams p) {
-    constexpr int K = KT * 32, LNV = K / 256, NC = KT / KC, LDXS = K + 8;
-    static_assert(K % 256 == 0 && KT % KC == 0 && NC % 2 == 0, "d_model a multiple of 256; an even number of K chunks");
+    constexpr int K = KT * 32, LNV = (K + 255) / 256, NC = KT / KC, LDXS = K + 8;
+    constexpr bool LNT = (K % 256) != 0;                    // d_model 384 = 1.5 x 256: the second float4 unit is live on lanes 0..31 only (see dec_gemv2_kernel)
+    static_assert((K % 256 == 0 || K == 384) && KT % KC == 0 && NC % 2 == 0, "d_model a multiple of 256 (or 384); an even number of K chunks");
     constexpr int RPT = (MT == 1) ? 2 : 4;                  // LayerNorm rows a wave requests per trip (8 waves: 16 / 32 rows per trip)
     constexpr int NTRIP = (MT * 16 + 8 * RPT - 1) / (8 * RPT);
     extern __shared__ __attribute__((aligned(16))) half_t vxs[];   // [M][LDXS] fp16 LayerNorm rows
@@ -1337,6 +1362,8 @@ __global__ __launch_bounds__(512) void dec_vocab_kernel(VocabParams p) {
     WLX_TR_BEGIN();
     const int pair = blockIdx.x * 8 + wave;
     const int t0 = (2 * pair < p.NT) ? 2 * pair : p.NT - 1, t1 = (2 * pair + 1 < p.NT) ? 2 * pair + 1 : p.NT - 1;
+    const bool tail_on = !LNT || lane < 32;
+    const int tback = LNT ? (tail_on ? 0 : lane) : 0;
     // ---- first trip's rows FIRST (vmcnt retires in order: the LayerNorm must not wait behind the weight stream)
     float4 x[RPT][LNV];
 #pragma unroll
@@ -1344,14 +1371,14 @@ __global__ __launch_bounds__(512) void dec_vocab_kernel(VocabParams p) {
         const int r = (wave + 8 * i < p.M) ? wave + 8 * i : p.M - 1;
         const float4* x4 = reinterpret_cast<const float4*>(p.X + (long)r * p.ldx) + lane;
 #pragma unroll
-        for (int j = 0; j < LNV; ++j) x[i][j] = x4[64 * j];
+        for (int j = 0; j < LNV; ++j) x[i][j] = x4[64 * j - ((j == LNV - 1) ? tback : 0)];
     }
     float4 gq[LNV], bq[LNV];
     {
         const float4* g4 = reinterpret_cast<const float4*>(p.gamma) + lane;
         const float4* b4 = reinterpret_cast<const float4*>(p.beta) + lane;
 #pragma unroll
-        for (int j = 0; j < LNV; ++j) { gq[j] = g4[64 * j]; bq[j] = b4[64 * j]; }
+        for (int j = 0; j < LNV; ++j) { const int tb = (j == LNV - 1) ? tback : 0; gq[j] = g4[64 * j - tb]; bq[j] = b4[64 * j - tb]; }
     }
     asm volatile("" ::: "memory");                         // compile-time fence: the weight requests stay behind the row requests
     const half_t* wq[2] = {p.Wp + (long)t0 * KT * 512 + lane * 8, p.Wp + (long)t1 * KT * 512 + lane * 8};
@@ -1364,6 +1391,7 @@ __global__ __launch_bounds__(512) void dec_vocab_kernel(VocabParams p) {
             for (int i = 0; i < 2; ++i) wf[b][j][i] = ld_nt_f16x8(wq[i] + (b * KC + j) * 512);
     constexpr float invK = 1.0f / (float)K;
     auto ln_row = [&](float4 (&xr)[LNV], int r, bool keep) {
+        if constexpr (LNT) { if (!tail_on) xr[LNV - 1] = make_float4(0.f, 0.f, 0.f, 0.f); }
         float sm = 0.f;
 #pragma unroll
         for (int j = 0; j < LNV; ++j) sm += (xr[j].x + xr[j].y) + (xr[j].z + xr[j].w);
@@ -1372,6 +1400,7 @@ __global__ __launch_bounds__(512) void dec_vocab_kernel(VocabParams p) {
 #pragma unroll
         for (int j = 0; j < LNV; ++j) {
             xr[j].x -= mean; xr[j].y -= mean; xr[j].z -= mean; xr[j].w -= mean;
+            if constexpr (LNT) { if (j == LNV - 1 && !tail_on) xr[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
             q += (xr[j].x * xr[j].x + xr[j].y * xr[j].y) + (xr[j].z * xr[j].z + xr[j].w * xr[j].w);
         }
         const float rstd = rsqrtf(dpp_wave_sum(q) * invK + 1e-5f);
@@ -1380,7 +1409,7 @@ __global__ __launch_bounds__(512) void dec_vocab_kernel(VocabParams p) {
         for (int j = 0; j < LNV; ++j) {
             const f16x4 hv = {(half_t)(xr[j].x * rstd * gq[j].x + bq[j].x), (half_t)(xr[j].y * rstd * gq[j].y + bq[j].y),
                               (half_t)(xr[j].z * rstd * gq[j].z + bq[j].z), (half_t)(xr[j].w * rstd * gq[j].w + bq[j].w)};
-            if (keep) *reinterpret_cast<f16x4*>(dst + 256 * j) = hv;
+            if (keep && (j < LNV - 1 || tail_on)) *reinterpret_cast<f16x4*>(dst + 256 * j) = hv;
         }
     };
     // first trip: straight-line and unconditional (a wave without a row normalises the clamped row it loaded and keeps nothing)
@@ -1396,7 +1425,7 @@ __global__ __launch_bounds__(512) void dec_vocab_kernel(VocabParams p) {
             const int r = (rb + 8 * i < p.M) ? rb + 8 * i : p.M - 1;
             const float4* x4 = reinterpret_cast<const float4*>(p.X + (long)r * p.ldx) + lane;
 #pragma unroll
-            for (int j = 0; j < LNV; ++j) y[i][j] = x4[64 * j];
+            for (int j = 0; j < LNV; ++j) y[i][j] = x4[64 * j - ((j == LNV - 1) ? tback : 0)];
         }
 #pragma unroll
         for (int i = 0; i < RPT; ++i) ln_row(y[i], (rb + 8 * i < p.M) ? rb + 8 * i : p.M - 1, rb + 8 * i < p.M);
@@ -1498,7 +1527,7 @@ static bool vocab2_ok(const GemvParams& p) {
     const int mode = vocab2_mode();
     if (mode == 0 || (mode == 1 && p.M <= 16)) return false;
     if (p.M < 1 || p.M > WLX_MAX_DEC_ROWS || p.K != p.KT * 32 || p.N < 256) return false;
-    if (!(p.KT == 16 || p.KT == 24 || p.KT == 32 || p.KT == 40)) return false;
+    if (!(p.KT == 12 || p.KT == 16 || p.KT == 24 || p.KT == 32 || p.KT == 40)) return false;
     const int rows = std::min(p.M, vocab2_chunk_rows(p.K));
     const size_t shm = (size_t)rows * (p.K + 8) * sizeof(half_t);
     if (shm > 64 * 1024 && g_lds_optin_refused.load(std::memory_order_relaxed)) return false;   // the device refused the raised LDS limit once: general kernel
@@ -1514,6 +1543,7 @@ static void vocab2_launch(const GemvParams& g, hipStream_t s) {
         p.trc = trace_next("vocab2");
 #endif
         switch (g.KT) {
+            case 12: vocab_go_mt<12, 3>(p, s); break;
             case 16: vocab_go_mt<16, 4>(p, s); break;
             case 24: vocab_go_mt<24, 6>(p, s); break;
             case 32: vocab_go_mt<32, 4>(p, s); break;
