@@ -155,6 +155,14 @@ def build_trace() -> Path:
     return out if _fresh(out) else _compile(out, ["WLX_TRACE"])
 
 
+def build_ab() -> Path:
+    """libwlx_ab.so: the same sources with -DWLX_AB — the A/B switches that survive in the source (csrc/common.h wlx_ab: WLX_GEMM3,
+    WLX_ROWTILE, WLX_RT_F16_NTB2, WLX_NO_FUSED_CQ, WLX_PREFILL_JOINT, WLX_DECODE_V1) read the
+    environment in THIS library only; the production libwlx.so compiles them out. Select with WLX_LIB=<path>."""
+    out = PKG_DIR / "libwlx_ab.so"
+    return out if _fresh(out) else _compile(out, ["WLX_AB"])
+
+
 def build_variant(name: str, defines) -> Path:
     """A/B builds of the same sources with extra -D flags (e.g. libwlx_wfirst.so: -DWLX_X_FIRST=0, the decode GEMVs with
     their weight stream requested BEFORE the activations, the round-1 order); selected at run time with WLX_LIB=<path>."""

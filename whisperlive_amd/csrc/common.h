@@ -10,6 +10,18 @@ typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// A/B switches (host side). The production library reads NO experiment switches from the environment: wlx_ab() is a constant there and
+// every alternative behind it is dead code the optimiser drops. `-DWLX_AB` (whisperlive_amd/_lib.py build_variant("ab", ["WLX_AB"]) ->
+// libwlx_ab.so, loaded with WLX_LIB) builds the library in which the surviving switches read the environment, for
+// re-measuring an alternative from the same source. Runtime CONFIGURATION (WLX_SLOT_CU_MASK, WLX_DEDICATED_QUEUES, WLX_NO_GRAPH,
+// WLX_QUIET, WLX_GEN_TRACE) and the two test hooks of the prompt prefill stay ordinary getenv() reads in engine.hip.
+#include <cstdlib>
+#ifdef WLX_AB
+static inline const char* wlx_ab(const char* name) { return getenv(name); }
+#else
+static inline const char* wlx_ab(const char*) { return nullptr; }
+#endif
+
 #define WLX_WAVE 64
 #define WLX_T_AUDIO 1500      // encoder positions per 30 s window
 #define WLX_T_AUDIO_PAD 1536  // key padding so 32-key tiles never read out of bounds

@@ -118,9 +118,6 @@ bool dec_cq_cross_attn_eligible(int d, int H, int R);
 void launch_dec_cq_cross_attn(const float* X, long ldx, const float* gamma, const float* beta, const half_t* Wp, const float* bias,
                               float qscale, int d, const half_t* Kp, const half_t* Vp, long item_stride, int H, int R, int groups,
                               int rows, const int* group_item, half_t* part_o, float* part_ml, hipStream_t s);
-// LayerNorm of M decoder rows on its own -> fp16 rows (batched rows, A/B: WLX_BATCHED_LN=1); d_model a multiple of 256, 512..1280
-bool dec_ln_rows_ok(int d);
-void launch_dec_ln_rows(const float* X, long ldx, const float* gamma, const float* beta, half_t* out, long ldo, int M, int d, hipStream_t s);
 // combine of the cross attention's split partials into fp16 rows out[M][H*64] (batched rows: see decoder.hip)
 void launch_dec_xattn_combine(const half_t* part_o, const float* part_ml, int M, int H, int R, half_t* out, long ldo, hipStream_t s);
 // raw cross-attention scores of head h (tile-packed K of one layer AND item) for `rows` query rows -> out[rows][1536] fp32

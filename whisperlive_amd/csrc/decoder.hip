@@ -999,8 +999,7 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     const bool combo = (p.in_mode == GEMV_IN_LN && (p.out_mode == GEMV_OUT_QKV || p.out_mode == GEMV_OUT_F16 ||
                                                     p.out_mode == GEMV_OUT_GELU_F16 || p.out_mode == GEMV_OUT_F32)) ||
                        (p.in_mode != GEMV_IN_LN && p.out_mode == GEMV_OUT_RESID) ||
-                       (p.in_mode == GEMV_IN_F16 && p.out_mode == GEMV_OUT_SLAB) ||
-                       (p.in_mode == GEMV_IN_F16 && p.xsrc == GEMV_X_PLAIN && (p.out_mode == GEMV_OUT_QKV || p.out_mode == GEMV_OUT_F16 || p.out_mode == GEMV_OUT_GELU_F16));   // rows normalised by dec_ln_rows_kernel
+                       (p.in_mode == GEMV_IN_F16 && p.out_mode == GEMV_OUT_SLAB);
     if (!combo || p.K != p.KT * 32) return c;
     // sources other than the plain rows: one row tile, and only where the kernel is instantiated for them
     if (p.xsrc != GEMV_X_PLAIN) {
@@ -1013,25 +1012,18 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
         if (p.KTS < 1 || p.KT % p.KTS || p.KT / p.KTS != WLX_FC2_KS) return c;
         KTf = p.KTS;
     }
-    static const int f16cap = [] { const char* e = getenv("WLX_GEMV_F16_NW"); return e ? atoi(e) : 16; }();
-    static const bool xattn_nw8 = [] { const char* e = getenv("WLX_XATTN_NW8"); return e && e[0] == '1'; }();   // measured equal to 4 + helpers (profiles/r2h_*): off
-    const int cap = (p.in_mode == GEMV_IN_F16 && p.out_mode != GEMV_OUT_SLAB && p.M <= 16) ? f16cap : 8;
+    const int cap = (p.in_mode == GEMV_IN_F16 && p.out_mode != GEMV_OUT_SLAB && p.M <= 16) ? 16 : 8;
     // exact factorisation KTf = nw * CH * NCH, CH in {6, 5, 4}: fewest chunks first, then the widest chunk
     int best_nch = 1 << 30;
     if (p.in_mode == GEMV_IN_LN && p.xsrc != GEMV_X_PLAIN) {
         // slab / embedding rows: one row per wave, so at least min(M, 8) waves, each streaming CH >= 2 k-tiles
-        static const int want_env = [] { const char* e = getenv("WLX_XS_WAVES"); return e ? atoi(e) : 0; }();   // (A/B: 8 = CH 3 on d_model 768)
-        const int want = std::max(std::min(p.M, 8), std::min(want_env, 8));
+        const int want = std::min(p.M, 8);
         for (int CH = 6; CH >= 2; --CH) {
             if (KTf % CH || KTf / CH > 8 || KTf / CH < want) continue;
             best_nch = 1; c.nw = KTf / CH; c.CH = CH; c.NCH = 1;
             break;
         }
-    } else if (p.in_mode == GEMV_IN_XATTN && xattn_nw8 && p.M <= 16 && KTf % 8 == 0 && KTf / 8 >= 2 && KTf / 8 <= 6) {
-        // the split combine wants ~8 waves (M * H * 8 threads): let all of them stream weights (8 x KT/8 k-tiles) instead of
-        // 4 MFMA waves + helper waves with dummy requests
-        best_nch = 1; c.nw = 8; c.CH = KTf / 8; c.NCH = 1;
-    } else
+    } else      // (the split combine as 8 weight-streaming waves instead of 4 + helpers measured equal, profiles/r2h_*: not instantiated any more)
     for (int CH = 6; CH >= 4; --CH) {
         if (KTf % CH) continue;
         const int q = KTf / CH;                     // = nw * NCH
@@ -1060,23 +1052,20 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     c.NTB = (p.out_mode == GEMV_OUT_F32 && p.N > 8192) ? 2 : 1;
     // more 16-column tiles than CUs (large-v3's first MLP projection: 320): two tiles per workgroup keep the launch to one
     // round of workgroups and halve the redundant LayerNorm prologues. WLX_GELU_NTB2=0 keeps one tile (A/B).
-    static const bool gelu_ntb2 = [] { const char* e = getenv("WLX_GELU_NTB2"); return !(e && e[0] == '0'); }();
-    if (gelu_ntb2 && p.in_mode == GEMV_IN_LN && p.out_mode == GEMV_OUT_GELU_F16 && p.xsrc == GEMV_X_PLAIN && (p.N + 15) / 16 > 256 && ((p.N + 15) / 16) % 2 == 0) c.NTB = 2;
+    if (p.in_mode == GEMV_IN_LN && p.out_mode == GEMV_OUT_GELU_F16 && p.xsrc == GEMV_X_PLAIN && (p.N + 15) / 16 > 256 && ((p.N + 15) / 16) % 2 == 0) c.NTB = 2;
     // row tiles of a batched step (round 4): every 16-column workgroup of a LayerNorm-fronted projection normalises its 16 rows again —
     // at 60 rows ~90 % of its instructions. Two column tiles per workgroup halve that redundant work (and the workgroup count) for the
     // wide projections (>= 128 tiles: QKV, first MLP projection). WLX_RT_NTB2=0 keeps one tile (A/B).
-    static const bool rt_ntb2 = [] { const char* e = getenv("WLX_RT_NTB2"); return !(e && e[0] == '0'); }();
-    if (rt_ntb2 && p.Mtot > 0 && p.rt_nz > 0 && p.in_mode == GEMV_IN_LN && p.xsrc == GEMV_X_PLAIN &&
+    if (p.Mtot > 0 && p.rt_nz > 0 && p.in_mode == GEMV_IN_LN && p.xsrc == GEMV_X_PLAIN &&
         (p.out_mode == GEMV_OUT_GELU_F16 || p.out_mode == GEMV_OUT_QKV) && (p.N + 15) / 16 >= 128 && ((p.N + 15) / 16) % 2 == 0) c.NTB = 2;
     // ... four where the tile count allows (60 rows, Whisper-small: first projection 6.6 -> 6.1 us, first MLP projection 6.5 -> 5.9 us; the 4 x 12
     // configuration +1.5 %, profiles/r4r_*). WLX_RT_NTB4=0 keeps two (A/B).
-    static const bool rt_ntb4 = [] { const char* e = getenv("WLX_RT_NTB4"); return !(e && e[0] == '0'); }();
-    if (rt_ntb4 && c.NTB == 2 && p.Mtot > 0 && p.rt_nz > 0 && ((p.N + 15) / 16) % 4 == 0 && p.M <= 16) c.NTB = 4;
+    if (c.NTB == 2 && p.Mtot > 0 && p.rt_nz > 0 && ((p.N + 15) / 16) % 4 == 0 && p.M <= 16) c.NTB = 4;
     // The row-tiled fp16-rows-in residual projections stage their 16 rows x K per 16-column workgroup as well. Two column tiles per
     // workgroup cost a single slot latency (4.7 -> 5.3 us per launch: half as many workgroups for a launch of 192) but save work, and with
     // three or more slots decoding on the device the GPU is work-bound: 4 x 12 windows +3 % (profiles/r4r_*). The engine
     // passes that situation in as GemvParams::busy_device. WLX_RT_F16_NTB2=0 / 1 forces it off / on (A/B).
-    static const int rt_f16_ntb2 = [] { const char* e = getenv("WLX_RT_F16_NTB2"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
+    static const int rt_f16_ntb2 = [] { const char* e = wlx_ab("WLX_RT_F16_NTB2"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     const bool f16_wide = rt_f16_ntb2 >= 0 ? rt_f16_ntb2 == 1 : p.busy_device != 0;
     if (f16_wide && p.Mtot > 0 && p.rt_nz > 0 && p.M <= 16 && p.in_mode == GEMV_IN_F16 && p.out_mode == GEMV_OUT_RESID && p.xsrc == GEMV_X_PLAIN && ((p.N + 15) / 16) % 2 == 0) c.NTB = 2;   // (one row tile per chunk: the only two-tile instantiation)
     // (measured and dropped, profiles/r4t_*: two tiles for the N = d_model LayerNorm + query projection under a busy device — no change;
@@ -1142,9 +1131,6 @@ static bool gemv2_launch_qkv_xs(const GemvParams& p, const Gemv2Cfg& c, dim3 gri
 template <int CH, int MT>
 static bool gemv2_launch_other(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, dim3 block, hipStream_t s) {
     if (p.in_mode == GEMV_IN_F16) {
-        if (p.out_mode == GEMV_OUT_QKV) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_QKV, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
-        if (p.out_mode == GEMV_OUT_F16) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_F16, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
-        if (p.out_mode == GEMV_OUT_GELU_F16) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_GELU_F16, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
         if (p.out_mode == GEMV_OUT_SLAB) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_SLAB, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
         if (p.xsrc == GEMV_X_SLABS) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, MT, GEMV_X_SLABS>(grid, block, c.shm, s, p); return true; }
         if (c.NTB == 2 && MT == 1) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 2, 1, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
@@ -1192,12 +1178,6 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
         if (c.CH == 2 && c.LNV == 15) return c.MT == 1 ? gemv2_launch_ln<2, 15, 1>(p, c, grid, block, s) : false;   // (one row tile: batched rows run as row tiles)
         return false;
     }
-    if (p.in_mode == GEMV_IN_XATTN && c.CH < 4) {
-        if (c.MT != 1) return false;                                       // (the 8-wave combine is picked for one row tile only, gemv2_cfg)
-        if (c.CH == 3) g2_launch<3, 1, GEMV_IN_XATTN, GEMV_OUT_RESID, 1, 1, GEMV_X_PLAIN>(grid, block, c.shm, s, p);
-        else g2_launch<2, 1, GEMV_IN_XATTN, GEMV_OUT_RESID, 1, 1, GEMV_X_PLAIN>(grid, block, c.shm, s, p);
-        return true;
-    }
     switch (c.CH) {
         case 6: return WLX_G2_OT(6);
         case 5: return WLX_G2_OT(5);
@@ -1225,11 +1205,8 @@ static bool gemv2_ok(const GemvParams& p, Gemv2Cfg* out) {
 // 17..WLX_ROWTILE_MAX rows (batched decode steps): row chunks of one 16-row tile folded into blockIdx.x (round 4, see
 // dec_gemv2_kernel). WLX_ROWTILE=0 restores the 48-row form (A/B).
 static GemvParams gemv_chunked(const GemvParams& p) {
-    static const bool rt_on = [] { const char* e = getenv("WLX_ROWTILE"); return !(e && e[0] == '0'); }();
-    static const int rt_max = [] { const char* e = getenv("WLX_ROWTILE_MAX"); const int v = e ? atoi(e) : WLX_MAX_DEC_ROWS; return v < 16 ? 16 : v; }();
-    // (experiments: WLX_ROWTILE_NMAX = widest N that is cut into row tiles, WLX_ROWTILE_CHUNK = rows per tile: 16 / 32 / 48)
-    static const int rt_nmax = [] { const char* e = getenv("WLX_ROWTILE_NMAX"); return e ? atoi(e) : (1 << 30); }();
-    static const int rt_chunk = [] { const char* e = getenv("WLX_ROWTILE_CHUNK"); const int v = e ? atoi(e) : 16; return (v == 32 || v == 48) ? v : 16; }();
+    static const bool rt_on = [] { const char* e = wlx_ab("WLX_ROWTILE"); return !(e && e[0] == '0'); }();
+    constexpr int rt_max = WLX_MAX_DEC_ROWS, rt_chunk = 16;      // (32- and 48-row tiles, and a cap on the N that is cut, were measured in round 4: DESIGN.md)
     GemvParams q = p;
     if (p.Mtot != 0 || p.in_mode == GEMV_IN_XATTN) return q;
     // Which projections: measured per kernel at 20 / 40 / 60 rows (profiles/r4a-c_*): row tiles win wherever the launch has few
@@ -1240,19 +1217,17 @@ static GemvParams gemv_chunked(const GemvParams& p) {
     // projection 8.8 -> 7.7 us, first MLP projection 9.2 -> 7.6 us, step 2183 -> 2087 us; profiles/r4lv3rt_decode_step.txt): every
     // LayerNorm-fronted projection whose tile count divides by four is cut too from three row tiles up (60 rows: 3157 -> 2857 us; 20 rows,
     // two row tiles: 1845 -> 1905 us, left as it was). WLX_ROWTILE_WIDE=0 = the earlier policy (A/B).
-    static const bool rt_wide = [] { const char* e = getenv("WLX_ROWTILE_WIDE"); return !(e && e[0] == '0'); }();
-    const bool ln_wide4 = rt_wide && rt_chunk == 16 && p.M > 32 && p.in_mode == GEMV_IN_LN && p.xsrc == GEMV_X_PLAIN && (p.out_mode == GEMV_OUT_QKV || p.out_mode == GEMV_OUT_GELU_F16) &&
+    const bool ln_wide4 = p.M > 32 && p.in_mode == GEMV_IN_LN && p.xsrc == GEMV_X_PLAIN && (p.out_mode == GEMV_OUT_QKV || p.out_mode == GEMV_OUT_GELU_F16) &&
                           (p.N & 15) == 0 && ((p.N >> 4) & 3) == 0;
     const bool rt_shape = p.N <= 1536 || (long)p.N * p.K <= 3200000L || ln_wide4;
-    if (rt_on && !g_decode_v1 && p.M > rt_chunk && p.M <= rt_max && p.N <= rt_nmax && (rt_shape || rt_nmax != (1 << 30))) { q.Mtot = p.M; q.M = rt_chunk; q.chunk = rt_chunk; q.rt_nz = (p.M + rt_chunk - 1) / rt_chunk; }
+    if (rt_on && !g_decode_v1 && p.M > rt_chunk && p.M <= rt_max && rt_shape) { q.Mtot = p.M; q.M = rt_chunk; q.chunk = rt_chunk; q.rt_nz = (p.M + rt_chunk - 1) / rt_chunk; }
     else if (p.M > 48 && p.xsrc != GEMV_X_EMBED) { q.Mtot = p.M; q.M = 48; q.chunk = 48; }
     return q;
 }
 bool dec_gemv_is_lean(const GemvParams& p) { return gemv2_ok(gemv_chunked(p), nullptr); }
 
 int dec_gemv_slab_split(int M, int K, int N) {
-    static const int ks_env = [] { const char* e = getenv("WLX_FC2_KS"); return e ? atoi(e) : WLX_FC2_KS; }();
-    if (ks_env != WLX_FC2_KS || WLX_FC2_KS < 2) return 0;                     // (the slab count is a compile-time constant of the consumers)
+    if (WLX_FC2_KS < 2) return 0;                                             // (the slab count is a compile-time constant of the consumers: -DWLX_FC2_KS)
     if (g_decode_v1 || M < 1 || K % 32 || (K / 32) % WLX_FC2_KS || K < 2048) return 0;
     GemvParams p0{};
     p0.in_mode = GEMV_IN_F16; p0.out_mode = GEMV_OUT_SLAB; p0.M = M; p0.K = K; p0.KT = K / 32; p0.N = N; p0.KTS = p0.KT / WLX_FC2_KS;
@@ -1281,57 +1256,6 @@ const char* dec_gemv_kernel_name(const GemvParams& p_any) {
     }
     snprintf(buf, sizeof(buf), "dec_gemv_kernel<%d, %d, %d>", MT > 4 ? 4 : MT, MT == 1 ? 2 : 1, p.in_mode);
     return buf;
-}
-
-// ------------------------------------------------------------------ LayerNorm of the decoder rows on its own (batched rows, A/B)
-// One wave per row, the arithmetic of the LayerNorm prologues above to the last bit (same lane layout, same summation order): fp16
-// rows for projections that then run as plain fp16-rows-in launches. At 60 rows a LayerNorm-fronted projection spends ~90 % of its
-// instructions re-normalising the rows in every 16-column workgroup (144-192 times per launch); this is the alternative the
-// round-2 / round-3 reviews asked for. WLX_BATCHED_LN=1 selects it (engine.hip decoder_pass); see DESIGN.md §7 for the measurement.
-template <int LNV>
-__global__ __launch_bounds__(256) void dec_ln_rows_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, half_t* __restrict__ out, long ldo, int M WLX_TR_PARAM) {
-    WLX_TR_BEGIN();
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (r < M) {
-        const float4* x4 = reinterpret_cast<const float4*>(X + (long)r * ldx) + lane;
-        const float4* g4 = reinterpret_cast<const float4*>(gamma) + lane;
-        const float4* b4 = reinterpret_cast<const float4*>(beta) + lane;
-        float4 x[LNV], gq[LNV], bq[LNV];
-#pragma unroll
-        for (int j = 0; j < LNV; ++j) { x[j] = x4[64 * j]; gq[j] = g4[64 * j]; bq[j] = b4[64 * j]; }
-        constexpr float invK = 1.0f / (256.0f * LNV);
-        float sm = 0.f;
-#pragma unroll
-        for (int j = 0; j < LNV; ++j) sm += (x[j].x + x[j].y) + (x[j].z + x[j].w);
-        const float mean = wave_sum_dpp(sm) * invK;
-        float q = 0.f;
-#pragma unroll
-        for (int j = 0; j < LNV; ++j) {
-            x[j].x -= mean; x[j].y -= mean; x[j].z -= mean; x[j].w -= mean;
-            q += (x[j].x * x[j].x + x[j].y * x[j].y) + (x[j].z * x[j].z + x[j].w * x[j].w);
-        }
-        const float rstd = rsqrtf(wave_sum_dpp(q) * invK + 1e-5f);
-        half_t* dst = out + (long)r * ldo + lane * 4;
-#pragma unroll
-        for (int j = 0; j < LNV; ++j) {
-            const f16x4 hv = {(half_t)(x[j].x * rstd * gq[j].x + bq[j].x), (half_t)(x[j].y * rstd * gq[j].y + bq[j].y),
-                              (half_t)(x[j].z * rstd * gq[j].z + bq[j].z), (half_t)(x[j].w * rstd * gq[j].w + bq[j].w)};
-            *reinterpret_cast<f16x4*>(dst + 256 * j) = hv;
-        }
-    }
-    WLX_TR_END(trc);
-}
-bool dec_ln_rows_ok(int d) { return d % 256 == 0 && d / 256 >= 2 && d / 256 <= 5; }
-void launch_dec_ln_rows(const float* X, long ldx, const float* gamma, const float* beta, half_t* out, long ldo, int M, int d, hipStream_t s) {
-    const dim3 grid((M + 3) / 4), block(256);
-    switch (d / 256) {
-        case 2: hipLaunchKernelGGL((dec_ln_rows_kernel<2>), grid, block, 0, s, X, ldx, gamma, beta, out, ldo, M WLX_TR_ARG("ln_rows")); break;
-        case 3: hipLaunchKernelGGL((dec_ln_rows_kernel<3>), grid, block, 0, s, X, ldx, gamma, beta, out, ldo, M WLX_TR_ARG("ln_rows")); break;
-        case 4: hipLaunchKernelGGL((dec_ln_rows_kernel<4>), grid, block, 0, s, X, ldx, gamma, beta, out, ldo, M WLX_TR_ARG("ln_rows")); break;
-        default: hipLaunchKernelGGL((dec_ln_rows_kernel<5>), grid, block, 0, s, X, ldx, gamma, beta, out, ldo, M WLX_TR_ARG("ln_rows")); break;
-    }
 }
 
 // ------------------------------------------------------------------ vocabulary projection: final LayerNorm + tied output projection
@@ -1509,11 +1433,6 @@ static void vocab_go_mt(const VocabParams& p, hipStream_t s) {
         default: vocab_go<KT, KC, 4>(p, s); break;
     }
 }
-// WLX_VOCAB2 = 0 off, 1 batched rows only (> 16), 2 every row count (default)
-static int vocab2_mode() {
-    static const int m = [] { const char* e = getenv("WLX_VOCAB2"); return e ? atoi(e) : 2; }();
-    return m;
-}
 // rows one launch of dec_vocab_kernel takes: its fp16 LayerNorm rows must fit the workgroup's LDS (152 KiB: d_model <= 1024 64 rows,
 // large-v3 60 -> 48 = three whole row tiles). A wider pass (round 5: up to WLX_MAX_DEC_ROWS rows per step) runs as consecutive row
 // chunks, each streaming the weights again (Whisper-small 80 MB = ~25 us per 64 rows of a ~1 ms step).
@@ -1524,8 +1443,6 @@ static int vocab2_chunk_rows(int K) {
 }
 static bool vocab2_ok(const GemvParams& p) {
     if (g_decode_v1 || p.in_mode != GEMV_IN_LN || p.out_mode != GEMV_OUT_F32 || p.bias || p.xsrc != GEMV_X_PLAIN || p.Mtot != 0) return false;
-    const int mode = vocab2_mode();
-    if (mode == 0 || (mode == 1 && p.M <= 16)) return false;
     if (p.M < 1 || p.M > WLX_MAX_DEC_ROWS || p.K != p.KT * 32 || p.N < 256) return false;
     if (!(p.KT == 12 || p.KT == 16 || p.KT == 24 || p.KT == 32 || p.KT == 40)) return false;
     const int rows = std::min(p.M, vocab2_chunk_rows(p.K));
@@ -1742,8 +1659,7 @@ __global__ __launch_bounds__(64 * SA_NW) void dec_self_attn2_kernel(const half_t
 void launch_dec_self_attn(const half_t* q, long ldq, const half_t* Kc, const half_t* Vc, long crs, int d, int H,
                           const RowTables& rt, int rows, half_t* out, long ldo, const int* done, bool ident_ancestry, hipStream_t s) {
     (void)done;   // a step that runs after the search raised `done` only rewrites scratch (engine.hip decoder_pass)
-    static const bool no_ident = [] { const char* e = getenv("WLX_SELF_ATTN_IDENT"); return e && e[0] == '0'; }();   // (A/B)
-    if (ident_ancestry && !no_ident)
+    if (ident_ancestry)
         hipLaunchKernelGGL(dec_self_attn2_kernel<true>, dim3(rows, H), dim3(64 * SA_NW), 0, s, q, ldq, Kc, Vc, crs, d, rt.pos,
                            rt.ancrow, rt.anc, out, ldo WLX_TR_ARG("self_attn"));
     else
@@ -2074,7 +1990,7 @@ __global__ __launch_bounds__(XA_TPS * 64) void dec_cq_cross_attn_kernel(
 // eligibility: d_model 768 (LNV = 3, KT = 24 = 6 waves x 4 k-tiles), groups of <= 16 rows; WLX_NO_FUSED_CQ=1 forces the
 // two separate launches (A/B)
 bool dec_cq_cross_attn_eligible(int d, int H, int R) {
-    static const bool off = [] { const char* e = getenv("WLX_NO_FUSED_CQ"); return e && e[0] == '1'; }();
+    static const bool off = [] { const char* e = wlx_ab("WLX_NO_FUSED_CQ"); return e && e[0] == '1'; }();
     if (off || g_decode_v1 || d != 768 || H * 64 != d || R < 1 || R > 16) return false;
     const size_t xs_floats = (size_t)((R * (d + 8) * 2 + 15) / 16) * 4;
     const size_t shm = sizeof(float) * (xs_floats + (size_t)XA_TPS * 16 * 68 + XA_TPS * 16 * 2) + 16 * 72 * sizeof(half_t);

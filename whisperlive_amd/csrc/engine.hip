@@ -372,7 +372,7 @@ extern "C" int32_t wlx_engine_create(const wlx_spec* spec, const wlx_tensor* wei
         if (weights[i].on_device) { g_embedded_device_memory.store(true); break; }
     const char* ng = getenv("WLX_NO_GRAPH");
     e->use_graph = !(ng && ng[0] == '1');
-    const char* v1 = getenv("WLX_DECODE_V1");
+    const char* v1 = wlx_ab("WLX_DECODE_V1");
     g_decode_v1 = (v1 && v1[0] == '1');
     int rc = engine_load(e, weights, n_weights);
     if (rc != WLX_OK) {
@@ -543,7 +543,7 @@ static int create_slot_stream(int device, hipStream_t* out, bool* dedicated_out)
         static std::atomic<bool> said{false};
         if (!said.exchange(true) && getenv("WLX_QUIET") == nullptr)
             fprintf(stderr, "[wlx] slot streams: WLX_SLOT_CU_MASK=%s%s, up to %d hardware queues per device%s\n", m.c_str(),
-                    (!getenv("WLX_SLOT_CU_MASK") && g_embedded_device_memory.load()) ? " (chosen: weights were handed over as device pointers of another runtime)" : "",
+                    (m == "off" && g_embedded_device_memory.load()) ? " (weights were handed over as device pointers of another runtime: non-blocking streams unless the variable says otherwise)" : "",
                     max_dedicated,
                     m == "off" ? "" : " (CU-mask streams are blocking streams: keep NULL-stream work of this process off the device, or set WLX_SLOT_CU_MASK=off)");
     }
@@ -1051,40 +1051,25 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
     };
     // ---- what this pass may use (decided once, from the shapes only — never from what a profiling filter lets through):
     // the K-split MLP output projection needs every consumer of its slabs on the lean kernel; the embedding folds into
-    // layer 0's first projection under the same condition. WLX_NO_EMBED_FOLD=1 keeps the embedding launch (A/B).
-    static const bool no_fold = [] { const char* v = getenv("WLX_NO_EMBED_FOLD"); return v && v[0] == '1'; }();
+    // layer 0's first projection under the same condition (re-measured in round 5 against the separate embedding launch: 27.80 vs 28.02 ms
+    // per window, profiles/r5a_*).
     int KS = dec_gemv_slab_split(rows, F, d);
     if (rows > s.slab_rows) KS = 0;         // the partial-sum slabs of this working set hold slab_rows rows
     // batched decode steps (17..64 rows) keep the single MLP output launch (round 4, profiles/r4b_*): the split saves ~1 us
     // there but every consumer of the slabs then reads three fp32 copies of every row in its LayerNorm prologue — per 16-column
     // workgroup — and those launches are bound by load instructions per CU (60 rows, small.en: first projection 9.8 us with
-    // slabs, 7.0 us without; large-v3 at 40 rows: 11.4 -> 8.7 us). WLX_FC2_KS_BATCHED=1 keeps the split (A/B).
-    static const bool ks_batched = [] { const char* v = getenv("WLX_FC2_KS_BATCHED"); return v && v[0] == '1'; }();
-    if (rows > 16 && !alt && !ks_batched) KS = 0;
-    if (alt != nullptr && rows > 48 && [] { const char* v = getenv("WLX_PREFILL_LN"); return v && v[0] == '1'; }()) KS = 0;   // (the separate LayerNorm launch reads plain rows)
+    // slabs, 7.0 us without; large-v3 at 40 rows: 11.4 -> 8.7 us).
+    if (rows > 16 && !alt) KS = 0;
     if (KS && !(dec_gemv_is_lean(qkv_params(0, GEMV_X_SLABS)) && dec_gemv_is_lean(oproj_params(0, GEMV_X_SLABS)))) KS = 0;
     // (batched steps, 17..64 rows: the folded form gathers ONE row per wave and trip — two trips per 16-row tile, the second behind the
     // weight stream — and has no four-tile instantiation: 13.6 us at 60 rows against 2.4 + 5.9 us for the embedding launch + the plain
-    // four-tile projection, profiles/r4s_decode_step.txt. WLX_EMBED_FOLD_BATCHED=1 folds there too (A/B).)
-    static const bool fold_batched = [] { const char* v = getenv("WLX_EMBED_FOLD_BATCHED"); return v && v[0] == '1'; }();
-    const bool fold_embed = !no_fold && (rows <= 16 || alt != nullptr || (fold_batched && rows <= 64)) && dec_gemv_is_lean(qkv_params(0, GEMV_X_EMBED));
-    // (A/B, round 4) batched rows: ONE LayerNorm launch per layer phase writing fp16 rows (into the attention-output rows, which are
-    // free at those three points), the projections behind it as fp16-rows-in launches. WLX_BATCHED_LN=1.
-    static const bool batched_ln_env = [] { const char* v = getenv("WLX_BATCHED_LN"); return v && v[0] == '1'; }();
-    // (A/B, not measured yet — written at the end of round 4 without GPU minutes) the same for the prompt-prefill pass: its LayerNorm
-    // projections run as 48-row chunks whose every 16-column workgroup normalises its 48 rows again (23-27 us per launch at 224 rows,
-    // profiles/r4pf_conditioned_window_kernel_table.txt; estimated ~13 us as LayerNorm launch + fp16-rows-in projection). WLX_PREFILL_LN=1.
-    static const bool prefill_ln_env = [] { const char* v = getenv("WLX_PREFILL_LN"); return v && v[0] == '1'; }();
-    const bool sep_ln = !g_decode_v1 && dec_ln_rows_ok(d) &&
-                        ((batched_ln_env && rows > 16 && !alt) || (prefill_ln_env && alt != nullptr && rows > 48));
-    auto ln_to_f16 = [&](GemvParams& q) {       // q: a LayerNorm-fronted projection over the plain rows -> LayerNorm launch + fp16-rows-in projection
-        GemvParams t = q;
-        t.in_mode = GEMV_IN_F16; t.Xh = s.attnd; t.ldxh = d;
-        if (!dec_gemv_is_lean(t)) return false;
-        plaunch(s.base, "dec_ln_rows_kernel", 0.0, [&] { launch_dec_ln_rows(q.X, q.ldx, q.gamma, q.beta, s.attnd, d, rows, d, st); });
-        q = t;
-        return true;
-    };
+    // four-tile projection, profiles/r4s_decode_step.txt.)
+    // (prefill passes of more than 64 rows keep the embedding launch, as they always did: the folded form's K split over the waves — one
+    // row per wave — differs from the plain LayerNorm projection's, i.e. another summation order for the prompt rows' layer-0 K / V)
+    const bool fold_embed = (rows <= 16 || (alt != nullptr && rows <= 64)) && dec_gemv_is_lean(qkv_params(0, GEMV_X_EMBED));
+    // (Measured and closed: ONE LayerNorm launch per layer phase + fp16-rows-in projections instead of the LayerNorm prologue in every
+    // 16-column workgroup — for batched decode steps in round 4, for the prompt-prefill pass in round 5 (conditioned window 30.88 vs
+    // 30.89 ms, profiles/r5a_*): no gain either way; the kernel left the library.)
     if (!fold_embed)
         plaunch(s.base, "dec_embed_kernel", (double)rows * d * (2 + 4), [&] { launch_dec_embed(e->tok_emb16, e->dec_pos, d, rt, rows, s.xd, done, st); });
     bool slabs_pending = false;             // the residual stream is xd + slabs until the next residual update writes the sum back
@@ -1095,7 +1080,6 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
         // LN1 + QKV, K/V appended to the self-attention cache
         {
             GemvParams pq = qkv_params(l, (l == 0 && fold_embed) ? GEMV_X_EMBED : (slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN));
-            if (sep_ln && pq.xsrc == GEMV_X_PLAIN) (void)ln_to_f16(pq);
             pgemv(s.base, pq);
         }
         plaunch(s.base, "dec_self_attn2_kernel", 4.0 * rows * d * (s->prof ? s->prof->t + 1 : 1), [&] { launch_dec_self_attn(s.qd, d, kc, vc, crs, d, H, rt, rows, s.attnd, d, done, s->anc_ident, st); });
@@ -1119,7 +1103,6 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
             p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_F16; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
             p.Wp = w.Wcq; p.bias = w.bcq; p.X = s.xd; p.ldx = d; p.gamma = w.ln2_g; p.beta = w.ln2_b;
             p.Yh = s.qd; p.ldyh = d; p.qscale = 0.125f; p.done = done;
-            if (sep_ln) (void)ln_to_f16(p);
             pgemv(s.base, p);
             if (s->align) {     // word alignment: raw q.k of this layer's alignment heads for the rows of this chunk
                 const Slot::AlignCapture& a = *s->align;
@@ -1136,8 +1119,7 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
         p.in_mode = GEMV_IN_XATTN; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
         p.Wp = w.Wco; p.bias = w.bco; p.part_o = s.part_o; p.part_ml = s.part_ml; p.H = H; p.R = R;
         p.Xres = s.xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
-        static const bool no_sep = [] { const char* v = getenv("WLX_XATTN_SEPARATE"); return v && v[0] == '0'; }();   // (A/B)
-        if (rows > 16 && !no_sep) {
+        if (rows > 16) {
             // batched rows: the split combine once, in its own launch, then a plain fp16-rows-in projection (decoder.hip)
             plaunch(s.base, "dec_xattn_combine_kernel", 0.0, [&] { launch_dec_xattn_combine(s.part_o, s.part_ml, rows, H, R, s.attnd, d, st); });
             p.in_mode = GEMV_IN_F16; p.Xh = s.attnd; p.ldxh = d;
@@ -1148,7 +1130,6 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
         p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_GELU_F16; p.M = rows; p.K = d; p.KT = d / 32; p.N = F;
         p.Wp = w.W1; p.bias = w.b1; p.X = s.xd; p.ldx = d; p.gamma = w.ln3_g; p.beta = w.ln3_b;
         p.Yh = s.hd; p.ldyh = F; p.qscale = 1.f; p.done = done;
-        if (sep_ln) (void)ln_to_f16(p);
         pgemv(s.base, p);
         p = GemvParams{};
         p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = F; p.KT = F / 32; p.N = d;
@@ -1462,7 +1443,7 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
         // batch_inference batch): ALL items' prompt rows in ONE decoder pass — item b is row group b (16 rows, the unused ones
         // repeat the item's last prompt row: the same K / V written to the same cache position again) — instead of one full
         // pass per item, each of which streams every decoder weight (large-v3: 1.3 ms per item, 8 items per batch).
-        static const bool joint = [] { const char* v = getenv("WLX_PREFILL_JOINT"); return !(v && v[0] == '0'); }();
+        static const bool joint = [] { const char* v = wlx_ab("WLX_PREFILL_JOINT"); return !(v && v[0] == '0'); }();
         if (joint && batch > 1 && with_prompt > 1 && longest <= 16 && s->pf_ok && !s->align && !s->prof && !g_decode_v1) {
             // (the prefill working set holds WLX_T_TEXT rows = 28 items of 16 rows: a wider batch, round 5, goes in blocks of 28 items)
             const int IB = WLX_T_TEXT / 16;
@@ -1903,7 +1884,7 @@ extern "C" int32_t wlx_debug_time_decode_step(wlx_engine* e, int32_t slot, int32
     CK(hipMemsetAsync(s->st.done, 0, 4, st));
     hipGraph_t graph; hipGraphExec_t exec;
     decoder_pass(e, s, rows, tR, tG, true, true);      // eager first (dynamic-LDS limits are raised outside capture)
-    static const int passes = [] { const char* v = getenv("WLX_PROBE_PASSES_PER_GRAPH"); return v ? std::max(1, atoi(v)) : 1; }();   // (experiment: graph-to-graph boundary)
+    constexpr int passes = 1;      // (several steps per graph were measured in round 2: the ~7 us graph-to-graph boundary is not worth running past a transcript's end)
     CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     for (int q = 0; q < passes; ++q) decoder_pass(e, s, rows, tR, tG, true, true);
     CK(hipStreamEndCapture(st, &graph));

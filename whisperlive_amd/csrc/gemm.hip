@@ -23,6 +23,7 @@
 #include <algorithm>
 #include <type_traits>
 #include <cstdlib>
+#include <cstdio>
 
 namespace wlx {
 
@@ -287,128 +288,8 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
     }
 }
 
-template <int WNT, int WMT>
-__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
-    constexpr int KS = 2;                       // k-tiles (of 32) per LDS stage
-    constexpr int FA = 2 * WNT * KS;            // weight fragments per stage (1 KiB each)
-    constexpr int FB = 2 * WMT * KS;            // activation fragments per stage
-    constexpr int CA = FA / 4, CB = FB / 4;     // fragments each of the 4 waves copies per stage
-    extern __shared__ __attribute__((aligned(16))) f16x8 stage_lds[];   // [2][FA + FB][64 lanes] x 16 B
-    const int tid = threadIdx.x;
-    const int wave = tid >> 6, lane = tid & 63;
-    const int c = lane & 15, g = lane >> 4;
-    const int wn = wave & 1, wm = wave >> 1;
-    const int NT_total = (p.N + 15) >> 4;
-    const int ntb = blockIdx.x * (2 * WNT);     // first n-tile of the workgroup
-    const int mb = blockIdx.y * (2 * WMT * 16); // first row of the workgroup
-    const int nt0 = ntb + wn * WNT;
-    const int m0 = mb + wm * (WMT * 16);
-    const int z = blockIdx.z;
-    const half_t* A = p.A + (long)z * p.strideA;
-    const int KT = p.KT;
-
-    // global -> register -> LDS staging: wave w copies fragments w, w + 4, ... of the stage; both operands land in LDS
-    // in MFMA fragment order (weights are stored that way; an activation fragment is 16 rows x 64 contiguous bytes),
-    // so every LDS access of the kernel is a linear, conflict-free 16 bytes per lane.
-    const half_t* asrc[CA];
-    const half_t* bsrc[CB];
-#pragma unroll
-    for (int j = 0; j < CA; ++j) {
-        const int f = wave + 4 * j, ni = f / KS, kk = f % KS;
-        int nt = ntb + ni;
-        if (nt >= NT_total) nt = NT_total - 1;
-        asrc[j] = p.Wp + ((long)nt * KT + kk) * 512 + lane * 8;
-    }
-#pragma unroll
-    for (int j = 0; j < CB; ++j) {
-        const int f = wave + 4 * j, mi = f / KS, kk = f % KS;
-        int row = mb + mi * 16 + c;
-        if (row >= p.M) row = p.M - 1;
-        bsrc[j] = A + (long)row * p.lda + kk * 32 + g * 8;
-    }
-    f16x8 ra[CA], rb[CB];
-    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    auto gload = [&](int kt0) {
-#pragma unroll
-        for (int j = 0; j < CA; ++j) {
-            const int kk = (wave + 4 * j) % KS;
-            ra[j] = (kt0 + kk < KT) ? ld_f16x8(asrc[j] + (long)kt0 * 512) : zero8;
-        }
-#pragma unroll
-        for (int j = 0; j < CB; ++j) {
-            const int kk = (wave + 4 * j) % KS;
-            rb[j] = (kt0 + kk < KT) ? ld_f16x8(bsrc[j] + (long)kt0 * 32) : zero8;
-        }
-    };
-    auto lstore = [&](int buf) {
-        f16x8* dst = stage_lds + (long)buf * (FA + FB) * 64 + lane;
-#pragma unroll
-        for (int j = 0; j < CA; ++j) dst[(wave + 4 * j) * 64] = ra[j];
-#pragma unroll
-        for (int j = 0; j < CB; ++j) dst[(FA + wave + 4 * j) * 64] = rb[j];
-    };
-
-    f32x4 acc[WNT][WMT];
-#pragma unroll
-    for (int ni = 0; ni < WNT; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < WMT; ++mi) acc[ni][mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    const int S = (KT + KS - 1) / KS;
-    gload(0);
-    lstore(0);
-    __syncthreads();
-    for (int st = 0; st < S; ++st) {
-        const bool more = st + 1 < S;
-#ifndef WLX_PROBE_NO_GLOAD   // (WLX_PROBE_*: scripts/ubench/gemm_probe.hip removes one pipeline phase at a time; never defined in libwlx)
-        if (more) gload((st + 1) * KS);                                   // next stage in flight under this stage's MFMAs
-#endif
-        const f16x8* src = stage_lds + (long)(st & 1) * (FA + FB) * 64 + lane;
-#pragma unroll
-        for (int kk = 0; kk < KS; ++kk) {
-            f16x8 wf[WNT], af[WMT];
-#pragma unroll
-#ifndef WLX_PROBE_NO_LREAD
-            for (int ni = 0; ni < WNT; ++ni) wf[ni] = src[((wn * WNT + ni) * KS + kk) * 64];
-#pragma unroll
-            for (int mi = 0; mi < WMT; ++mi) af[mi] = src[(FA + (wm * WMT + mi) * KS + kk) * 64];
-#else
-            for (int ni = 0; ni < WNT; ++ni) wf[ni] = ra[ni % CA];
-#pragma unroll
-            for (int mi = 0; mi < WMT; ++mi) af[mi] = rb[mi % CB];
-#endif
-#pragma unroll
-            for (int ni = 0; ni < WNT; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < WMT; ++mi) {
-#ifndef WLX_PROBE_NO_MFMA
-                    acc[ni][mi] = mfma16(wf[ni], af[mi], acc[ni][mi]);
-#else
-                    asm volatile("" :: "v"(wf[ni]), "v"(af[mi]));
-#endif
-                }
-        }
-#ifndef WLX_PROBE_NO_LSTORE
-        if (more) lstore((st + 1) & 1);                                   // the other buffer: last read one barrier ago
-#endif
-#ifndef WLX_PROBE_NO_BARRIER
-        __syncthreads();
-#endif
-    }
-#ifdef WLX_PROBE_NO_EPILOGUE
-    {
-        float t = 0.f;
-#pragma unroll
-        for (int ni = 0; ni < WNT; ++ni)
-#pragma unroll
-            for (int mi = 0; mi < WMT; ++mi) t += acc[ni][mi][0] + acc[ni][mi][1] + acc[ni][mi][2] + acc[ni][mi][3];
-        if (t == 1.2345e30f) p.X[0] = t;
-        return;
-    }
-#endif
-
-    gemm_epilogue<WNT, WMT>(p, acc, nt0, m0, z, c, g);
-}
+// (The first form — register-staged double buffer, one stage ahead — was the A/B reference of round 2 and is no longer in the library
+// since round 5; the second form below is bit-identical to it, DESIGN.md "Encoder GEMM".)
 
 // ------------------------------------------------------------------------------------------------------------------
 // Second form (round 2): the same tiles, fragments, MFMA order and epilogue — bit-identical results — with the stage loop
@@ -702,7 +583,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
         auto kloop = [&](auto TRc) {
         constexpr bool TR = decltype(TRc)::value;
 #pragma unroll 1
-        for (int t = 0; t < ((p.xcd_a & 2) ? 2 : NK); t += 2) {    // (xcd_a: timing probes, 0 in production — WLX_GEMM3_PROBE, gemm3_go)
+        for (int t = 0; t < NK; t += 2) {
 #pragma unroll
             for (int u = 0; u < 2; ++u) {       // K tile t + u lives in buffer u (NK is even: launcher)
                 const int tt = t + u;
@@ -735,14 +616,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
         kpos += nper;
         const bool more = kpos < runlen;
         if (more) { set_tile(run0 + kpos); prologue(); }                    // (the clamped tail requests of this wave land before these: same wave, in order)
-        if (p.xcd_a & 1) {                                                  // probe: no epilogue (keep the accumulators alive)
-            float tsum = 0.f;
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int mi = 0; mi < 8; ++mi) tsum += acc[ni][mi][0] + acc[ni][mi][3];
-            if (tsum == 1.2345e30f) p.X[0] = tsum;
-        } else if (!staged) {
+        if (!staged) {
             gemm_epilogue<4, 8>(p, acc, nt0, m0, 0, c, g);
         } else if (trq) {
             // transposed accumulators: lane (c, g) holds rows m = m-tile + g*4 .. +3 of column nt*16 + c: an 8-byte piece of V^T (QKV) or of
@@ -828,11 +702,11 @@ __global__ __launch_bounds__(512) void gemm3_kernel(GemmParams p) {
     }
 }
 #define G3_LDS_BYTES (256 * (256 + 8) * 2)      // the fp16 output tile of the LDS-transposed epilogue (135168 B) >= the 128 KiB ring
+// WLX_GEMM3 (A/B builds, -DWLX_AB: common.h wlx_ab): 0 = off, 2 = every GEMM with M >= 256 on this form (the full-depth parity tests of
+// a single window are run once that way: the form is then held to the single-window path bit for bit)
 static bool gemm3_ok(const GemmParams& p, int zbatch) {
-    static const int mode = [] { const char* e = getenv("WLX_GEMM3"); return e ? atoi(e) : 1; }();   // 0 = off (A/B), 2 = any M
+    static const int mode = [] { const char* e = wlx_ab("WLX_GEMM3"); return e ? atoi(e) : 1; }();
     if (mode == 0 || zbatch != 1 || (p.N & 255) || (p.KT & 3) || p.KT < 8) return false;
-    static const bool resid_off = [] { const char* e = getenv("WLX_GEMM3_RESID"); return e && e[0] == '0'; }();   // (A/B) residual GEMMs (N = d_model) on the second form
-    if (resid_off && p.mode == GEMM_RESID_F32) return false;
     if ((long)p.M * p.lda * 2 >= (1L << 31) || (long)p.N * p.KT * 64 >= (1L << 31)) return false;   // 32-bit buffer offsets
     // measured (profiles/r4k_encode_shape_times.txt, Whisper-small): 2 windows (M = 3000) 2.77 ms here vs 2.60 on the 64 x 96 tile, 3 windows
     // (M = 4500) 3.10 vs 3.64, 12 windows 7.75 vs 11.8
@@ -841,26 +715,19 @@ static bool gemm3_ok(const GemmParams& p, int zbatch) {
 static void gemm3_go(const GemmParams& p0, hipStream_t s) {
     GemmParams p = p0;
     if (p.rows_per_item <= 0) p.rows_per_item = 4;
-    static const bool epi_lds = [] { const char* e = getenv("WLX_GEMM_EPI_LDS"); return !(e && e[0] == '0'); }();   // 0 = direct epilogue (A/B)
     const bool scatter = p.mode == GEMM_QKV || p.mode == GEMM_CROSS_KV;
-    p.epi_lds = (epi_lds && (p.rows_per_item & 3) == 0 && (!scatter || p.d % 256 == 0)) ? 1 : 0;
-    static const int probe = [] { const char* e = getenv("WLX_GEMM3_PROBE"); return e ? atoi(e) : 0; }();   // timing probes: 1 no epilogue, 2 one K-tile pair only
-    p.xcd_a = probe;
+    p.epi_lds = ((p.rows_per_item & 3) == 0 && (!scatter || p.d % 256 == 0)) ? 1 : 0;       // LDS-transposed epilogue wherever the shape allows it
+    p.xcd_a = 0;
     p.g3_gx = p.N / 256;
     p.g3_tiles = p.g3_gx * ((p.M + 255) / 256);
     // one workgroup per CU (the kernel holds 128 KiB of LDS and 256 registers); fewer when there are fewer tiles. A multiple of 8:
     // workgroup id % 8 is the XCD
     static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount; return n; }();
-    static const int cu_cap = [] { const char* e = getenv("WLX_GEMM3_CUS"); return e ? atoi(e) : 0; }();   // (A/B) leave CUs to other streams: this kernel fills a CU alone
-    const int cus = (cu_cap >= 8 && cu_cap < n_cu) ? cu_cap : n_cu;
-    const int nwg = std::min((cus / 8) * 8, ((p.g3_tiles + 7) / 8) * 8);   // (workgroups past the end of their XCD's run leave at once)
+    const int nwg = std::min((n_cu / 8) * 8, ((p.g3_tiles + 7) / 8) * 8);   // (workgroups past the end of their XCD's run leave at once)
     hipLaunchKernelGGL(gemm3_kernel, dim3(nwg), dim3(512), G3_LDS_BYTES, s, p);
 }
 
-// tile shapes of the second form: (WNT, WMT) wave tiles -> workgroup tile (32 WNT) x (32 WMT); ring depth by what fits
-// the 160 KiB of LDS with one workgroup per CU
-struct Gemm2Shape { int wnt, wmt, depth; };
-static const Gemm2Shape kGemm2Shapes[] = {{4, 4, 4}, {4, 6, 3}, {6, 4, 3}, {2, 3, 4}, {2, 4, 4}, {4, 2, 4}, {2, 2, 4}, {4, 4, 2}};   // (the last: 128 x 128 with 64 KiB = two workgroups per CU, measured for large M in round 4)
+// the second form's launch: (WNT, WMT) wave tiles -> workgroup tile (32 WNT) x (32 WMT), ring of DEPTH stages, XCD-aware tile map
 template <int WNT, int WMT, int DEPTH>
 static void gemm2_go(const GemmParams& p0, int zbatch, hipStream_t s) {
     constexpr size_t shm = (size_t)DEPTH * (4 * WNT + 4 * WMT) * 1024;
@@ -868,12 +735,10 @@ static void gemm2_go(const GemmParams& p0, int zbatch, hipStream_t s) {
     dim3 grid((NT_total + 2 * WNT - 1) / (2 * WNT), (p0.M + 32 * WMT - 1) / (32 * WMT), zbatch);
     GemmParams p = p0;
     p.xcd_a = p.xcd_b = 0;
-    static const bool epi_lds = [] { const char* e = getenv("WLX_GEMM_EPI_LDS"); return !(e && e[0] == '0'); }();   // 0 = direct epilogue (A/B)
-    p.epi_lds = epi_lds ? 1 : 0;
+    p.epi_lds = 1;                                          // fp16 outputs leave through the LDS-transposed epilogue
     if (p.rows_per_item <= 0) p.rows_per_item = 4;          // (modes without items: only its divisibility is looked at)
-    static const bool swz_on = [] { const char* e = getenv("WLX_GEMM2_XCD"); return !(e && e[0] == '0'); }();   // 0 = plain map (A/B)
     const int gx = (int)grid.x, gy = (int)grid.y;
-    if (swz_on && zbatch == 1 && (gx * gy) % 8 == 0 && gx * gy >= 16) {
+    if (zbatch == 1 && (gx * gy) % 8 == 0 && gx * gy >= 16) {
         // split of the 8 XCDs into a m-parts x b n-parts that minimises the bytes one XCD's L2 must hold:
         // activations / a + weights / b (both x K x 2 bytes; K cancels)
         double best = 1e300;
@@ -911,60 +776,21 @@ static hipError_t gemm2_optin() {      // > 64 KiB of dynamic LDS needs the opt-
 // the ring depth, both queues counted by hand; bit-identical results): 1.586-1.591 ms vs 1.583-1.598 — no change either, so the
 // LDS port is not it; the kernel was dropped again. What the probes leave standing: ~0.45 us of a 0.64 us stage remain with
 // neither fills nor MFMAs, i.e. the per-stage wait + barrier + LDS-read + issue sequence of four lock-stepped waves itself.
-static int gemm2_pick(const GemmParams& p, int zbatch) {
-    static const int forced = [] { const char* e = getenv("WLX_GEMM2_SHAPE"); return e ? atoi(e) : -1; }();
-    const int n_shapes = (int)(sizeof(kGemm2Shapes) / sizeof(kGemm2Shapes[0]));
-    if (forced >= 0 && forced < n_shapes) return forced;
-    static const int large = [] { const char* e = getenv("WLX_GEMM2_LARGE_SHAPE"); return e ? atoi(e) : 3; }();   // (A/B) shape for M >= 4000 launches that do not take the third form
-    if ((long)p.M * zbatch >= 4000 && large >= 0 && large < n_shapes) return large;   // (batched conv front end: 12 x 3000 / 1500 rows)
-    return 3;
-}
 int gemm_prepare_device() {      // once per engine, on the engine's device (wlx_engine_create)
-    hipError_t e = hipSuccess;
-    if (e == hipSuccess) e = gemm2_optin<4, 4, 4>();
-    if (e == hipSuccess) e = gemm2_optin<4, 6, 3>();
-    if (e == hipSuccess) e = gemm2_optin<6, 4, 3>();
-    if (e == hipSuccess) e = gemm2_optin<2, 3, 4>();
-    if (e == hipSuccess) e = gemm2_optin<2, 4, 4>();
-    if (e == hipSuccess) e = gemm2_optin<4, 2, 4>();
-    if (e == hipSuccess) e = gemm2_optin<2, 2, 4>();
-    if (e == hipSuccess) e = gemm2_optin<4, 4, 2>();
+    hipError_t e = gemm2_optin<2, 3, 4>();
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES);
     return (int)e;
 }
 
+// Every encoder GEMM: the large-M form where it applies (batched encodes), else the 64 x 96 tile of the second form — the one tile shape
+// left of the eight measured in rounds 2-4 (the comment above; the first form and the other instantiations left the library in round 5).
 void launch_gemm(const GemmParams& p, int zbatch, hipStream_t s) {
-    static const int form = [] { const char* e = getenv("WLX_ENC_GEMM"); return e ? atoi(e) : 2; }();   // 1 = first form (A/B)
-    if (form != 1 && gemm3_ok(p, zbatch)) { gemm3_go(p, s); return; }
-    if (form != 1 && (p.KT & 1) == 0 && p.KT >= 2) {
-        switch (gemm2_pick(p, zbatch)) {
-            case 0: gemm2_go<4, 4, 4>(p, zbatch, s); return;
-            case 1: gemm2_go<4, 6, 3>(p, zbatch, s); return;
-            case 2: gemm2_go<6, 4, 3>(p, zbatch, s); return;
-            case 3: gemm2_go<2, 3, 4>(p, zbatch, s); return;
-            case 4: gemm2_go<2, 4, 4>(p, zbatch, s); return;
-            case 5: gemm2_go<4, 2, 4>(p, zbatch, s); return;
-            case 7: gemm2_go<4, 4, 2>(p, zbatch, s); return;
-            default: gemm2_go<2, 2, 4>(p, zbatch, s); return;
-        }
+    if (gemm3_ok(p, zbatch)) { gemm3_go(p, s); return; }
+    if ((p.KT & 1) || p.KT < 2) {      // every K the engine builds is a multiple of 64 (d_model, ffn: multiples of 128; conv1: 3 n_mels padded)
+        fprintf(stderr, "[wlx] encoder GEMM with K = %d refused: the k-tile count must be even (wlx_engine_create validates the model shape)\n", p.KT * 32);
+        return;
     }
-    const int NT_total = (p.N + 15) / 16;
-    // tile choice: wide outputs get 128x128 workgroup tiles (4x4 wave tiles: 16 MFMAs per 8 fragment
-    // loads); narrow ones (N = d) use 64x64 so the launch still spreads over the 256 CUs.
-    long blocks_big = (long)((NT_total + 7) / 8) * ((p.M + 127) / 128) * zbatch;
-    if (blocks_big >= 200) {
-        dim3 grid((NT_total + 7) / 8, (p.M + 127) / 128, zbatch);
-        hipLaunchKernelGGL((gemm_kernel<4, 4>), grid, dim3(256), 2 * (16 + 16) * 1024, s, p);
-    } else {
-        long blocks_mid = (long)((NT_total + 7) / 8) * ((p.M + 63) / 64) * zbatch;
-        if (blocks_mid >= 200) {
-            dim3 grid((NT_total + 7) / 8, (p.M + 63) / 64, zbatch);
-            hipLaunchKernelGGL((gemm_kernel<4, 2>), grid, dim3(256), 2 * (16 + 8) * 1024, s, p);
-        } else {
-            dim3 grid((NT_total + 3) / 4, (p.M + 63) / 64, zbatch);
-            hipLaunchKernelGGL((gemm_kernel<2, 2>), grid, dim3(256), 2 * (8 + 8) * 1024, s, p);
-        }
-    }
+    gemm2_go<2, 3, 4>(p, zbatch, s);
 }
 
 // ---------------------------------------------------------------- LayerNorm (wave per row)
