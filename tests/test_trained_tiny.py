@@ -111,7 +111,7 @@ def test_hip_engine_transcribes_the_trained_checkpoint(gpu):
 # The same learned function through the BENCHMARKED kernels (VERDICT r03 'weak' 2 / task 3): the trained checkpoint widened
 # function-preservingly (tests/golden/widen_trained_tiny.py) to Whisper-small's widths (d_model 768 / 12 heads / ffn 3072) and
 # to large-v3's (1280 / 20 / 5120). d_model 128 is rejected by the lean decode kernels; 768 and 1280 are exactly their shapes.
-LEAN_NAMES = ("dec_gemv2_kernel", "dec_self_attn2_kernel", "dec_sao_kernel")
+LEAN_NAMES = ("dec_gemv2_kernel", "dec_self_attn2_kernel")
 
 
 @pytest.fixture(scope="module")
@@ -157,12 +157,7 @@ def test_hip_engine_transcribes_the_widened_checkpoint_through_the_lean_kernels(
         names = [k["name"] for k in slot.debug_profile_step(5, 8, 2)]
         print("decode-step kernels:", sorted(set(names)))
         assert not any(n.startswith("dec_gemv_kernel<") for n in names), names          # nothing fell back to the general kernel
-        assert any(n.startswith("dec_gemv2_kernel<") for n in names), names
-        # Whisper-small shapes (round 5): self-attention + its output projection in one launch, its six partial-sum slabs read by the fused
-        # cross-attention launch and by the cross-attention output projection (xsrc 3 = GEMV_X_SLABS6); other widths keep the two launches
-        assert any(n.startswith("dec_sao_kernel") for n in names) == (d_model == 768), names
-        assert any(n.startswith("dec_self_attn2_kernel") for n in names) == (d_model != 768), names
-        assert any(n.startswith("dec_gemv2_kernel<") and n.endswith(", 2, 3, 1, 1, 3>") for n in names) == (d_model == 768), names
+        assert any(n.startswith("dec_gemv2_kernel<") for n in names) and any(n.startswith("dec_self_attn2_kernel") for n in names), names
         assert any(n.startswith("dec_cq_cross_attn_kernel") for n in names) == (d_model == 768), names   # the fused query + cross attention: Whisper-small shapes
         assert any(n.startswith("dec_gemv2_kernel<") and n.endswith(", 5, 1, 1, 0>") for n in names), names   # the K-split MLP projection (out mode 5 = GEMV_OUT_SLAB)
         assert any(n.startswith("dec_gemv2_kernel<") and n.endswith(", 1>") for n in names), names            # ... and a consumer of its slabs (xsrc 1)

@@ -34,9 +34,7 @@ enum GemvOut : int { GEMV_OUT_F16 = 0, GEMV_OUT_GELU_F16 = 1, GEMV_OUT_F32 = 2, 
 //   SLABS  those rows + the WLX_FC2_KS partial-sum slabs the K-split MLP output projection of the previous layer left
 //          (nobody materialises the sum until the next residual update writes it back);
 //   EMBED  token embedding + position (layer 0: the separate embedding launch folded into the first projection's prologue).
-//   SLABS6 (round 5) those rows + the WLX_SAO_SLABS partial-sum slabs dec_sao_kernel left (residual epilogue of the cross-attention output
-//          projection only: it writes the sum back).
-enum GemvXsrc : int { GEMV_X_PLAIN = 0, GEMV_X_SLABS = 1, GEMV_X_EMBED = 2, GEMV_X_SLABS6 = 3 };
+enum GemvXsrc : int { GEMV_X_PLAIN = 0, GEMV_X_SLABS = 1, GEMV_X_EMBED = 2 };
 #ifndef WLX_FC2_KS
 #define WLX_FC2_KS 2          // K slices of the lean MLP output projection (compile time: the consumers unroll over the slabs)
 #endif
@@ -108,13 +106,6 @@ int dec_gemv_slab_split(int M, int K, int N);
 void launch_dec_self_attn(const half_t* q, long ldq, const half_t* Kc, const half_t* Vc, long cache_row_stride,
                           int d, int H, const RowTables& rt, int rows, half_t* out, long ldo,
                           const int* done, bool ident_ancestry, hipStream_t s);
-// self-attention + attention output projection in one launch (round 5, decoder.hip dec_sao_kernel): partial rows to the H / 2 slabs of
-// slabB; the consumers read rows + slabs (GEMV_X_SLABS6, dec_cq_cross_attn_kernel's slab prologue). d_model 768 / 12 heads / <= 16 rows.
-#define WLX_SAO_SLABS 6
-bool dec_sao_eligible(int d, int H, int rows);
-void launch_dec_sao(const half_t* q, long ldq, const half_t* Kc, const half_t* Vc, long cache_row_stride, int d, int H, const RowTables& rt,
-                    int rows, const half_t* Wo, const float* bo, const float* slabA, long slabA_stride, float* slabB, long slabB_stride,
-                    bool ident_ancestry, hipStream_t s);
 // cross-attention of R rows per item against the item's 1500 encoder keys, split over keys; groups of R (<=16) rows,
 // group_item[g] = audio item whose K/V group g attends to. Kp / Vp: tile-packed cross K / V of ONE decoder layer
 // (gemm.hip GEMM_CROSS_KV), item_stride halfs per item.
@@ -126,8 +117,7 @@ void launch_dec_cross_attn(const half_t* q, long ldq, const half_t* Kp, const ha
 bool dec_cq_cross_attn_eligible(int d, int H, int R);
 void launch_dec_cq_cross_attn(const float* X, long ldx, const float* gamma, const float* beta, const half_t* Wp, const float* bias,
                               float qscale, int d, const half_t* Kp, const half_t* Vp, long item_stride, int H, int R, int groups,
-                              int rows, const int* group_item, half_t* part_o, float* part_ml, const float* sao_slabs, long sao_slab_stride,
-                              hipStream_t s);      // sao_slabs: the residual rows are X + dec_sao_kernel's WLX_SAO_SLABS slabs (nullptr: plain rows)
+                              int rows, const int* group_item, half_t* part_o, float* part_ml, hipStream_t s);
 // combine of the cross attention's split partials into fp16 rows out[M][H*64] (batched rows: see decoder.hip)
 void launch_dec_xattn_combine(const half_t* part_o, const float* part_ml, int M, int H, int R, half_t* out, long ldo, hipStream_t s);
 // raw cross-attention scores of head h (tile-packed K of one layer AND item) for `rows` query rows -> out[rows][1536] fp32

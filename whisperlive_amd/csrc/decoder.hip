@@ -474,10 +474,8 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
         if (p.row_cache) p.row_cache += r0;
         if (p.row_pos) p.row_pos += r0;
     }
-    static_assert(XS == GEMV_X_PLAIN || (IN == GEMV_IN_LN && XS != GEMV_X_SLABS6) || (IN == GEMV_IN_F16 && OUT == GEMV_OUT_RESID && NTB == 1 && XS == GEMV_X_SLABS) ||
-                  (IN == GEMV_IN_XATTN && OUT == GEMV_OUT_RESID && NTB == 1 && MT == 1 && XS == GEMV_X_SLABS6),
+    static_assert(XS == GEMV_X_PLAIN || IN == GEMV_IN_LN || (IN == GEMV_IN_F16 && OUT == GEMV_OUT_RESID && NTB == 1),
                   "slab / embedding sources: LayerNorm prologue or residual epilogue only");
-    constexpr int NSLR = (OUT != GEMV_OUT_RESID) ? 0 : (XS == GEMV_X_SLABS ? WLX_FC2_KS : (XS == GEMV_X_SLABS6 ? WLX_SAO_SLABS : 0));   // slabs the residual epilogue sums
     static_assert(OUT != GEMV_OUT_SLAB || (IN == GEMV_IN_F16 && NTB == 1), "K-split form: fp16 rows in");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63, c = lane & 15, g = lane >> 4;
@@ -546,10 +544,10 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
     if constexpr (OUT != GEMV_OUT_F32) bias_e = *reinterpret_cast<const float4*>(p.bias + n_e);
     if constexpr (OUT == GEMV_OUT_RESID) res_e = *reinterpret_cast<const float4*>(p.Xres + (long)row_e * p.ldxres + n_e);
     if constexpr (OUT == GEMV_OUT_QKV) { rc_e = p.row_cache[row_e]; rp_e = p.row_pos[row_e]; }
-    float4 slab_e[NSLR > 0 ? NSLR : 1];
-    if constexpr (NSLR > 0) {                                              // the residual is rows + slabs (summed at the store)
+    float4 slab_e[(OUT == GEMV_OUT_RESID && XS == GEMV_X_SLABS) ? WLX_FC2_KS : 1];
+    if constexpr (OUT == GEMV_OUT_RESID && XS == GEMV_X_SLABS) {           // the residual is rows + slabs (summed at the store)
 #pragma unroll
-        for (int sl = 0; sl < NSLR; ++sl)
+        for (int sl = 0; sl < WLX_FC2_KS; ++sl)
             slab_e[sl] = *reinterpret_cast<const float4*>(p.slab + sl * p.slab_stride + (long)row_e * p.ldxres + n_e);
     }
     if constexpr (OUT == GEMV_OUT_SLAB) { if (blockIdx.y != 0) bias_e = make_float4(0.f, 0.f, 0.f, 0.f); }   // the bias once: slice 0
@@ -907,9 +905,9 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
         const int rr = (row_p < p.M) ? row_p : p.M - 1;
         if constexpr (OUT != GEMV_OUT_F32) bias_e = *reinterpret_cast<const float4*>(p.bias + n_p);
         if constexpr (OUT == GEMV_OUT_RESID) res_e = *reinterpret_cast<const float4*>(p.Xres + (long)rr * p.ldxres + n_p);
-        if constexpr (NSLR > 0) {
+        if constexpr (OUT == GEMV_OUT_RESID && XS == GEMV_X_SLABS) {
 #pragma unroll
-            for (int sl = 0; sl < NSLR; ++sl)
+            for (int sl = 0; sl < WLX_FC2_KS; ++sl)
                 slab_e[sl] = *reinterpret_cast<const float4*>(p.slab + sl * p.slab_stride + (long)rr * p.ldxres + n_p);
         }
         if constexpr (OUT == GEMV_OUT_SLAB) { if (blockIdx.y != 0) bias_e = make_float4(0.f, 0.f, 0.f, 0.f); }
@@ -936,9 +934,9 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
             if (n_e + 3 < p.N) *reinterpret_cast<float4*>(yp) = make_float4(o0, o1, o2, o3);
             else { if (n_e < p.N) yp[0] = o0; if (n_e + 1 < p.N) yp[1] = o1; if (n_e + 2 < p.N) yp[2] = o2; }
         } else if constexpr (OUT == GEMV_OUT_RESID) {
-            if constexpr (NSLR > 0) {                                       // rows + slabs (the LayerNorm prologue's association)
+            if constexpr (XS == GEMV_X_SLABS) {                             // rows + slabs (the LayerNorm prologue's association)
 #pragma unroll
-                for (int sl = 0; sl < NSLR; ++sl) { res_e.x += slab_e[sl].x; res_e.y += slab_e[sl].y; res_e.z += slab_e[sl].z; res_e.w += slab_e[sl].w; }
+                for (int sl = 0; sl < WLX_FC2_KS; ++sl) { res_e.x += slab_e[sl].x; res_e.y += slab_e[sl].y; res_e.z += slab_e[sl].z; res_e.w += slab_e[sl].w; }
             }
             *reinterpret_cast<float4*>(p.Xres + (long)c * p.ldxres + n_e) =
                 make_float4(res_e.x + o0, res_e.y + o1, res_e.z + o2, res_e.w + o3);
@@ -1007,8 +1005,7 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     if (p.xsrc != GEMV_X_PLAIN) {
         const bool ln_ok = p.in_mode == GEMV_IN_LN && p.out_mode == GEMV_OUT_QKV;
         const bool res_ok = p.in_mode == GEMV_IN_F16 && p.out_mode == GEMV_OUT_RESID && p.xsrc == GEMV_X_SLABS;
-        const bool sao_ok = p.in_mode == GEMV_IN_XATTN && p.out_mode == GEMV_OUT_RESID && p.xsrc == GEMV_X_SLABS6 && p.M <= 16 && p.Mtot == 0;
-        if (p.xsrc == GEMV_X_SLABS6 ? !sao_ok : !(ln_ok || res_ok)) return c;
+        if (!(ln_ok || res_ok)) return c;
     }
     int KTf = p.KT;                                                           // k-tiles one workgroup multiplies
     if (p.out_mode == GEMV_OUT_SLAB) {
@@ -1138,9 +1135,6 @@ static bool gemv2_launch_other(const GemvParams& p, const Gemv2Cfg& c, dim3 grid
         if (p.xsrc == GEMV_X_SLABS) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, MT, GEMV_X_SLABS>(grid, block, c.shm, s, p); return true; }
         if (c.NTB == 2 && MT == 1) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 2, 1, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
         g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p);
-    } else if (p.xsrc == GEMV_X_SLABS6) {
-        if (MT != 1) return false;
-        g2_launch<CH, 1, GEMV_IN_XATTN, GEMV_OUT_RESID, 1, 1, GEMV_X_SLABS6>(grid, block, c.shm, s, p);
     } else g2_launch<CH, 1, GEMV_IN_XATTN, GEMV_OUT_RESID, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p);
     return true;
 }
@@ -1673,205 +1667,6 @@ void launch_dec_self_attn(const half_t* q, long ldq, const half_t* Kc, const hal
                            rt.ancrow, rt.anc, out, ldo WLX_TR_ARG("self_attn"));
 }
 
-// ------------------------------------------------------------------ self-attention + attention output projection in ONE launch (round 5)
-// A decoder layer at 5 rows was seven dependent launches of 3.1-6.6 us, each ~1 us above the floor of a dependent phase: the
-// step is bound by its launch COUNT. This kernel removes one launch per layer: the workgroup of (row r, head pair hp) runs the two heads'
-// causal attention exactly as dec_self_attn2_kernel does (four waves per head, flash-style over 64-position blocks, merged through LDS in
-// wave order) and goes straight on to ITS K slice of the output projection — the 128 attention dims it has just produced against the
-// 768 x 128 slice of Wo (96 x 1 KiB fragments... 24 per wave), requested at kernel entry, behind the first ancestry / query requests, so the
-// weight stream lands in the shadow of the attention's dependent round trips (position -> ancestry -> K / V -> softmax). What leaves is a
-// PARTIAL row: slab hp of H / 2 = 6 fp32 slabs [hp][row][d_model]; nobody sums them in this launch (a cross-workgroup reduction costs a
-// launch boundary): the consumers — the LayerNorm prologue of dec_cq_cross_attn_kernel and the residual epilogue of the cross-attention
-// output projection (GEMV_X_SLABS6), which writes x + slabs + its own result back — read rows + slabs, the mechanism the K-split MLP
-// projection introduced in round 2. Slab 0 also carries the projection's bias and, when the previous layer's MLP partial sums are still
-// pending (slabA), those: after this launch the residual stream is x + slab 0 + ... + slab 5.
-// The five row-workgroups of a head pair sit on ONE XCD (workgroup id = hp + 8 row: its L2 fetches the 192 KiB weight slice once).
-// Eligibility (launcher): d_model 768, 12 heads (NTW = 6 n-tiles per wave), <= 16 rows, decode steps only.
-struct SaoParams {
-    const half_t* q; long ldq;
-    const half_t* Kc; const half_t* Vc; long crs; int d;
-    const int* pos; const int* ancrow; const short* anc;
-    const half_t* Wp; int KT; const float* bias;
-    const float* slabA; long slabA_stride;      // pending K-split MLP partial sums of the previous layer [WLX_FC2_KS][.][d] (nullptr: none)
-    float* slabB; long slabB_stride;            // out: [H / 2][.][d]
-    int H;
-    WLX_TR_FIELD
-};
-template <bool IDENT, int NTW>
-__global__ __launch_bounds__(512) void dec_sao_kernel(SaoParams p) {
-    __shared__ float prob_s[8][64];
-    __shared__ int crow_s[8][64];
-    __shared__ float part_s[8][8][64];
-    __shared__ float ml_s[8][2];
-    __shared__ __attribute__((aligned(16))) half_t qs[8][64];            // the head's query row, per wave
-    __shared__ __attribute__((aligned(16))) half_t os[128];             // the two heads' attention outputs = this workgroup's K slice
-    __shared__ __attribute__((aligned(16))) float ys[NTW * 8 * 16];      // the partial output row, gathered from the lanes that hold it
-    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int hp = (int)blockIdx.x & 7, r = (int)blockIdx.x >> 3;
-    if (hp >= (p.H >> 1)) return;                                       // (the grid is padded to 8 workgroups per row)
-    WLX_TR_BEGIN();
-    const int hsel = w >> 2, sw = w & 3;
-    const int h = 2 * hp + hsel;
-    // ---- the attention's first requests FIRST (vmcnt retires in order: they must not queue behind the weight slice)
-    const short* ar = p.anc + (long)(IDENT ? r : p.ancrow[r]) * WLX_T_TEXT;
-    int cr0 = 0;
-    if constexpr (IDENT) cr0 = ar[sw * 64 + lane];
-    const int len = p.pos[r] + 1;
-    const int nblk = (len + 63) >> 6;
-    const bool active = sw < nblk;                                      // this wave walks blocks sw, sw + 4, ... of its head (wave 0 of a head always)
-    // the head's query row goes through LDS (a broadcast read per use) instead of 32 registers per lane held across the loop: with the
-    // 24 KiB of weights this wave keeps in flight the kernel sat at 256 VGPRs and spilled
-    const f16x8 q8 = ld_f16x8(p.q + (long)r * p.ldq + h * WLX_HEAD_DIM + (lane & 7) * 8);
-    // epilogue operands of the finishing threads (one float4 of the row each): bias and the pending MLP slabs go into slab 0
-    const int d4 = p.d >> 2;
-    const bool fin = (int)threadIdx.x < d4;
-    const int fi = fin ? (int)threadIdx.x : 0;
-    float4 eb = make_float4(0.f, 0.f, 0.f, 0.f), ea[WLX_FC2_KS];
-#pragma unroll
-    for (int sl = 0; sl < WLX_FC2_KS; ++sl) ea[sl] = eb;
-    if (hp == 0) {                                                      // (workgroup-uniform)
-        eb = reinterpret_cast<const float4*>(p.bias)[fi];
-        if (p.slabA) {
-#pragma unroll
-            for (int sl = 0; sl < WLX_FC2_KS; ++sl) ea[sl] = reinterpret_cast<const float4*>(p.slabA + sl * p.slabA_stride + (long)r * p.d)[fi];
-        }
-    }
-    asm volatile("" ::: "memory");                                      // compile-time fence: the weight requests stay behind the ones above
-    // ---- this wave's part of the weight slice: n-tiles w * NTW .. + NTW - 1, k-tiles 4 hp .. 4 hp + 3 (the two heads' 128 dims)
-    f16x8 wf[NTW][4];
-    {
-        const half_t* wq = p.Wp + (((long)(w * NTW) * p.KT + 4 * hp) * 64 + lane) * 8;
-#pragma unroll
-        for (int i = 0; i < NTW; ++i)
-#pragma unroll
-            for (int kt = 0; kt < 4; ++kt) wf[i][kt] = ld_nt_f16x8(wq + ((long)i * p.KT + kt) * 512);
-    }
-    // ---- causal attention of (row r, head h): dec_self_attn2_kernel's arithmetic, operation for operation
-    float* prob = prob_s[w];
-    int* crow = crow_s[w];
-    const int pg = lane >> 3, dc = lane & 7;
-    const int hoff = h * WLX_HEAD_DIM;
-    const int icrs = (int)p.crs;
-    float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    float mrun = WLX_NEG_INF, lrun = 0.f;
-    if (lane < 8) *reinterpret_cast<f16x8*>(qs[w] + lane * 8) = q8;      // (read back by this same wave only)
-    WLX_TR_MARK(1);
-    if (active) {
-#pragma unroll 1
-        for (int p0 = sw * 64; p0 < len; p0 += 64 * 4) {
-            const int pp_ = p0 + lane;
-            const bool ok = pp_ < len;
-            int cr;
-            if (IDENT && p0 == sw * 64) cr = ok ? cr0 : __builtin_amdgcn_readlane(cr0, 0);
-            else cr = ar[ok ? pp_ : len - 1];
-            crow[lane] = cr;
-            const half_t* kp = p.Kc + (unsigned)(cr * icrs + (ok ? pp_ : len - 1) * p.d + hoff);
-            f16x8 kv[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) kv[i] = ld_f16x8(kp + i * 8);
-            f16x8 vv[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int pq = p0 + u * 8 + pg;
-                const int pc = (pq < len) ? pq : len - 1;
-                vv[u] = ld_f16x8(p.Vc + (unsigned)(crow[u * 8 + pg] * icrs + pc * p.d + hoff + dc * 8));
-            }
-            float sc = 0.f;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const f16x8 qi = *reinterpret_cast<const f16x8*>(qs[w] + i * 8);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) sc = fmaf((float)kv[i][e], (float)qi[e], sc);
-            }
-            sc = ok ? sc : WLX_NEG_INF;
-            const float bmax = dpp_wave_max(sc);
-            const float mnew = fmaxf(mrun, bmax);
-            const float alpha = __expf(mrun - mnew);
-            const float pe = __expf(sc - mnew);
-            lrun = lrun * alpha + dpp_wave_sum(pe);
-            mrun = mnew;
-            prob[lane] = pe;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] *= alpha;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float pr = prob[u * 8 + pg];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = fmaf(pr, (float)vv[u][e], o[e]);
-            }
-        }
-        // sum the 8 position groups: lane dd then owns output dim dd of this wave's partial
-        *reinterpret_cast<float4*>(&part_s[w][pg][dc * 8]) = make_float4(o[0], o[1], o[2], o[3]);
-        *reinterpret_cast<float4*>(&part_s[w][pg][dc * 8 + 4]) = make_float4(o[4], o[5], o[6], o[7]);
-        float acc = 0.f;
-#pragma unroll
-        for (int g8 = 0; g8 < 8; ++g8) acc += part_s[w][g8][lane];
-        part_s[w][0][lane] = acc;                                       // (this wave's own rows of part_s: read above by the same wave only)
-        if (lane == 0) { ml_s[w][0] = mrun; ml_s[w][1] = lrun; }
-    }
-    WLX_TR_MARK(2);
-    __syncthreads();
-    if (sw == 0) {
-        // merge the head's waves in wave order: o = sum_k o_k e^(m_k - m), l = sum_k l_k e^(m_k - m)  (one block: o_0 / l_0, as before)
-        const int nwv = nblk < 4 ? nblk : 4;
-        const int w0 = hsel * 4;
-        float m = ml_s[w0][0];
-        for (int k = 1; k < nwv; ++k) m = fmaxf(m, ml_s[w0 + k][0]);
-        float L = 0.f, O = 0.f;
-        for (int k = 0; k < nwv; ++k) {
-            const float f = __expf(ml_s[w0 + k][0] - m);
-            L += ml_s[w0 + k][1] * f;
-            O += part_s[w0 + k][0][lane] * f;
-        }
-        os[hsel * 64 + lane] = (half_t)(O / L);
-    }
-    __syncthreads();
-    // ---- the K slice of the output projection: B operand = the 128 attention dims (every column the same row: column 0 is kept)
-    f32x4 acc2[NTW];
-#pragma unroll
-    for (int i = 0; i < NTW; ++i) acc2[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kt = 0; kt < 4; ++kt) {
-        const f16x8 xf = *reinterpret_cast<const f16x8*>(os + kt * 32 + g * 8);
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) acc2[i] = mfma16(wf[i][kt], xf, acc2[i]);
-    }
-    if (c == 0) {                                                       // lane (c = 0, g) holds outputs n-tile * 16 + g * 4 .. + 3 of the row
-#pragma unroll
-        for (int i = 0; i < NTW; ++i) *reinterpret_cast<f32x4*>(ys + (w * NTW + i) * 16 + g * 4) = acc2[i];
-    }
-    WLX_TR_MARK(3);
-    __syncthreads();
-    if (fin) {
-        float4 v = reinterpret_cast<const float4*>(ys)[fi];
-        if (hp == 0) {                                                  // ((partial + bias) + pending slab 0) + pending slab 1
-            v.x += eb.x; v.y += eb.y; v.z += eb.z; v.w += eb.w;
-#pragma unroll
-            for (int sl = 0; sl < WLX_FC2_KS; ++sl) { v.x += ea[sl].x; v.y += ea[sl].y; v.z += ea[sl].z; v.w += ea[sl].w; }
-        }
-        reinterpret_cast<float4*>(p.slabB + hp * p.slabB_stride + (long)r * p.d)[fi] = v;
-    }
-    WLX_TR_END(p.trc);
-}
-
-bool dec_sao_eligible(int d, int H, int rows) {
-    static const bool off = [] { const char* e = wlx_ab("WLX_NO_SAO"); return e && e[0] == '1'; }();
-    return !off && !g_decode_v1 && d == 768 && H == 12 && rows >= 1 && rows <= 16 && WLX_FC2_KS == 2;
-}
-void launch_dec_sao(const half_t* q, long ldq, const half_t* Kc, const half_t* Vc, long crs, int d, int H, const RowTables& rt, int rows,
-                    const half_t* Wo, const float* bo, const float* slabA, long slabA_stride, float* slabB, long slabB_stride,
-                    bool ident_ancestry, hipStream_t s) {
-    SaoParams p{};
-    p.q = q; p.ldq = ldq; p.Kc = Kc; p.Vc = Vc; p.crs = crs; p.d = d; p.pos = rt.pos; p.ancrow = rt.ancrow; p.anc = rt.anc;
-    p.Wp = Wo; p.KT = d / 32; p.bias = bo; p.slabA = slabA; p.slabA_stride = slabA_stride; p.slabB = slabB; p.slabB_stride = slabB_stride; p.H = H;
-#ifdef WLX_TRACE
-    p.trc = trace_next("sao");
-#endif
-    if (ident_ancestry) hipLaunchKernelGGL((dec_sao_kernel<true, 6>), dim3(8 * rows), dim3(512), 0, s, p);
-    else hipLaunchKernelGGL((dec_sao_kernel<false, 6>), dim3(8 * rows), dim3(512), 0, s, p);
-}
-
 // ------------------------------------------------------------------ decode cross-attention (flash-decoding split over keys)
 // grid (split, head, group): the R rows of an item share the item's encoder K/V, so they form ONE 16-row MFMA query
 // tile (scores transposed as in attention.hip: S^T = K Q^T, softmax in-lane + 2 DPP steps, O^T = V^T P^T).
@@ -1988,15 +1783,12 @@ __global__ __launch_bounds__(XA_TPS * 64) void dec_cross_attn_kernel(const half_
 // repeats are L2 hits, not HBM reads. What it buys: one launch boundary (1.6 us) and one launch's fixed latency per
 // layer; what it costs: ~200 load instructions per CU instead of ~60 (2.2 us of issue at ~11 ns each).
 // Eligibility (launcher): d_model = 256 * LNV with KT % 6 == 0 — Whisper-small; other sizes keep the two launches.
-// NSL (round 5): the residual rows are X + NSL partial-sum slabs (dec_sao_kernel's: the attention output projection is not summed by
-// anybody before this prologue); 0 = plain rows. Association: ((x + s0) + s1) + ..., the residual epilogue's.
-template <int LNV, int KPW, int NSL>
+template <int LNV, int KPW>
 __global__ __launch_bounds__(XA_TPS * 64) void dec_cq_cross_attn_kernel(
     const float* __restrict__ X, long ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
     const half_t* __restrict__ Wp, const float* __restrict__ bias, float qscale, int KT,
     const half_t* __restrict__ Kp, const half_t* __restrict__ Vp, long item_stride, int H, int R, int rows,
-    const int* __restrict__ group_item, half_t* __restrict__ part_o, float* __restrict__ part_ml,
-    const float* __restrict__ slab, long slab_stride WLX_TR_PARAM) {
+    const int* __restrict__ group_item, half_t* __restrict__ part_o, float* __restrict__ part_ml WLX_TR_PARAM) {
     constexpr int TPS = XA_TPS;
     static_assert(TPS == 6, "six waves: KT/6 k-tiles of the query projection and one key tile each");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -2030,20 +1822,11 @@ __global__ __launch_bounds__(XA_TPS * 64) void dec_cq_cross_attn_kernel(
     // LayerNorm (which everything else waits for) started 2.6 us into a 5.9 us launch
     const int nrow = (rows - grp * R < R) ? rows - grp * R : R;           // live rows of this group
     float4 x0[LNV];
-    float4 sl0[NSL > 0 ? NSL : 1][LNV];
     {
         const int r0 = (wave < nrow) ? wave : nrow - 1;
         const float4* x4 = reinterpret_cast<const float4*>(X + (long)(grp * R + r0) * ldx) + lane;
 #pragma unroll
         for (int j = 0; j < LNV; ++j) x0[j] = x4[64 * j];
-        if constexpr (NSL > 0) {
-#pragma unroll
-            for (int q = 0; q < NSL; ++q) {
-                const float4* s4 = reinterpret_cast<const float4*>(slab + q * slab_stride + (long)(grp * R + r0) * ldx) + lane;
-#pragma unroll
-                for (int j = 0; j < LNV; ++j) sl0[q][j] = s4[64 * j];
-            }
-        }
     }
     float4 gq[LNV], bq[LNV];
     {
@@ -2096,27 +1879,13 @@ __global__ __launch_bounds__(XA_TPS * 64) void dec_cq_cross_attn_kernel(
         };
         // first trip: straight-line and UNCONDITIONAL (a wave without a row normalises the clamped row it loaded and
         // keeps nothing): inside an `if (wave < nrow)` hipcc sinks the row loads into the branch, behind the weights
-        if constexpr (NSL > 0) {
-#pragma unroll
-            for (int q = 0; q < NSL; ++q)
-#pragma unroll
-                for (int j = 0; j < LNV; ++j) { x0[j].x += sl0[q][j].x; x0[j].y += sl0[q][j].y; x0[j].z += sl0[q][j].z; x0[j].w += sl0[q][j].w; }
-        }
         ln_row(x0, (wave < nrow) ? wave : nrow - 1, wave < nrow);
 #pragma unroll 1
-        for (int r = wave + TPS; r < nrow; r += TPS) {                      // groups of more than six rows
+        for (int r = wave + TPS; r < nrow; r += TPS) {                      // groups of more than six rows (prefill)
             const float4* x4 = reinterpret_cast<const float4*>(X + (long)(grp * R + r) * ldx) + lane;
             float4 x[LNV];
 #pragma unroll
             for (int j = 0; j < LNV; ++j) x[j] = x4[64 * j];
-            if constexpr (NSL > 0) {
-#pragma unroll 1
-                for (int q = 0; q < NSL; ++q) {
-                    const float4* s4 = reinterpret_cast<const float4*>(slab + q * slab_stride + (long)(grp * R + r) * ldx) + lane;
-#pragma unroll
-                    for (int j = 0; j < LNV; ++j) { const float4 t = s4[64 * j]; x[j].x += t.x; x[j].y += t.y; x[j].z += t.z; x[j].w += t.w; }
-                }
-            }
             ln_row(x, r, true);
         }
     }
@@ -2229,17 +1998,12 @@ bool dec_cq_cross_attn_eligible(int d, int H, int R) {
 }
 void launch_dec_cq_cross_attn(const float* X, long ldx, const float* gamma, const float* beta, const half_t* Wp, const float* bias,
                               float qscale, int d, const half_t* Kp, const half_t* Vp, long item_stride, int H, int R, int groups,
-                              int rows, const int* group_item, half_t* part_o, float* part_ml, const float* sao_slabs, long sao_slab_stride,
-                              hipStream_t s) {
+                              int rows, const int* group_item, half_t* part_o, float* part_ml, hipStream_t s) {
     const int KT = d / 32;
     const size_t xs_floats = (size_t)((R * (d + 8) * 2 + 15) / 16) * 4;
     const size_t shm = sizeof(float) * (xs_floats + (size_t)XA_TPS * 16 * 68 + XA_TPS * 16 * 2) + 16 * 72 * sizeof(half_t);
-    if (sao_slabs)
-        hipLaunchKernelGGL((dec_cq_cross_attn_kernel<3, 4, WLX_SAO_SLABS>), dim3(H * WLX_XSPLIT * groups), dim3(XA_TPS * 64), shm, s, X, ldx, gamma, beta,
-                           Wp, bias, qscale, KT, Kp, Vp, item_stride, H, R, rows, group_item, part_o, part_ml, sao_slabs, sao_slab_stride WLX_TR_ARG("cq_cross_attn"));
-    else
-        hipLaunchKernelGGL((dec_cq_cross_attn_kernel<3, 4, 0>), dim3(H * WLX_XSPLIT * groups), dim3(XA_TPS * 64), shm, s, X, ldx, gamma, beta,
-                           Wp, bias, qscale, KT, Kp, Vp, item_stride, H, R, rows, group_item, part_o, part_ml, (const float*)nullptr, 0L WLX_TR_ARG("cq_cross_attn"));
+    hipLaunchKernelGGL((dec_cq_cross_attn_kernel<3, 4>), dim3(H * WLX_XSPLIT * groups), dim3(XA_TPS * 64), shm, s, X, ldx, gamma, beta,
+                       Wp, bias, qscale, KT, Kp, Vp, item_stride, H, R, rows, group_item, part_o, part_ml WLX_TR_ARG("cq_cross_attn"));
 }
 
 // ------------------------------------------------------------------ split combine of the cross attention, on its own

@@ -73,7 +73,6 @@ struct Slot {
     half_t *kc = nullptr, *vc = nullptr;             // self cache [L][cache_rows][448][d]
     float* xd = nullptr; half_t *qd = nullptr, *attnd = nullptr, *hd = nullptr;
     float* slab = nullptr;                           // [WLX_FC2_KS][48][d] partial sums of the K-split MLP output projection (decoder.hip GEMV_OUT_SLAB)
-    float* slab6 = nullptr;                          // [WLX_SAO_SLABS][16][d] partial sums of the attention output projection (decoder.hip dec_sao_kernel)
     half_t* part_o = nullptr;
     float *part_ml = nullptr, *logits = nullptr;
     long ldl = 0;

@@ -641,7 +641,6 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         CKR(dalloc(s->allocs, &s->attnd, (size_t)RC * d));
         CKR(dalloc(s->allocs, &s->hd, (size_t)RC * F));
         CKR(dalloc(s->allocs, &s->slab, (size_t)WLX_FC2_KS * RC * d));
-        CKR(dalloc(s->allocs, &s->slab6, (size_t)WLX_SAO_SLABS * 16 * d));
         CKR(dalloc(s->allocs, &s->part_o, (size_t)s->groups_cap * e->H * WLX_XSPLIT * 16 * 64));
         CKR(dalloc(s->allocs, &s->part_ml, (size_t)s->groups_cap * e->H * WLX_XSPLIT * 16 * 2));
         {   // the one-pass prompt prefill's working set: up to WLX_T_TEXT rows (engine.hip prefill_tokens)
@@ -1083,6 +1082,10 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
             GemvParams pq = qkv_params(l, (l == 0 && fold_embed) ? GEMV_X_EMBED : (slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN));
             pgemv(s.base, pq);
         }
+        plaunch(s.base, "dec_self_attn2_kernel", 4.0 * rows * d * (s->prof ? s->prof->t + 1 : 1), [&] { launch_dec_self_attn(s.qd, d, kc, vc, crs, d, H, rt, rows, s.attnd, d, done, s->anc_ident, st); });
+        pgemv(s.base, oproj_params(l, slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN));
+        slabs_pending = false;
+        GemvParams p{};
         // LN2 + cross-attention query + cross-attention partials: one fused launch when the shape allows and nobody needs
         // the query rows (word alignment captures them), else projection and attention separately
         const half_t* ckl = s->ck + (size_t)l * s->B * WLX_T_AUDIO_PAD * d;
@@ -1090,32 +1093,10 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
         // (not for the one-pass prompt prefill: with 14+ groups every (split, head, group) workgroup re-reads its head's 96 KiB of
         // query weights — 224 tokens: 1.49 ms fused, 1.32 ms as projection + attention, profiles/r3l_prefill_fused_cq.txt)
         const bool fused = !s->align && rows <= 48 && dec_cq_cross_attn_eligible(d, H, R);
-        // (round 5) self-attention and its output projection in ONE launch, the projection left as six partial-sum slabs that the fused
-        // cross-attention launch and the cross-attention output projection read (decoder.hip dec_sao_kernel): decode steps of one stream
-        // at Whisper-small shapes — one launch fewer per layer
-        const long sao_stride = (long)16 * d;
-        bool sao = fused && !alt && s->slab6 != nullptr && dec_sao_eligible(d, H, rows);
-        if (sao) {      // its second consumer must be the lean kernel (the only one that knows GEMV_X_SLABS6)
-            GemvParams q{};
-            q.in_mode = GEMV_IN_XATTN; q.out_mode = GEMV_OUT_RESID; q.M = rows; q.K = d; q.KT = d / 32; q.N = d; q.bias = w.bco; q.H = H; q.R = R;
-            q.xsrc = GEMV_X_SLABS6;
-            sao = dec_gemv_is_lean(q);
-        }
-        if (sao) {
-            plaunch(s.base, "dec_sao_kernel", 4.0 * rows * d * (s->prof ? s->prof->t + 1 : 1) + 2.0 * d * d, [&] {
-                launch_dec_sao(s.qd, d, kc, vc, crs, d, H, rt, rows, w.Wo, w.bo, slabs_pending ? s.slab : nullptr, s.slab_rows * d, s->slab6, sao_stride,
-                               s->anc_ident, st);
-            });
-        } else {
-            plaunch(s.base, "dec_self_attn2_kernel", 4.0 * rows * d * (s->prof ? s->prof->t + 1 : 1), [&] { launch_dec_self_attn(s.qd, d, kc, vc, crs, d, H, rt, rows, s.attnd, d, done, s->anc_ident, st); });
-            pgemv(s.base, oproj_params(l, slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN));
-        }
-        slabs_pending = false;
-        GemvParams p{};
         if (fused)
             plaunch(s.base, "dec_cq_cross_attn_kernel", 2.0 * d * d + 4.0 * groups * WLX_T_AUDIO * d, [&] {
                 launch_dec_cq_cross_attn(s.xd, d, w.ln2_g, w.ln2_b, w.Wcq, w.bcq, 0.125f, d, ckl, cvl, (long)WLX_T_AUDIO_PAD * d, H, R,
-                                         groups, rows, s.d_group_item, s.part_o, s.part_ml, sao ? s->slab6 : nullptr, sao_stride, st);
+                                         groups, rows, s.d_group_item, s.part_o, s.part_ml, st);
             });
         if (!fused) {
             p = GemvParams{};
@@ -1138,7 +1119,6 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
         p.in_mode = GEMV_IN_XATTN; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
         p.Wp = w.Wco; p.bias = w.bco; p.part_o = s.part_o; p.part_ml = s.part_ml; p.H = H; p.R = R;
         p.Xres = s.xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
-        if (sao) { p.xsrc = GEMV_X_SLABS6; p.slab = s->slab6; p.slab_stride = sao_stride; }      // x + the six slabs + this projection -> x
         if (rows > 16) {
             // batched rows: the split combine once, in its own launch, then a plain fp16-rows-in projection (decoder.hip)
             plaunch(s.base, "dec_xattn_combine_kernel", 0.0, [&] { launch_dec_xattn_combine(s.part_o, s.part_ml, rows, H, R, s.attnd, d, st); });
