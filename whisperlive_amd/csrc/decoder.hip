@@ -1224,7 +1224,8 @@ static GemvParams gemv_chunked(const GemvParams& p) {
     else if (p.M > 48 && p.xsrc != GEMV_X_EMBED) { q.Mtot = p.M; q.M = 48; q.chunk = 48; }
     return q;
 }
-bool dec_gemv_is_lean(const GemvParams& p) { return gemv2_ok(gemv_chunked(p), nullptr); }
+static bool vocab2_ok(const GemvParams& p);   // (dec_vocab_kernel, below)
+bool dec_gemv_is_lean(const GemvParams& p) { return vocab2_ok(p) || gemv2_ok(gemv_chunked(p), nullptr); }
 
 int dec_gemv_slab_split(int M, int K, int N) {
     if (WLX_FC2_KS < 2) return 0;                                             // (the slab count is a compile-time constant of the consumers: -DWLX_FC2_KS)
@@ -1271,10 +1272,16 @@ struct VocabParams {
     const float* X; long ldx; const float* gamma; const float* beta;
     const half_t* Wp; int M, N, NT;            // rows, real outputs, 16-column tiles of the packed weights
     float* Y; long ldy;
+    const float* slab; long slab_stride;       // SLABS: the rows are X + the WLX_FC2_KS partial-sum slabs of the LAST layer's K-split MLP projection
     WLX_TR_FIELD
 };
-template <int KT, int KC, int MT>
+// SLABS (round 5, one row tile): the last decoder layer's MLP output projection used to stay a single launch because its consumer — this
+// projection, then 1621 workgroups that would each have summed the slabs — made the split a loss; as ONE launch with K = 4 d_model it is
+// the slowest projection of the step (11-13 us at 5 rows against 4.3 us for the K-split form, profiles/r5b_*). With 203 workgroups that
+// share one LayerNorm the slab reads are three small loads per row, so the last layer splits like the others.
+template <int KT, int KC, int MT, bool SLABS>
 __global__ __launch_bounds__(512) void dec_vocab_kernel(VocabParams p) {
+    static_assert(!SLABS || MT == 1, "slab rows: decode steps of one row tile");
     constexpr int K = KT * 32, LNV = (K + 255) / 256, NC = KT / KC, LDXS = K + 8;
     constexpr bool LNT = (K % 256) != 0;                    // d_model 384 = 1.5 x 256: the second float4 unit is live on lanes 0..31 only (see dec_gemv2_kernel)
     static_assert((K % 256 == 0 || K == 384) && KT % KC == 0 && NC % 2 == 0, "d_model a multiple of 256 (or 384); an even number of K chunks");
@@ -1296,6 +1303,18 @@ __global__ __launch_bounds__(512) void dec_vocab_kernel(VocabParams p) {
         const float4* x4 = reinterpret_cast<const float4*>(p.X + (long)r * p.ldx) + lane;
 #pragma unroll
         for (int j = 0; j < LNV; ++j) x[i][j] = x4[64 * j - ((j == LNV - 1) ? tback : 0)];
+    }
+    float4 xsl[SLABS ? WLX_FC2_KS : 1][RPT][LNV];
+    if constexpr (SLABS) {
+#pragma unroll
+        for (int q = 0; q < WLX_FC2_KS; ++q)
+#pragma unroll
+            for (int i = 0; i < RPT; ++i) {
+                const int r = (wave + 8 * i < p.M) ? wave + 8 * i : p.M - 1;
+                const float4* s4 = reinterpret_cast<const float4*>(p.slab + q * p.slab_stride + (long)r * p.ldx) + lane;
+#pragma unroll
+                for (int j = 0; j < LNV; ++j) xsl[q][i][j] = s4[64 * j - ((j == LNV - 1) ? tback : 0)];
+            }
     }
     float4 gq[LNV], bq[LNV];
     {
@@ -1337,6 +1356,14 @@ __global__ __launch_bounds__(512) void dec_vocab_kernel(VocabParams p) {
         }
     };
     // first trip: straight-line and unconditional (a wave without a row normalises the clamped row it loaded and keeps nothing)
+    if constexpr (SLABS) {                                  // the row = ((x + s0) + s1): the association of every other consumer of the slabs
+#pragma unroll
+        for (int q = 0; q < WLX_FC2_KS; ++q)
+#pragma unroll
+            for (int i = 0; i < RPT; ++i)
+#pragma unroll
+                for (int j = 0; j < LNV; ++j) { x[i][j].x += xsl[q][i][j].x; x[i][j].y += xsl[q][i][j].y; x[i][j].z += xsl[q][i][j].z; x[i][j].w += xsl[q][i][j].w; }
+    }
 #pragma unroll
     for (int i = 0; i < RPT; ++i) ln_row(x[i], (wave + 8 * i < p.M) ? wave + 8 * i : p.M - 1, wave + 8 * i < p.M);
 #pragma unroll 1
@@ -1404,7 +1431,7 @@ __global__ __launch_bounds__(512) void dec_vocab_kernel(VocabParams p) {
     WLX_TR_END(p.trc);
 }
 
-template <int KT, int KC, int MT>
+template <int KT, int KC, int MT, bool SLABS = false>
 static void vocab_go(const VocabParams& p, hipStream_t s) {
     const size_t shm = (size_t)p.M * (KT * 32 + 8) * sizeof(half_t);
     if (shm > 64 * 1024) {          // > 64 KiB of dynamic LDS: opt in once per device (first launch of a shape happens outside capture)
@@ -1412,7 +1439,7 @@ static void vocab_go(const VocabParams& p, hipStream_t s) {
         int dev = 0;
         (void)hipGetDevice(&dev);
         if (dev >= 0 && dev < 64 && granted[dev].load(std::memory_order_acquire) == 0) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_vocab_kernel<KT, KC, MT>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&dec_vocab_kernel<KT, KC, MT, SLABS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     WLX_G2_LDS_MAX) == hipSuccess) granted[dev].store(1, std::memory_order_release);
             else {                  // this launch fails with the runtime's own error (reported for THIS call); later calls take the general kernel (vocab2_ok)
                 (void)hipGetLastError();
@@ -1422,10 +1449,11 @@ static void vocab_go(const VocabParams& p, hipStream_t s) {
         }
     }
     const int pairs = (p.NT + 1) / 2;
-    hipLaunchKernelGGL((dec_vocab_kernel<KT, KC, MT>), dim3((pairs + 7) / 8), dim3(512), shm, s, p);
+    hipLaunchKernelGGL((dec_vocab_kernel<KT, KC, MT, SLABS>), dim3((pairs + 7) / 8), dim3(512), shm, s, p);
 }
 template <int KT, int KC>
 static void vocab_go_mt(const VocabParams& p, hipStream_t s) {
+    if (p.slab) { vocab_go<KT, KC, 1, true>(p, s); return; }        // (vocab2_ok: one row tile)
     switch ((p.M + 15) / 16) {
         case 1: vocab_go<KT, KC, 1>(p, s); break;
         case 2: vocab_go<KT, KC, 2>(p, s); break;
@@ -1442,7 +1470,8 @@ static int vocab2_chunk_rows(int K) {
     return r;
 }
 static bool vocab2_ok(const GemvParams& p) {
-    if (g_decode_v1 || p.in_mode != GEMV_IN_LN || p.out_mode != GEMV_OUT_F32 || p.bias || p.xsrc != GEMV_X_PLAIN || p.Mtot != 0) return false;
+    if (g_decode_v1 || p.in_mode != GEMV_IN_LN || p.out_mode != GEMV_OUT_F32 || p.bias || p.Mtot != 0) return false;
+    if (p.xsrc != GEMV_X_PLAIN && !(p.xsrc == GEMV_X_SLABS && p.M <= 16 && p.slab != nullptr)) return false;   // rows + slabs: decode steps of one row tile
     if (p.M < 1 || p.M > WLX_MAX_DEC_ROWS || p.K != p.KT * 32 || p.N < 256) return false;
     if (!(p.KT == 12 || p.KT == 16 || p.KT == 24 || p.KT == 32 || p.KT == 40)) return false;
     const int rows = std::min(p.M, vocab2_chunk_rows(p.K));
@@ -1456,6 +1485,7 @@ static void vocab2_launch(const GemvParams& g, hipStream_t s) {
         VocabParams p{};
         p.X = g.X + (long)r0 * g.ldx; p.ldx = g.ldx; p.gamma = g.gamma; p.beta = g.beta; p.Wp = g.Wp; p.M = std::min(CH, g.M - r0); p.N = g.N; p.NT = (g.N + 15) / 16;
         p.Y = g.Y + (long)r0 * g.ldy; p.ldy = g.ldy;
+        if (g.xsrc == GEMV_X_SLABS) { p.slab = g.slab; p.slab_stride = g.slab_stride; }
 #ifdef WLX_TRACE
         p.trc = trace_next("vocab2");
 #endif

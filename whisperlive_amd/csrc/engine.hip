@@ -1134,15 +1134,17 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
         p = GemvParams{};
         p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = F; p.KT = F / 32; p.N = d;
         p.Wp = w.W2; p.bias = w.b2; p.Xh = s.hd; p.ldxh = F; p.Xres = s.xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
-        // the last layer keeps the single launch: its consumer would be the vocabulary projection, thousands of workgroups
-        // that would each sum the slabs (measured: +2.2 us there against 1.2 us saved here, profiles/r2f_*)
-        if (KS && l + 1 < sp.dec_layers) {
+        // the last layer: its consumer is the vocabulary projection. While that was 1621 workgroups that would each have summed the slabs the
+        // split was a loss there (+2.2 us against 1.2 us saved, profiles/r2f_*) and the last layer kept the single launch — 11-13 us at 5 rows,
+        // the slowest projection of the step (profiles/r5b_*). dec_vocab_kernel (203 workgroups, one LayerNorm each) takes rows + slabs.
+        const bool last_split = with_logits && dec_gemv_is_lean(vocab_params(GEMV_X_SLABS));
+        if (KS && (l + 1 < sp.dec_layers || last_split)) {
             p.out_mode = GEMV_OUT_SLAB; p.KTS = p.KT / KS; p.slab = s.slab; p.slab_stride = s.slab_rows * d;
             slabs_pending = true;
         }
         pgemv(s.base, p);
     }
-    if (with_logits) pgemv(s.base, vocab_params(GEMV_X_PLAIN));
+    if (with_logits) pgemv(s.base, vocab_params(slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN));
 }
 
 // upload row tables for a pass: token/pos/cache/ancrow [rows], group_item [groups]
