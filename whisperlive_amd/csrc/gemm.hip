@@ -778,19 +778,53 @@ static hipError_t gemm2_optin() {      // > 64 KiB of dynamic LDS needs the opt-
 // neither fills nor MFMAs, i.e. the per-stage wait + barrier + LDS-read + issue sequence of four lock-stepped waves itself.
 int gemm_prepare_device() {      // once per engine, on the engine's device (wlx_engine_create)
     hipError_t e = gemm2_optin<2, 3, 4>();
+    if (e == hipSuccess) e = gemm2_optin<3, 3, 3>();
+    if (e == hipSuccess) e = gemm2_optin<4, 4, 2>();
     if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES);
     return (int)e;
 }
 
-// Every encoder GEMM: the large-M form where it applies (batched encodes), else the 64 x 96 tile of the second form — the one tile shape
-// left of the eight measured in rounds 2-4 (the comment above; the first form and the other instantiations left the library in round 5).
+// Tile shape of the second form, per GEMM (round 5). One window (M = 1500) on the 64 x 96 tile alone: the N = 3 d / 4 d projections are
+// 576 / 768 workgroups against the 512 that are resident together (two 64-80 KiB rings per CU x 256 CUs), i.e. TWO rounds of a
+// latency-bound stage loop — 22-27 us per launch where the N = d projection with the same K (192 workgroups, one round) takes 10 us
+// (profiles/r5d_encoder_launches_*.txt). Three shapes that all keep two workgroups per CU are instantiated — 64 x 96 (ring of 4, 80 KiB),
+// 96 x 96 (ring of 3, 72 KiB), 128 x 128 (ring of 2, 64 KiB) — and the launch takes the one with the smallest
+// rounds x (cost of one stage of that shape); ties go to the smaller tile. Results do not depend on the shape (same products, same K order).
+// WLX_GEMM2_SHAPE=0/1/2 (A/B builds) forces one shape for every launch.
+static int gemm2_pick(const GemmParams& p, int zbatch) {
+    static const int forced = [] { const char* e = wlx_ab("WLX_GEMM2_SHAPE"); return e ? atoi(e) : -1; }();
+    if (forced >= 0 && forced <= 2) return forced;
+    static const int slots = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount; return 2 * n; }();
+    static const int wnt[3] = {2, 3, 4}, wmt[3] = {3, 3, 4};
+    // relative cost of one stage (two k-tiles): a fixed wait + barrier + issue part and the MFMAs / LDS reads of the wave tile (measured
+    // stage times: 64 x 96 ~0.7 us; the larger tiles by their MFMA count, profiles/r5e_*)
+    static const double stage[3] = {0.45 + 0.02 * 12, 0.45 + 0.02 * 18, 0.45 + 0.02 * 32};
+    const bool scatter = p.mode == GEMM_QKV || p.mode == GEMM_CROSS_KV;
+    int best = 0;
+    double best_cost = 1e300;
+    for (int i = 0; i < 3; ++i) {
+        if (scatter && p.d % (32 * wnt[i]) != 0) continue;             // the LDS-transposed epilogue needs q / k / v boundaries on tile boundaries
+        const long wgs = (long)((p.N + 32 * wnt[i] - 1) / (32 * wnt[i])) * ((p.M + 32 * wmt[i] - 1) / (32 * wmt[i])) * zbatch;
+        const long rounds = (wgs + slots - 1) / slots;
+        const double cost = (double)rounds * stage[i];
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = i; }
+    }
+    return best;
+}
+
+// Every encoder GEMM: the large-M form where it applies (batched encodes), else the second form on the tile gemm2_pick chooses (the first
+// form and the other five tile shapes measured in rounds 2-4 left the library in round 5).
 void launch_gemm(const GemmParams& p, int zbatch, hipStream_t s) {
     if (gemm3_ok(p, zbatch)) { gemm3_go(p, s); return; }
     if ((p.KT & 1) || p.KT < 2) {      // every K the engine builds is a multiple of 64 (d_model, ffn: multiples of 128; conv1: 3 n_mels padded)
         fprintf(stderr, "[wlx] encoder GEMM with K = %d refused: the k-tile count must be even (wlx_engine_create validates the model shape)\n", p.KT * 32);
         return;
     }
-    gemm2_go<2, 3, 4>(p, zbatch, s);
+    switch (gemm2_pick(p, zbatch)) {
+        case 1: gemm2_go<3, 3, 3>(p, zbatch, s); return;
+        case 2: gemm2_go<4, 4, 2>(p, zbatch, s); return;
+        default: gemm2_go<2, 3, 4>(p, zbatch, s); return;
+    }
 }
 
 // ---------------------------------------------------------------- LayerNorm (wave per row)
