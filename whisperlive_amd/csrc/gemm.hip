@@ -303,9 +303,12 @@ __device__ __forceinline__ void gemm_epilogue_lds(const GemmParams& p, f32x4 (&a
 // not be used here: with LDS-DMA in flight hipcc lowers it to vmcnt(0) + s_barrier and the ring drains every stage.
 typedef __attribute__((address_space(3))) void wlx_lds_void;
 
-template <int WNT, int WMT, int DEPTH>
+// KS = k-tiles (of 32) per stage. (KS = 4 — 128-deep stages, a 120 KiB ring, one workgroup per CU — was measured in round 5 for the
+// N = d_model projections of one window, 192 workgroups whose K = 4 d_model loop takes 24 us against 10 us at K = d_model: 17.44 vs
+// 17.49 us per launch, profiles/r5f_*. Halving the number of stages and barriers changes nothing: the loop's time goes with the BYTES a
+// workgroup pulls through its CU — ~0.25 us per k-tile of a 64 x 96 tile = ~40 GB/s per CU — not with its stage count.)
+template <int WNT, int WMT, int DEPTH, int KS = 2>
 __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
-    constexpr int KS = 2;                       // k-tiles (of 32) per stage
     constexpr int FA = 2 * WNT * KS, FB = 2 * WMT * KS;
     constexpr int CA = FA / 4, CB = FB / 4;     // fragments (1 KiB LDS-DMA pieces) each wave requests per stage
     constexpr int NL = CA + CB;                 // = this wave's vmcnt events per stage
@@ -728,9 +731,9 @@ static void gemm3_go(const GemmParams& p0, hipStream_t s) {
 }
 
 // the second form's launch: (WNT, WMT) wave tiles -> workgroup tile (32 WNT) x (32 WMT), ring of DEPTH stages, XCD-aware tile map
-template <int WNT, int WMT, int DEPTH>
+template <int WNT, int WMT, int DEPTH, int KS = 2>
 static void gemm2_go(const GemmParams& p0, int zbatch, hipStream_t s) {
-    constexpr size_t shm = (size_t)DEPTH * (4 * WNT + 4 * WMT) * 1024;
+    constexpr size_t shm = (size_t)DEPTH * (2 * KS * (WNT + WMT)) * 1024;
     const int NT_total = (p0.N + 15) / 16;
     dim3 grid((NT_total + 2 * WNT - 1) / (2 * WNT), (p0.M + 32 * WMT - 1) / (32 * WMT), zbatch);
     GemmParams p = p0;
@@ -749,12 +752,12 @@ static void gemm2_go(const GemmParams& p0, int zbatch, hipStream_t s) {
             if (bytes < best) { best = bytes; p.xcd_a = a; p.xcd_b = b; }
         }
     }
-    hipLaunchKernelGGL((gemm2_kernel<WNT, WMT, DEPTH>), grid, dim3(256), shm, s, p);
+    hipLaunchKernelGGL((gemm2_kernel<WNT, WMT, DEPTH, KS>), grid, dim3(256), shm, s, p);
 }
-template <int WNT, int WMT, int DEPTH>
+template <int WNT, int WMT, int DEPTH, int KS = 2>
 static hipError_t gemm2_optin() {      // > 64 KiB of dynamic LDS needs the opt-in, per device (not a stream operation)
-    constexpr size_t shm = (size_t)DEPTH * (4 * WNT + 4 * WMT) * 1024;
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<WNT, WMT, DEPTH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
+    constexpr size_t shm = (size_t)DEPTH * (2 * KS * (WNT + WMT)) * 1024;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm2_kernel<WNT, WMT, DEPTH, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm);
 }
 // Tile shape. Measured on the Whisper-small encoder (MI355X, one shape forced for every GEMM, profiles/r2c_*): 64 x 96
 // workgroup tiles (2 x 3 wave tiles, ring of 4) 1.87 ms per encoder, 64 x 64 1.97, 128 x 64 2.00, 64 x 128 2.14,
