@@ -583,10 +583,11 @@ def config5(args, rank, world, local, dist, torch):
         print(json.dumps(out))
 
 
-def throughput_leg(eng, spec, olm, torch, ids, eids, gen_kw, decode_steps, TS=4, TB=12, tsteps=3):
-    """The throughput configuration of ONE GPU, timed by the same driver run (VERDICT r03 task 5): 4 slots on their own hardware
-    queues x 12 windows batched into every decode — what a --batch_inference server with four lanes runs. Called after
-    the headline's own slot is closed: a fifth live slot would send every slot back to the shared queue pool."""
+def throughput_leg(eng, spec, olm, torch, ids, eids, gen_kw, decode_steps, TS=3, TB=48, tsteps=2):
+    """The throughput configuration of ONE GPU, timed by the same driver run (VERDICT r03 task 5): TS slots on their own hardware
+    queues x TB windows batched into every decode — what a --batch_inference server with TS lanes and --batch_max_size TB
+    runs (round 5: 3 x 48; a slot held at most 12 windows until then). Called after the headline's own slot is closed: a fifth live
+    slot would send every slot back to the shared queue pool."""
     from concurrent.futures import ThreadPoolExecutor
     tslots = [eng.create_slot(TB, 5) for _ in range(TS)]
     try:
@@ -652,7 +653,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=4, help="--config 5: lanes of the BatchInferenceWorker (1 = the reference's single worker thread, 2 = the library default; measured 1086 / 1513 / 1618 / 1708 xRT at 1 / 2 / 3 / 4 lanes, profiles/r3k_*, r3d_*)")
     ap.add_argument("--free-run", action="store_true", help="--streams S: every stream runs its steps back to back, started 1/S of a step apart, instead of a barrier per step")
     ap.add_argument("--no-throughput", action="store_true", help="skip the throughput leg of the default run")
-    ap.add_argument("--throughput-shape", default="4x12", help="throughput leg: SLOTSxWINDOWS batched per decode (4x12 = the round-4 shape; 2x24, 1x48 since the 64-row cap was lifted)")
+    ap.add_argument("--throughput-shape", default="3x48", help="throughput leg: SLOTSxWINDOWS batched per decode (3x48 = 14.9k xRT, profiles/r5b_*; 4x12 = the round-4 shape, 12.4k; 4x24 14.3k; 1x48 11.6k)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 FETCH_SIZE pass that fills roofline.traffic")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--ws-client", default=None, help=argparse.SUPPRESS)
