@@ -38,7 +38,10 @@
  * with every slot, and if it is issued while a slot captures its decode-step graph that one
  * wlx_generate call fails with WLX_ERR_HIP (the slot's stream is replaced, the next call works).
  * Such processes should set WLX_SLOT_CU_MASK=off (ordinary non-blocking streams on the shared queue
- * pool). The library states the mode once on stderr at the first slot creation (WLX_QUIET silences it).
+ * pool) — and get exactly that by DEFAULT (round 5) once any weight tensor has been handed to
+ * wlx_engine_create with on_device = 1, i.e. when the process demonstrably holds device memory of
+ * another runtime; an explicit WLX_SLOT_CU_MASK always wins. The library states the mode once on
+ * stderr at the first slot creation (WLX_QUIET silences it).
  */
 #ifndef WLX_H
 #define WLX_H
