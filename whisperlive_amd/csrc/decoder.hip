@@ -1206,7 +1206,27 @@ static bool gemv2_ok(const GemvParams& p, Gemv2Cfg* out) {
 // dec_gemv2_kernel). WLX_ROWTILE=0 restores the 48-row form (A/B).
 static GemvParams gemv_chunked(const GemvParams& p) {
     static const bool rt_on = [] { const char* e = wlx_ab("WLX_ROWTILE"); return !(e && e[0] == '0'); }();
-    constexpr int rt_max = WLX_MAX_DEC_ROWS, rt_chunk = 16;      // (32- and 48-row tiles, and a cap on the N that is cut, were measured in round 4: DESIGN.md)
+    constexpr int rt_max = WLX_MAX_DEC_ROWS;
+    // rows per tile: 16 (one MFMA row tile per workgroup; 32- and 48-row tiles were measured in round 4 for <= 64 rows and lost). WLX_ROWTILE_CHUNK
+    // (A/B builds) = 32 / 48: two / three row tiles per workgroup share one pass over the weight tile
+    static const int rt_chunk_env = [] { const char* e = wlx_ab("WLX_ROWTILE_CHUNK"); const int v = e ? atoi(e) : 0; return (v == 16 || v == 32 || v == 48) ? v : 0; }();
+    int rt_chunk = 16;
+    // Round 5 (wide batches): the fp16-rows-in residual projections (attention output, cross-attention output, MLP down: 1024-thread
+    // workgroups, one per CU, no LayerNorm prologue to repeat) take two or three row tiles per workgroup where that saves ROUNDS of
+    // workgroups: N = 768 at 120 rows is 48 x 8 = 384 workgroups on 256 CUs with 16-row tiles, 192 with 32-row tiles (6.7 -> 5.8 us per
+    // launch; large-v3 at 160 rows 16.7 -> 13.9 us; profiles/r5h_rowtile_chunk_by_rows.txt). Cost model: rounds x (1 + 0.35 per extra row
+    // tile). The LayerNorm-fronted projections stay on 16 rows (every workgroup re-normalises its rows: 32-row tiles measured 10-40 % slower).
+    if (p.in_mode == GEMV_IN_F16 && p.out_mode == GEMV_OUT_RESID && p.xsrc == GEMV_X_PLAIN && !p.busy_device && p.M > 64) {
+        static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount; return n; }();
+        const int tiles = (p.N + 15) / 16;
+        double best = 1e300;
+        for (int mt = 1; mt <= 3; ++mt) {
+            const long wgs = (long)tiles * ((p.M + 16 * mt - 1) / (16 * mt));
+            const double cost = (double)((wgs + n_cu - 1) / n_cu) * (1.0 + 0.35 * (mt - 1));
+            if (cost < best - 1e-9) { best = cost; rt_chunk = 16 * mt; }
+        }
+    }
+    if (rt_chunk_env) rt_chunk = rt_chunk_env;
     GemvParams q = p;
     if (p.Mtot != 0 || p.in_mode == GEMV_IN_XATTN) return q;
     // Which projections: measured per kernel at 20 / 40 / 60 rows (profiles/r4a-c_*): row tiles win wherever the launch has few
@@ -1217,7 +1237,7 @@ static GemvParams gemv_chunked(const GemvParams& p) {
     // projection 8.8 -> 7.7 us, first MLP projection 9.2 -> 7.6 us, step 2183 -> 2087 us; profiles/r4lv3rt_decode_step.txt): every
     // LayerNorm-fronted projection whose tile count divides by four is cut too from three row tiles up (60 rows: 3157 -> 2857 us; 20 rows,
     // two row tiles: 1845 -> 1905 us, left as it was). WLX_ROWTILE_WIDE=0 = the earlier policy (A/B).
-    const bool ln_wide4 = p.M > 32 && p.in_mode == GEMV_IN_LN && p.xsrc == GEMV_X_PLAIN && (p.out_mode == GEMV_OUT_QKV || p.out_mode == GEMV_OUT_GELU_F16) &&
+    const bool ln_wide4 = rt_chunk == 16 && p.M > 32 && p.in_mode == GEMV_IN_LN && p.xsrc == GEMV_X_PLAIN && (p.out_mode == GEMV_OUT_QKV || p.out_mode == GEMV_OUT_GELU_F16) &&
                           (p.N & 15) == 0 && ((p.N >> 4) & 3) == 0;
     const bool rt_shape = p.N <= 1536 || (long)p.N * p.K <= 3200000L || ln_wide4;
     if (rt_on && !g_decode_v1 && p.M > rt_chunk && p.M <= rt_max && rt_shape) { q.Mtot = p.M; q.M = rt_chunk; q.chunk = rt_chunk; q.rt_nz = (p.M + rt_chunk - 1) / rt_chunk; }
