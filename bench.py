@@ -111,6 +111,12 @@ def cpu_baseline(spec, weights, pcm, ids, decode_steps: int, full_steps: int, th
         oracle = omodel.WhisperOracle(omodel.Spec(spec.n_mels, spec.d_model, spec.n_heads, spec.enc_layers, spec.dec_layers,
                                                   spec.ffn, spec.vocab), weights, int8=int8)
         ests, parts, res = [], [], None
+        if repeats > 1:
+            # untimed warm-up (thread pool start, first-touch of the weights, allocator): the first of three runs was 2x the others
+            # (7.99 / 3.54 / 3.66 s, profiles/r5final_bench_default.json) — the median hid it, the reported spread did not
+            enc_w = oracle.encode(olm.pad_or_trim(olm.log_mel_spectrogram(pcm, spec.n_mels, precise=False)[:, :-1])[None])
+            odec.generate(NetProvider(oracle, enc_w), [ids["sot"]], odec.GenOptions(ids=odec.TokenIds(**ids), beam_size=5, patience=1.0, max_length=1 + 2,
+                                                                                   suppress_tokens=suppress_list(ids, True)))
         for _ in range(max(1, repeats)):
             t0 = time.perf_counter()
             feats = olm.log_mel_spectrogram(pcm, spec.n_mels, precise=False)
@@ -208,30 +214,38 @@ def measured_traffic(kernel_name: str, model: str, timeout_s: int = 300, child_a
                         n += 1
         if not n:
             return None, f"no FETCH_SIZE rows for {kernel_name} (rocprofv3 rc {proc.returncode}: {proc.stderr[-200:]})", {}
-        extra = {"raw_fetch_size_kib_per_launch": tot / n, "kib_to_bytes_factor_used": FETCH_KIB_TO_BYTES}
         from whisperlive_amd.specs import get_spec
         sp = get_spec(model)
-        # calibration inside the SAME pass: the vocabulary projection (dec_vocab_kernel since round 4) streams its V x d fp16 weight image
-        # exactly once per launch and nothing else of size, so known bytes / (raw KiB x 1024) must come out at ~2.0 for the
-        # x 1024 x 2 conversion to hold on this box. Outside [1.8, 2.2] the converted figure is NOT reported (traffic = null + why).
-        voc = {k: v for k, v in per.items() if "dec_vocab_kernel" in k}
-        if not voc:
-            extra["calibration"] = {"error": "no dec_vocab_kernel rows in the pass"}
-            return None, "FETCH_SIZE factor not calibrated: no dec_vocab_kernel launch in the counter pass", extra
-        big = max(voc.items(), key=lambda kv: kv[1][1])
-        raw_big = big[1][0] / big[1][1]
-        known = 2.0 * sp.vocab * sp.d_model
-        factor = known / (raw_big * 1024.0)
-        extra["calibration"] = {"kernel": big[0][:80], "launches": big[1][1], "raw_kib_per_launch": raw_big, "known_bytes": known,
-                                "bytes_per_raw_kib_over_1024": factor, "accepted_range": [1.8, 2.2]}
-        if not 1.8 <= factor <= 2.2:
-            return None, (f"FETCH_SIZE factor calibrated at {factor:.2f} on {big[0][:40]} — outside [1.8, 2.2]: the x1024x2 conversion "
-                          f"does not hold in this pass, traffic withheld"), extra
-        return tot / n * FETCH_KIB_TO_BYTES, f"rocprofv3 --pmc FETCH_SIZE pass of this run ({int(n)} launches)", extra
+        return reduce_fetch_pass(per, kernel_name, 2.0 * sp.vocab * sp.d_model)
     except Exception as e:  # noqa: BLE001 — the headline line must survive a failed counter pass
         return None, f"{type(e).__name__}: {e}", {}
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def reduce_fetch_pass(per, kernel_name: str, vocab_bytes: float):
+    """`per`: {kernel name: [sum of raw FETCH_SIZE (KiB), launches]} of ONE counter pass -> (bytes per launch of `kernel_name`, source, detail).
+    The KiB -> bytes factor is calibrated inside the SAME pass: the vocabulary projection (`dec_vocab_kernel`) streams its V x d fp16 weight
+    image exactly once per launch and nothing else of size, so known bytes / (raw KiB x 1024) must come out at ~2.0 for the x 1024 x 2
+    conversion (MI355X guide, HBM section) to hold on this box. Outside [1.8, 2.2] the converted figure is NOT reported (None + why)."""
+    hit = [(k, v) for k, v in per.items() if kernel_name in k]
+    tot, n = sum(v[0] for _, v in hit), sum(v[1] for _, v in hit)
+    if not n:
+        return None, f"no FETCH_SIZE rows for {kernel_name}", {}
+    extra = {"raw_fetch_size_kib_per_launch": tot / n, "kib_to_bytes_factor_used": FETCH_KIB_TO_BYTES}
+    voc = {k: v for k, v in per.items() if "dec_vocab_kernel" in k}
+    if not voc:
+        extra["calibration"] = {"error": "no dec_vocab_kernel rows in the pass"}
+        return None, "FETCH_SIZE factor not calibrated: no dec_vocab_kernel launch in the counter pass", extra
+    big = max(voc.items(), key=lambda kv: kv[1][1])
+    raw_big = big[1][0] / big[1][1]
+    factor = vocab_bytes / (raw_big * 1024.0)
+    extra["calibration"] = {"kernel": big[0][:80], "launches": big[1][1], "raw_kib_per_launch": raw_big, "known_bytes": vocab_bytes,
+                            "bytes_per_raw_kib_over_1024": factor, "accepted_range": [1.8, 2.2]}
+    if not 1.8 <= factor <= 2.2:
+        return None, (f"FETCH_SIZE factor calibrated at {factor:.2f} on {big[0][:40]} — outside [1.8, 2.2]: the x1024x2 conversion "
+                      f"does not hold in this pass, traffic withheld"), extra
+    return tot / n * FETCH_KIB_TO_BYTES, f"rocprofv3 --pmc FETCH_SIZE pass of this run ({int(n)} launches)", extra
 
 
 def rocprof_kernel_avg(kernel_name: str, model: str, timeout_s: int = 240, child_args=()):
