@@ -57,6 +57,28 @@ def test_transcribe_matches_oracle_pipeline(pair):
         assert abs(gs[0].avg_logprob - rs[0].avg_logprob) < 2e-2 and abs(gs[0].no_speech_prob - rs[0].no_speech_prob) < 1e-2
 
 
+def test_a_wider_beam_gets_a_wider_slot(pair):
+    """The reference passes any beam_size through to CTranslate2 (transcriber_faster_whisper.py:1380-1407). Slots are built for 5 rows per
+    item; a call that asks for more gets a wider slot (round 5: it used to be refused) — beam 8 against the oracle pipeline, then the
+    default again on the same (now 8-row) slot."""
+    hip, ora = pair
+    pcm = olm.speech_like_pcm(6.0, seed=5)
+    kw = dict(language="en", temperature=0.0, max_new_tokens=16, vad_filter=False, beam_size=8)
+    gs, _ = hip.transcribe(pcm, **kw)
+    rs, _ = ora.transcribe(pcm, **kw)
+    assert hip._slot().rows == 8
+    gt = [t for s in gs for t in s.tokens]
+    rt = [t for s in rs for t in s.tokens]
+    n = _common_prefix(gt, rt)
+    print("beam 8 common prefix", n, len(rt))
+    assert n >= min(6, len(rt))
+    kw5 = dict(kw, beam_size=5)
+    g5, _ = hip.transcribe(pcm, **kw5)
+    r5, _ = ora.transcribe(pcm, **kw5)
+    assert hip._slot().rows == 8                                   # kept: five rows fit in it
+    assert _common_prefix([t for s in g5 for t in s.tokens], [t for s in r5 for t in s.tokens]) >= min(6, sum(len(s.tokens) for s in r5))
+
+
 def test_language_detection_matches_oracle(pair):
     hip, ora = pair
     pcm = olm.speech_like_pcm(4.0, seed=9)

@@ -349,6 +349,20 @@ def test_wide_batches_decode_in_groups_over_the_same_encoder_output():
     assert eng.slots[-1].max_batch == 24 and eng.slots[-1].rows == 5
 
 
+def test_slot_widens_for_a_larger_beam_and_is_then_kept():
+    """`_slot(rows)`: five rows per item by default; a transcribe call with beam_size 8 replaces the thread's slot by an 8-row one (closed
+    slots leave the pool), later calls with the default beam keep it; more than the engine's 16 rows per item is refused."""
+    eng = FakeEngine()
+    m = WhisperModelHIP("fake", engine=eng, hf_tokenizer=synthetic_tokenizer(V), vad_model=EnergyGateModel())
+    s5 = m._slot()
+    assert (s5.max_batch, s5.rows) == (1, 5) and m._slot() is s5
+    s8 = m._slot(rows=8)
+    assert s8 is not s5 and s8.rows == 8 and s5.sid < 0 and m._slots == [s8]
+    assert m._slot() is s8 and m._slot(rows=6) is s8
+    with pytest.raises(ValueError, match="16 rows"):
+        m._slot(rows=17)
+
+
 def test_vad_unavailable_from_a_factory_built_transcriber_downgrades_once(monkeypatch):
     """a model_factory-built transcriber without Silero weights raised VadUnavailable on EVERY chunk (the server's
     availability check only runs for transcribers it builds itself): the session must downgrade to use_vad=False once, warn

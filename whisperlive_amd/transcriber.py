@@ -362,23 +362,34 @@ class WhisperModelHIP:
         return self.vad_model if self.vad_model is not None else _vad.get_default_model(getattr(self.engine, "device", 0))
 
     # ---- slots: one per calling thread (the reference runs one transcription thread per client)
-    def _slot(self) -> Slot:
+    def _slot(self, rows: int = 5) -> Slot:
         """The calling thread's slot. A slot is a few hundred MB of HBM (encoder activations, cross K/V, KV cache), so
         slots are POOLED: a thread that needs one first takes over a slot whose owner thread has ended (a client that
         disconnected) or that was handed back with release_slot(); a new one is created only when every slot is in use.
         The pool therefore holds max-concurrent-clients slots, not one per connection ever made, and reconnecting
-        clients reuse the captured decode graphs of their predecessor."""
+        clients reuse the captured decode graphs of their predecessor.
+        `rows`: decoder rows per audio item the caller is about to need (beam_size / best_of; 5 = the reference's defaults). A call
+        that asks for more than the thread's slot holds (the reference passes any beam_size through to CTranslate2) gets a wider slot
+        (up to the engine's 16 rows per item); the narrower one is closed."""
+        rows = max(5, int(rows))
         s = getattr(self._tls, "slot", None)
+        if s is not None and s.sid >= 0 and isinstance(getattr(s, "rows", None), int) and s.rows < rows:
+            with self._slots_lock:
+                self._slots = [x for x in self._slots if x is not s]
+            s.close()
+            s = None
         if s is None or s.sid < 0:
             me = threading.current_thread()
             with self._slots_lock:
                 self._slots = [x for x in self._slots if x.sid >= 0]
-                s = next((x for x in self._slots if x._owner is None or not x._owner.is_alive()), None)
+                s = next((x for x in self._slots if (x._owner is None or not x._owner.is_alive()) and getattr(x, "rows", rows) >= rows), None)
                 if s is not None:
                     s._owner = me
             if s is None:
-                # (5 rows per item = the reference's beam_size / best_of; the engine takes up to 64 items x 5 rows per slot)
-                s = self.engine.create_slot(self.max_batch, 5)
+                if rows > 16:
+                    raise ValueError(f"beam_size / best_of {rows}: the engine decodes at most 16 rows per audio item")
+                # (5 rows per item = the reference's beam_size / best_of; the engine takes up to 64 items x 5 rows = 320 rows per slot)
+                s = self.engine.create_slot(self.max_batch, rows)
                 s._enc_generation = 0
                 s._owner = me
                 with self._slots_lock:
@@ -488,7 +499,8 @@ class WhisperModelHIP:
             duration_after_vad = audio.shape[0] / sr
         if audio.shape[0] == 0:
             return None, None                                 # reference patch, :860-861
-        slot = self._slot()
+        temps_ = temperature if isinstance(temperature, (list, tuple)) else [temperature]
+        slot = self._slot(rows=max(int(beam_size), int(best_of) if any(t > 0 for t in temps_) else 1))
         with slot.lock:
             n_frames = slot.logmel(audio)                      # PCM -> HBM -> log-mel, stays on the device
             features = DeviceFeatures(slot, n_frames)
