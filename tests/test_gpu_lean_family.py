@@ -21,6 +21,7 @@ FAMILY = {
     "tiny-like": (80, 384, 6, 1, 2, 1536, 20000),       # round 5: d_model 384 = 1.5 x 256 on the lean kernels too (LNV = 15, six waves of two k-tiles)
     "base-like": (80, 512, 8, 1, 2, 2048, 20000),
     "small-like": (80, 768, 12, 1, 2, 3072, 51864),     # full vocabulary: the 2-tile vocabulary projection
+    "small-multilingual-like": (80, 768, 12, 1, 2, 3072, 51865),    # BASELINE configs[2]: the multilingual vocabulary is NOT a multiple of 16 (ragged last tile of the vocabulary projection, of the search's last timestamp chunk)
     "medium-like": (80, 1024, 16, 1, 2, 4096, 20000),
     "large-like": (128, 1280, 20, 1, 2, 5120, 20000),
 }

@@ -166,6 +166,38 @@ def test_batch_worker_on_device_equals_single_requests(pair):
     assert [[s.tokens for s in o] for o in outs] == [[s.tokens for s in o] for o in seq]
 
 
+def test_batch_worker_sixteen_requests_in_one_batch(gpu):
+    """`--batch_max_size 16` through the worker (round 5: the reference takes any max_batch_size, batch_inference.py:113-121; a slot used to
+    hold 12 clips and the server clamped): 16 requests = ONE batch = one encode of 16 windows and one 80-row decode, every request equal to
+    the same request processed alone."""
+    from whisperlive_amd.batching import BatchInferenceWorker, BatchRequest
+    from whisperlive_amd.specs import WhisperSpec
+    from whisperlive_amd.tokenizer import synthetic_tokenizer
+    from whisperlive_amd.transcriber import WhisperModelHIP
+    from whisperlive_amd.vad import EnergyGateModel
+    from whisperlive_amd.weights import random_weights
+    spec = WhisperSpec(n_mels=80, d_model=256, n_heads=4, enc_layers=2, dec_layers=2, ffn=1024, vocab=4310)
+    hip = WhisperModelHIP("rand", weights=random_weights(spec, seed=21), spec=spec, hf_tokenizer=synthetic_tokenizer(spec.vocab), max_batch=16,
+                          multilingual=False, vad_model=EnergyGateModel())
+    try:
+        clips = [olm.speech_like_pcm(2.0 + 0.25 * i, seed=140 + i) for i in range(16)]
+        w = BatchInferenceWorker(hip, max_batch_size=16, batch_window_ms=10)
+        assert w.max_batch_size == 16                                   # not clamped
+        w.TEMPERATURES = (0.0,)
+        reqs = [BatchRequest(audio=c, language="en", use_vad=False) for c in clips]
+        w._process_batch(reqs)
+        assert all(r.error is None and r.future.is_set() for r in reqs)
+        slot = hip._slot()
+        assert (slot.max_batch, slot.rows) == (16, 5)
+        for i in (0, 5, 11, 12, 15):                                    # incl. items past the old 12-clip limit
+            solo = BatchRequest(audio=clips[i], language="en", use_vad=False)
+            w._process_multi([solo])
+            assert [s.tokens for s in solo.result] == [s.tokens for s in reqs[i].result], i
+    finally:
+        hip.close()
+        hip.engine.close()
+
+
 def test_websocket_server_end_to_end_on_the_engine(pair):
     """Stock-protocol clients over loopback sockets -> TranscriptionServer -> ServeClientHIP -> libwlx.so. The first
     transcript a client receives must carry exactly the text the transcriber returns for that audio when called
