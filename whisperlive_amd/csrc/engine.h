@@ -48,7 +48,7 @@ struct Slot {
     int device_of = -1;
     bool counted = false;               // in the per-device live-slot count
     unsigned promote_epoch = 0;         // the last "crowd left" event this slot tried to take a hardware queue at (engine.hip slot_acquire)
-    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_poll0 = nullptr, ev_poll1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_lm0 = nullptr, ev_lm1 = nullptr;   // the last log-mel launch (its time is read lazily: wlx_logmel_resident does not wait)
     hipEvent_t ev_en0 = nullptr, ev_en1 = nullptr;   // the last encoder pass (wlx_encode does not wait either)
     bool en_pending = false;

@@ -409,8 +409,6 @@ static void slot_free(Slot* s) {
     if (s->h_gen) (void)hipHostFree(s->h_gen);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
-    if (s->ev_poll0) (void)hipEventDestroy(s->ev_poll0);
-    if (s->ev_poll1) (void)hipEventDestroy(s->ev_poll1);
     if (s->ev_lm0) (void)hipEventDestroy(s->ev_lm0);
     if (s->ev_lm1) (void)hipEventDestroy(s->ev_lm1);
     if (s->ev_en0) (void)hipEventDestroy(s->ev_en0);
@@ -611,8 +609,6 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
             CKR(create_slot_stream(e->device, &s->stream, &s->dedicated_queue));
         }
         CK(hipEventCreate(&s->ev0)); CK(hipEventCreate(&s->ev1));
-        CK(hipEventCreateWithFlags(&s->ev_poll0, hipEventDisableTiming));
-        CK(hipEventCreateWithFlags(&s->ev_poll1, hipEventDisableTiming));
         CK(hipEventCreate(&s->ev_lm0)); CK(hipEventCreate(&s->ev_lm1));
         CK(hipEventCreate(&s->ev_en0)); CK(hipEventCreate(&s->ev_en1));
         CKR(slot_grow_audio(e, s, 480000));
@@ -1516,6 +1512,7 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
     // chain of early-exit kernels (every decode kernel tests the flag).
     volatile int* h_done = s->h_stage + (s->h_stage_ints - 4);
     h_done[0] = 0;
+    h_done[1] = 0;                                              // the update kernels' step number (search.hip step_mirror)
     const double tg1 = now_us();
     int steps_run = 0;
     bool finished = false;
@@ -1535,18 +1532,28 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
             if (gen_trace) tg_launch += now_us() - ta;
         }
         ++steps_run;
-        // The search kernel of the step that finishes the last item stores 1 to the pinned word h_done itself; an event
-        // after every step tells the host how far the stream got. Step k+1 is enqueued BEFORE the host waits for step
-        // k-1, so the stream never runs dry; at most two steps run past the finish (scratch-only, see decoder_pass).
-        // (Polling every 2nd / 4th step instead was measured: 27.76 / 27.74 ms vs 28.01 ms of device time for 64 steps, i.e. the
-        // events cost <1 %, while every skipped poll lets one more 140 us early-exit step run past a real end-of-text.)
-        CK(hipEventRecord((step & 1) ? s->ev_poll1 : s->ev_poll0, st));
+        // The search kernel of the step that finishes the last item stores 1 to the pinned word h_done itself, and every update kernel
+        // stores its step number to the pinned word next to it as it ends (search.hip step_mirror): the host reads how far the stream got
+        // from that word. Step k+1 is enqueued BEFORE the host waits for step k-1 to have ended, so the stream never runs dry; at most two
+        // steps run past the finish (scratch-only, see decoder_pass). Round 5: this replaced a hipEventRecord after every step graph +
+        // hipEventSynchronize one step behind, which cost 0.31 ms per 64-step window (profiles/r5p_*: 27.59 vs 27.28 ms with no
+        // synchronisation at all; polling every 2nd / 4th step had been measured in round 2 and rejected — a skipped poll lets a whole
+        // step run past a real end of text).
         if (injected_logits) {
             CK(hipStreamSynchronize(st));
             finished = h_done[0] != 0;
         } else if (step >= 1) {
             const double ta = gen_trace ? now_us() : 0.0;
-            CK(hipEventSynchronize(((step - 1) & 1) ? s->ev_poll1 : s->ev_poll0));
+            int spins = 0;
+            while (h_done[1] < step && h_done[0] == 0) {      // update kernel number `step` (= decode step `step - 1`) has not ended yet
+                __builtin_ia32_pause();
+                if (++spins >= (1 << 16)) {                    // every few ms: is the stream still alive? (a fault must not hang the caller)
+                    spins = 0;
+                    const hipError_t q = hipStreamQuery(st);
+                    if (q == hipSuccess) break;                // drained: the counter is final
+                    if (q != hipErrorNotReady) return fail(WLX_ERR_HIP, "decode loop: %s", hipGetErrorString(q));
+                }
+            }
             if (gen_trace) tg_wait += now_us() - ta;
             finished = h_done[0] != 0;
         }
