@@ -34,6 +34,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 WINDOW_S = 30.0
+COLL_DEVICE = "cuda"            # device of the tensors handed to torch.distributed (RCCL needs device tensors; the gloo rehearsal uses host ones)
 
 
 def token_ids(vocab: int):
@@ -512,7 +513,7 @@ def config5(args, rank, world, local, dist, torch):
     clips = [olm.speech_like_pcm(WINDOW_S, seed=2000 + i) if lo <= i < hi else None for i in range(n)]
     lang = "en"
     process = sh.worker_block_processor(worker, lambda c: BatchRequest(audio=c, language=lang, use_vad=False))
-    device = f"cuda:{local}"
+    device = f"cuda:{local}" if COLL_DEVICE == "cuda" else "cpu"     # where the gathered records live (host tensors in the gloo rehearsal)
 
     def step():
         t0 = time.perf_counter()
@@ -535,7 +536,7 @@ def config5(args, rank, world, local, dist, torch):
     barrier()
     wall = time.perf_counter() - t0
     if dist is not None:
-        tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        tw = torch.tensor([wall], dtype=torch.float64, device=COLL_DEVICE)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
     out = None
@@ -594,6 +595,8 @@ def config5(args, rank, world, local, dist, torch):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        if COLL_DEVICE == "cpu":
+            out["rehearsal"] = True          # WLX_BENCH_REHEARSAL: ranks shared a GPU over gloo — not a measurement
         print(json.dumps(out))
 
 
@@ -689,15 +692,27 @@ def main():
                          f"torch.distributed.run with --nproc-per-node equal to --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # WLX_BENCH_REHEARSAL=1: a rehearsal of the N-rank code path on a box with FEWER GPUs than ranks (the build pool has one-GPU boxes only):
+    # the ranks share the visible GPUs and rendezvous over gloo with host tensors. Everything else — rank roles, barriers, the max-over-ranks
+    # reduction, the latency gather, rank 0's extra legs while the others wait — runs as it does under RCCL. Its output line says
+    # "rehearsal": true and is not a measurement (RCCL refuses two ranks on one device, so the nccl backend cannot be rehearsed this way).
+    rehearsal = world > 1 and os.environ.get("WLX_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = local % max(1, torch.cuda.device_count())
     if torch.cuda.device_count() <= local:
         raise SystemExit(f"rank {rank} needs GPU {local} but only {torch.cuda.device_count()} are visible")
     torch.cuda.set_device(local)
     dist = None
+    global COLL_DEVICE
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if rehearsal:
+            COLL_DEVICE = "cpu"
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from oracle import logmel as olm   # synthetic-input generator only (speech_like_pcm); the timed path is HIP
     from whisperlive_amd.engine import HipWhisperEngine, TokenIds
@@ -805,10 +820,10 @@ def main():
     barrier()
     wall = time.perf_counter() - t0
     if dist is not None:
-        tw = torch.tensor([wall], dtype=torch.float64, device="cuda")
+        tw = torch.tensor([wall], dtype=torch.float64, device=COLL_DEVICE)
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
         wall = float(tw.item())
-        lt = torch.tensor(lat, dtype=torch.float64, device="cuda")
+        lt = torch.tensor(lat, dtype=torch.float64, device=COLL_DEVICE)
         gathered = [torch.zeros_like(lt) for _ in range(world)]
         dist.all_gather(gathered, lt)
         lat = torch.cat(gathered).cpu().tolist()
@@ -938,6 +953,8 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
+        if COLL_DEVICE == "cpu":
+            out["rehearsal"] = True          # WLX_BENCH_REHEARSAL: ranks shared a GPU over gloo — not a measurement
         print(json.dumps(out))
 
 
