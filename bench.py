@@ -31,6 +31,8 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+from whisperlive_amd.synthetic import energy_following_vad_weights, speech_like_pcm  # noqa: E402  (numpy-only generators)
+
 
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 WINDOW_S = 30.0
@@ -441,8 +443,7 @@ def make_bench_transcriber(eng, spec, ids, decode_steps, vad_model=None, max_bat
 def stream_pcm(seconds: float, seed: int = 1234) -> np.ndarray:
     """The stream leg's audio: `speech_like_pcm` (2.5 s phrases / 1.0 s pauses) with a 3 s noise-only stretch in every 12 s,
     i.e. longer than the gate's min_silence_duration_ms = 2000 — audio the VAD has to CUT, not only to look at."""
-    from oracle import logmel as olm          # synthetic-input generator only
-    pcm = olm.speech_like_pcm(seconds, seed).copy()
+    pcm = speech_like_pcm(seconds, seed).copy()
     t = np.arange(pcm.shape[0]) / 16000.0
     quiet = (t % 12.0) >= 9.0
     noise = np.random.default_rng(seed + 7).normal(0.0, 0.003, pcm.shape[0]).astype(np.float32)
@@ -453,13 +454,12 @@ def stream_pcm(seconds: float, seed: int = 1234) -> np.ndarray:
 def stream_leg(eng, spec, ids, decode_steps, pcm_fn, clients=1, batch=False, model_name="small.en"):
     """configs[1] / configs[2] through the server shell on the already-built engine (make_bench_transcriber). VAD: the
     Silero network on the GPU (libwlx.so wlx_vad_*) with seeded weights whose probabilities FOLLOW the audio's energy
-    (oracle/silero_vad.py::energy_following_weights — no Silero weight file exists offline): phrases pass, the 3 s
+    (whisperlive_amd/synthetic.py::energy_following_vad_weights — no Silero weight file exists offline): phrases pass, the 3 s
     noise-only stretches of `stream_pcm` are cut, so speech segmentation, `collect_chunks` and `restore_speech_timestamps`
     all run with real effect inside the timed path, and the network costs exactly what the real one costs."""
-    from oracle import silero_vad as sv          # seeded weight generator only; the network runs in libwlx.so
     from whisperlive_amd import vad
 
-    w = sv.energy_following_weights(3)
+    w = energy_following_vad_weights(3)
     vm = vad.SileroHIPModel(w, device=eng.device)
     probe = pcm_fn(24.0, 4321)
     spans = vad.get_speech_timestamps(probe, vad.VadOptions(threshold=0.5), model=vm)
@@ -493,7 +493,6 @@ def config5(args, rank, world, local, dist, torch):
     clients (whisper_live/server.py:665-673, batch_inference.py:155-438: per-item log-mel, ONE batched encode, ONE
     batched beam-5 decode per batch), then ONE fixed-size all_gather of 2 KiB result records over RCCL. A "step" = one
     pass over all clips; value = clips x 30 s x steps / max-over-ranks wall."""
-    from oracle import logmel as olm   # synthetic-input generator only
     from whisperlive_amd import sharding as sh
     from whisperlive_amd.batching import BatchInferenceWorker, BatchRequest
     from whisperlive_amd.engine import HipWhisperEngine
@@ -510,7 +509,7 @@ def config5(args, rank, world, local, dist, torch):
     worker.start()
     n = args.clips
     lo, hi = sh.shard_range(n, rank, world)
-    clips = [olm.speech_like_pcm(WINDOW_S, seed=2000 + i) if lo <= i < hi else None for i in range(n)]
+    clips = [speech_like_pcm(WINDOW_S, seed=2000 + i) if lo <= i < hi else None for i in range(n)]
     lang = "en"
     process = sh.worker_block_processor(worker, lambda c: BatchRequest(audio=c, language=lang, use_vad=False))
     device = f"cuda:{local}" if COLL_DEVICE == "cuda" else "cpu"     # where the gathered records live (host tensors in the gloo rehearsal)
@@ -600,7 +599,7 @@ def config5(args, rank, world, local, dist, torch):
         print(json.dumps(out))
 
 
-def throughput_leg(eng, spec, olm, torch, ids, eids, gen_kw, decode_steps, TS=3, TB=48, tsteps=2):
+def throughput_leg(eng, spec, torch, ids, eids, gen_kw, decode_steps, TS=3, TB=48, tsteps=2):
     """The throughput configuration of ONE GPU, timed by the same driver run (VERDICT r03 task 5): TS slots on their own hardware
     queues x TB windows batched into every decode — what a --batch_inference server with TS lanes and --batch_max_size TB
     runs (round 5: 3 x 48; a slot held at most 12 windows until then). Called after the headline's own slot is closed: a fifth live
@@ -610,7 +609,7 @@ def throughput_leg(eng, spec, olm, torch, ids, eids, gen_kw, decode_steps, TS=3,
     try:
         for i, sl in enumerate(tslots):
             for b in range(TB):
-                sl.pcm_put(olm.speech_like_pcm(WINDOW_S, seed=5000 + 100 * i + b), b)
+                sl.pcm_put(speech_like_pcm(WINDOW_S, seed=5000 + 100 * i + b), b)
 
         def tstep(sl):
             Ts_ = [sl.logmel_resident(b) for b in range(TB)]
@@ -714,7 +713,6 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
-    from oracle import logmel as olm   # synthetic-input generator only (speech_like_pcm); the timed path is HIP
     from whisperlive_amd.engine import HipWhisperEngine, TokenIds
     from whisperlive_amd.specs import get_spec
     from whisperlive_amd.weights import random_weights
@@ -732,7 +730,7 @@ def main():
         sl = eng.create_slot(Bc, 5)
         ids_ = token_ids(spec.vocab)
         for b in range(Bc):
-            sl.pcm_put(olm.speech_like_pcm(WINDOW_S, seed=1234 + b), b)
+            sl.pcm_put(speech_like_pcm(WINDOW_S, seed=1234 + b), b)
         Ts = [sl.logmel_resident(b) for b in range(Bc)]
         sl.encode(Bc, seek=[0] * Bc, seg=[min(T - 1, 3000) for T in Ts])
         sl.generate([[ids_["sot"]]] * Bc, TokenIds(**ids_), beam_size=5, patience=1.0, max_length=1 + 12,
@@ -746,12 +744,12 @@ def main():
     slot = slots[0]
     ids = token_ids(spec.vocab)
     eids = TokenIds(**ids)
-    pcm = olm.speech_like_pcm(WINDOW_S, seed=1234 + rank)
+    pcm = speech_like_pcm(WINDOW_S, seed=1234 + rank)
     gen_kw = dict(beam_size=5, patience=1.0, max_length=1 + args.decode_steps, suppress_tokens=suppress_list(ids, True))
 
     for i, sl in enumerate(slots):     # inputs resident in HBM before the timed region
         for b in range(B):
-            sl.pcm_put(pcm if (i == 0 and b == 0) else olm.speech_like_pcm(WINDOW_S, seed=1234 + rank + 100 * i + b), b)
+            sl.pcm_put(pcm if (i == 0 and b == 0) else speech_like_pcm(WINDOW_S, seed=1234 + rank + 100 * i + b), b)
 
     def step_on(sl):
         t0 = time.perf_counter()
@@ -945,7 +943,7 @@ def main():
         ts_, tb_ = (int(v) for v in args.throughput_shape.lower().split("x"))
         note(f"throughput leg ({ts_} streams x {tb_} windows per decode)")
         try:
-            out["throughput"] = throughput_leg(eng, spec, olm, torch, ids, eids, gen_kw, args.decode_steps, TS=ts_, TB=tb_)
+            out["throughput"] = throughput_leg(eng, spec, torch, ids, eids, gen_kw, args.decode_steps, TS=ts_, TB=tb_)
         except Exception as e:  # noqa: BLE001 — the headline line must survive a failure of this leg
             out["throughput"] = {"error": f"{type(e).__name__}: {e}"}
     eng.close()

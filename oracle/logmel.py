@@ -104,17 +104,4 @@ def pad_or_trim(array: np.ndarray, length: int = N_FRAMES, axis: int = -1) -> np
     return array
 
 
-def speech_like_pcm(seconds: float, seed: int = 1234) -> np.ndarray:
-    """Deterministic synthetic 'speech-like' PCM of SURVEY.md §8(d): formants x 4 Hz syllabic envelope
-    x on/off phrases (2.5 s on / 1.0 s off) + noise, peak 0.5, float32, 16 kHz."""
-    rng = np.random.default_rng(seed)
-    n = int(round(seconds * SAMPLE_RATE))
-    t = np.arange(n) / SAMPLE_RATE
-    sig = np.sin(2 * np.pi * 120 * t)
-    for f, a in ((700, 0.6), (1200, 0.4), (2600, 0.25)):
-        sig = sig + a * np.sin(2 * np.pi * f * t + rng.uniform(0, 2 * np.pi))
-    env = 0.5 * (1 + np.sin(2 * np.pi * 4 * t))
-    phrase = ((t % 3.5) < 2.5).astype(np.float64)
-    sig = sig * env * phrase + rng.normal(0, 0.01, n)
-    sig = 0.5 * sig / np.max(np.abs(sig))
-    return sig.astype(np.float32)
+from whisperlive_amd.synthetic import speech_like_pcm  # noqa: E402,F401  (generator, not oracle: kept importable from here for the tests)

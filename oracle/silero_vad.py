@@ -159,31 +159,4 @@ def speech_probs_torch(w: Dict[str, np.ndarray], audio: np.ndarray) -> np.ndarra
     return torch.cat(probs).numpy().astype(np.float32)
 
 
-def energy_following_weights(seed: int = 0, on_level: float = 0.05) -> Dict[str, np.ndarray]:
-    """Seeded weights of the exact Silero shapes whose output FOLLOWS the short-time spectral energy of the input, so that a
-    benchmark's VAD gate really gates (speech-like stretches pass, noise-only stretches are cut) while costing exactly what
-    the real network costs — no Silero weight file exists offline (module docstring). Construction: non-negative averaging
-    taps in the four convolutions (feature ~ mean STFT magnitude of the window), an LSTM cell opened wide (input / output
-    gates biased on, forget gate biased off, small seeded recurrent weights) whose candidate gate is tanh(k (m - on_level)),
-    and a positive read-out: p ~ sigmoid(+4) where the mean magnitude m is well above `on_level`, sigmoid(-3) below it."""
-    rng = np.random.default_rng(seed)
-    w = {"stft_basis": fourier_basis()}
-    for i, (cin, cout, _s) in enumerate(ENC_CHANNELS):
-        w[f"enc{i}_w"] = ((1.0 + 0.3 * rng.uniform(-1, 1, (cout, cin, 3))) / (3.0 * cin)).astype(np.float32)
-        w[f"enc{i}_b"] = np.zeros(cout, np.float32)
-    # a window's feature after the four averaging layers is ~ 0.3-0.6 x its mean magnitude (zero padding at the frame edges)
-    k = 6.0 / on_level
-    w_ih = np.zeros((4 * HIDDEN, HIDDEN), np.float32)
-    w_ih[2 * HIDDEN: 3 * HIDDEN] = (k / HIDDEN) * (1.0 + 0.3 * rng.uniform(-1, 1, (HIDDEN, HIDDEN)))
-    b = np.zeros(4 * HIDDEN, np.float32)
-    b[:HIDDEN] = 4.0                      # input gate open
-    b[HIDDEN: 2 * HIDDEN] = -4.0          # forget gate closed: c = i * g
-    b[2 * HIDDEN: 3 * HIDDEN] = -0.45 * k * on_level
-    b[3 * HIDDEN:] = 4.0                  # output gate open
-    w["lstm_w_ih"] = w_ih
-    w["lstm_w_hh"] = (rng.uniform(-1, 1, (4 * HIDDEN, HIDDEN)) * 0.02).astype(np.float32)
-    w["lstm_b_ih"] = b
-    w["lstm_b_hh"] = np.zeros(4 * HIDDEN, np.float32)
-    w["out_w"] = ((7.0 / (0.76 * HIDDEN)) * (1.0 + 0.2 * rng.uniform(-1, 1, HIDDEN))).astype(np.float32)
-    w["out_b"] = np.asarray([-3.0], np.float32)
-    return w
+from whisperlive_amd.synthetic import energy_following_vad_weights as energy_following_weights  # noqa: E402,F401  (generator, not oracle: kept importable from here for the tests)

@@ -3,7 +3,8 @@ on the same seeded inputs. Tolerances are stated per test:
 
 * log-mel: fp32 kernel vs float64 oracle: max-abs <= 2e-4 over the whole map (values live in roughly [-1, 2]).
 * encoder / decoder logits: fp16 MFMA operands with fp32 accumulation and an fp32 residual stream vs the fp32
-  oracle evaluated on the SAME fp16-rounded weights: relative RMS <= 2e-2, max-abs <= 6e-2 * ref_rms + 2e-2.
+  oracle evaluated on the SAME fp16-rounded weights: relative RMS <= 2e-3 (encoder states) / 5e-3 (logits),
+  max-abs <= 10 x that x ref_rms + 1e-3 — the bounds of tests/test_gpu_full_depth.py.
 * search (logits processors + beam/sampling bookkeeping) on injected logits: token-exact, scores to 1e-3.
 """
 import numpy as np
@@ -67,6 +68,29 @@ def test_logmel_parity(tiny, n):
         slot.close()
 
 
+def test_logmel_against_reference_vectors(tiny, micro128):
+    """The HIP log-mel against vectors the REFERENCE'S OWN code produced (tests/golden/ref_logmel_golden.npz: outputs of
+    whisper_live/transcriber/tensorrt_utils.py::log_mel_spectrogram(padding=160), generated in the build container by
+    tests/golden/make_ref_logmel_golden.py — /root/reference does not exist on the GPU box). Tolerance 2e-4 like the oracle
+    test (the reference's float32 STFT itself sits up to 6e-5 from the float64 answer, tests/test_reference_logmel_diff.py)."""
+    import os
+    from whisperlive_amd.synthetic import speech_like_pcm
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_logmel_golden.npz"))
+    for i, (sec, seed, n_mels) in enumerate(g["cases"]):
+        spec, eng, _ = tiny if int(n_mels) == 80 else micro128
+        assert spec.n_mels == int(n_mels)
+        slot = eng.create_slot(1, 5)
+        try:
+            slot.logmel(speech_like_pcm(float(sec), seed=int(seed)))
+            got = slot.features()
+        finally:
+            slot.close()
+        want = g[f"logmel_{i}"]
+        assert got.shape == want.shape
+        st = H.err_stats(got, want)
+        assert st["max_abs"] <= 2e-4, (i, st)
+
+
 def test_logmel_silence_and_128(micro128):
     spec, eng, _ = micro128
     slot = eng.create_slot(1, 5)
@@ -114,9 +138,11 @@ def test_logmel_ragged_items_one_launch(tiny):
         one.close()
 
 
-def _check_close(got, ref, what):
+def _check_close(got, ref, what, rel=2e-3):
+    """rel-rms <= 2e-3 (encoder states) / 5e-3 (logits): the bounds of tests/test_gpu_full_depth.py on the same quantities
+    (measured 1.8e-4 ... 8e-4); max-abs <= 10 x that bound x the reference's rms + 1e-3. (Until round 6: 2e-2 / 6e-2.)"""
     st = H.err_stats(got, ref)
-    ok = st["rel_rms"] <= 2e-2 and st["max_abs"] <= 6e-2 * st["ref_rms"] + 2e-2 and np.isfinite(got).all()
+    ok = st["rel_rms"] <= rel and st["max_abs"] <= 10 * rel * st["ref_rms"] + 1e-3 and np.isfinite(got).all()
     assert ok, (what, st)
     return st
 
@@ -169,7 +195,7 @@ def test_decoder_logits_parity(tiny, n_tok):
         toks = rng.integers(0, spec.vocab, size=n_tok)
         got = slot.debug_decode_logits(toks)
         ref = oracle.decode_logits(enc, toks[None])[0].numpy()
-        st = _check_close(got, ref, f"decoder logits n={n_tok}")
+        st = _check_close(got, ref, f"decoder logits n={n_tok}", rel=5e-3)
         print("decoder parity", n_tok, st)
     finally:
         slot.close()

@@ -218,3 +218,20 @@ def test_beam_search_equals_hf_beam_search(case):
         best = odec.generate(_BiasedProvider(oracle, enc, bias), [L["sot"]], o1)
         assert best.sequences_ids[0] == res.sequences_ids[0] and abs(best.scores[0] - res.scores[0]) < 1e-6
     assert n_eot >= 5                                  # the finished-hypothesis path was exercised
+
+
+# ---------------------------------------------------------------- vectors computed BY THE REFERENCE'S OWN log-mel (round 6)
+def test_oracle_logmel_against_reference_vectors():
+    """tests/golden/ref_logmel_golden.npz holds outputs of whisper_live/transcriber/tensorrt_utils.py::log_mel_spectrogram
+    (padding=160) on seeded PCM, generated by tests/golden/make_ref_logmel_golden.py in the build container; tolerance and its
+    reason: tests/test_reference_logmel_diff.py (the live differential, which needs /root/reference)."""
+    import os
+    from whisperlive_amd.synthetic import speech_like_pcm
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_logmel_golden.npz"))
+    for i, (sec, seed, n_mels) in enumerate(g["cases"]):
+        pcm = speech_like_pcm(float(sec), seed=int(seed))
+        want = g[f"logmel_{i}"]
+        got = olm.log_mel_spectrogram(pcm, int(n_mels))
+        assert got.shape == want.shape
+        d = np.abs(got - want)
+        assert float(d.max()) <= 1e-4 and float(np.quantile(d, 0.999)) <= 2e-5, (i, float(d.max()))
