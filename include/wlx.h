@@ -40,8 +40,11 @@
  * Such processes should set WLX_SLOT_CU_MASK=off (ordinary non-blocking streams on the shared queue
  * pool) — and get exactly that by DEFAULT (round 5) once any weight tensor has been handed to
  * wlx_engine_create with on_device = 1, i.e. when the process demonstrably holds device memory of
- * another runtime; an explicit WLX_SLOT_CU_MASK always wins. The library states the mode once on
- * stderr at the first slot creation (WLX_QUIET silences it).
+ * another runtime; an explicit WLX_SLOT_CU_MASK always wins. The flag is process-wide and sticky; a
+ * slot created BEFORE the first such engine gives its blocking stream back at its next call
+ * (round 6), so no creation order has to be observed. The library states the mode on stderr at the
+ * first slot creation in each mode (WLX_QUIET silences it). wlx_slot_create estimates the slot's
+ * device memory first and refuses (WLX_ERR_NOMEM, with the figure) what the device cannot hold.
  */
 #ifndef WLX_H
 #define WLX_H

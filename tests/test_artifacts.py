@@ -141,5 +141,38 @@ def test_default_vad_model_skips_a_file_that_is_not_silero(tmp_path, monkeypatch
     monkeypatch.setattr(vad, "_default_model", None)
     monkeypatch.setattr(vad, "_default_weights", None)
     monkeypatch.setattr(vad, "_device_models", {})
+    monkeypatch.setattr(vad, "_resolve_failed", None)
     with pytest.raises(vad.VadUnavailable, match="whisper-live/silero_vad.onnx"):
         vad.get_default_model(0)
+
+
+def test_default_vad_lookup_runs_once_and_outside_the_model_lock(monkeypatch):
+    """the look-up (which may download for up to 10 s) ran under the process-wide model lock on EVERY call that found no
+    weights. Now: one look-up per process, without the model lock; a failed one is remembered and later calls raise at once;
+    set_default_model(None) / configure() forget the failure."""
+    from whisperlive_amd import vad
+    for k in ("WLX_SILERO_VAD_NPZ", "WLX_SILERO_VAD_ONNX", "WLX_ALLOW_VAD_STANDIN"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setattr(vad, "_default_model", None)
+    monkeypatch.setattr(vad, "_default_weights", None)
+    monkeypatch.setattr(vad, "_device_models", {})
+    monkeypatch.setattr(vad, "_resolve_failed", None)
+    calls = []
+
+    def finder():
+        calls.append(vad._default_lock.acquire(blocking=False))      # the model lock is FREE while the look-up runs
+        if calls[-1]:
+            vad._default_lock.release()
+        return None
+    monkeypatch.setattr(vad, "_find_default_weights", finder)
+    for _ in range(3):
+        with pytest.raises(vad.VadUnavailable):
+            vad.get_default_model(0)
+    assert calls == [True]                                            # looked up once, lock not held; calls 2 and 3 raised immediately
+    vad.set_default_model(None)
+    with pytest.raises(vad.VadUnavailable):
+        vad.get_default_model(0)
+    assert calls == [True, True]
+    monkeypatch.setenv("WLX_ALLOW_VAD_STANDIN", "1")
+    assert isinstance(vad.get_default_model(0), vad.EnergyGateModel)
+    vad.set_default_model(None)

@@ -361,6 +361,12 @@ def test_slot_widens_for_a_larger_beam_and_is_then_kept():
     assert m._slot() is s8 and m._slot(rows=6) is s8
     with pytest.raises(ValueError, match="16 rows"):
         m._slot(rows=17)
+    # a refused request leaves the thread's slot alone (it used to be closed before the check)
+    assert s8.sid >= 0 and m._slots == [s8] and m._slot() is s8
+    m.max_batch = 64
+    with pytest.raises(ValueError, match="320"):
+        m._slot(rows=9)
+    assert s8.sid >= 0 and m._slot() is s8 and m._slot(rows=6) is s8
 
 
 def test_vad_unavailable_from_a_factory_built_transcriber_downgrades_once(monkeypatch):

@@ -79,6 +79,35 @@ def test_two_rank_gloo_gather(n_clips):
         assert toks == [[i, 10 + i] for i in range(n_clips)] and scores == [i * 0.5 for i in range(n_clips)]
 
 
+def _worker_ws1(port, q):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        clips = [np.full(10 + i, i, np.float32) for i in range(5)]
+        out = sh.transcribe_clips_sharded(clips, _fake_block, rank=0, world=1, dist=dist)
+        q.put([o[0] for o in out])
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_one_still_runs_the_collective():
+    """bench.py --rccl (tests/test_gpu_rccl.py): with an initialised process group the record exchange is a real all_gather at
+    world size 1 too (until round 6 it returned early), here over gloo."""
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_ws1, args=(port, q))
+    p.start()
+    assert q.get(timeout=120) == [[i, 10 + i] for i in range(5)]
+    p.join(60)
+    assert p.exitcode == 0
+
+
 # ---- config 5 driver: clips -> per-rank batch worker -> records -> one all_gather ------------------------------------
 class _FakeBatchWorker:
     """Stands in for a rank's BatchInferenceWorker (same submit()/future contract, batches of <= max_batch_size formed

@@ -2,6 +2,7 @@
 // (one HIP stream + all scratch per concurrent stream), and the host orchestration of
 // log-mel -> encoder -> prefill -> hipGraph-replayed decode steps.
 #include "engine.h"
+#include <sched.h>
 #include <atomic>
 #include <limits>
 #include <algorithm>
@@ -18,6 +19,16 @@
 
 using namespace wlx;
 
+// one polite spin-wait iteration (the decode loop polls a pinned word): the ISA's spin hint where there is one
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    asm volatile("" ::: "memory");
+#endif
+}
 static thread_local char g_err[512] = "";
 static int fail(int code, const char* fmt, ...) {
     va_list ap;
@@ -461,7 +472,11 @@ static int slot_acquire(wlx_engine* e, int slot, SlotGuard& g) {
     // more slots than dedicated hardware queues exist on this device now: give the queue back (see create_slot_stream: past
     // ~6 busy hardware queues everything collapses; eight ordinary streams over the shared pool run at 1883 xRT, eight with
     // four dedicated queues at 1145). The slot's captured graphs do not depend on the stream they were captured on.
-    if (s->dedicated_queue && g_demote[dv].load()) {
+    // ... or the process has since become an embedder of another runtime's device memory (a later engine's weights arrived as device
+    // pointers: g_embedded_device_memory): the CU-mask streams are BLOCKING streams and that runtime's NULL-stream work would invalidate
+    // this slot's captures, so a slot created before that engine gives its stream back at its next call too (the flag was
+    // read at stream creation only).
+    if (s->dedicated_queue && (g_demote[dv].load() || !dedicated_streams_possible())) {
         hipStream_t ns = nullptr;
         if (hipSetDevice(dv) == hipSuccess && hipStreamSynchronize(s->stream) == hipSuccess &&
             hipStreamCreateWithFlags(&ns, hipStreamNonBlocking) == hipSuccess) {
@@ -537,9 +552,11 @@ static int create_slot_stream(int device, hipStream_t* out, bool* dedicated_out)
     const int max_dedicated = max_dedicated_queues();
     static std::atomic<int> slot_seq{0};
     std::string m = slot_stream_mode();
-    {   // once per process: which kind of stream the slots get (the default synchronises implicitly with the NULL stream)
-        static std::atomic<bool> said{false};
-        if (!said.exchange(true) && getenv("WLX_QUIET") == nullptr)
+    {   // once per process AND MODE: which kind of stream the slots get (the default synchronises implicitly with the NULL
+        // stream; r05: the mode can change when an engine brings device-resident weights — say so again then)
+        static std::atomic<int> said{0};
+        const int bit = (m == "off") ? 1 : 2;
+        if (!(said.fetch_or(bit) & bit) && getenv("WLX_QUIET") == nullptr)
             fprintf(stderr, "[wlx] slot streams: WLX_SLOT_CU_MASK=%s%s, up to %d hardware queues per device%s\n", m.c_str(),
                     (m == "off" && g_embedded_device_memory.load()) ? " (weights were handed over as device pointers of another runtime: non-blocking streams unless the variable says otherwise)" : "",
                     max_dedicated,
@@ -592,6 +609,24 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
     CK(hipSetDevice(e->device));
     const wlx_spec& sp = e->spec;
     const int d = sp.d_model, F = sp.ffn, L = sp.dec_layers, B = max_batch, R = max_rows_per_item;
+    {   // what the slot will hold (its large terms), checked against the device BEFORE the first allocation (--batch_max_size 64
+        // builds 64 x 5-row slots — ~11 GB per lane for Whisper-small, ~45 GB for large-v3 — and used to fail, if at all, deep inside
+        // the allocation list with a bare hipMalloc error)
+        const double TBd = (double)B * WLX_T_AUDIO, rows = (double)std::max(64, B * R);
+        const double bytes = 2.0 * B * 480000 * 4 + (double)B * ((WLX_N_FRAMES + 2) * (sp.n_mels * 2.0 + d * 2.0)) +       // PCM + features, window, conv
+                             TBd * d * (4 + 2 + 2 + 2 + 2 + 4) + 2.0 * B * WLX_T_AUDIO_PAD * d * 2 + TBd * F * 2 +            // encoder activations
+                             2.0 * L * B * WLX_T_AUDIO_PAD * d * 2 +                                                           // cross K / V
+                             2.0 * L * (double)B * R * WLX_T_TEXT * d * 2 +                                                     // self-attention KV cache
+                             rows * (((sp.vocab + 15) / 16) * 16 * 4.0 + d * 8.0 + F * 2.0) + (double)WLX_T_TEXT * (d * 16.0 + F * 2.0);   // logits, step + prefill rows
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            if (bytes > (double)free_b)
+                return fail(WLX_ERR_NOMEM, "a slot of %d items x %d rows needs ~%.1f GB of device memory (encoder activations, cross K/V, KV cache, logits); "
+                            "%.1f GB are free on device %d: lower max_batch (--batch_max_size) or the number of lanes", B, R, bytes / 1e9, free_b / 1e9, e->device);
+        } else (void)hipGetLastError();
+        if (bytes > 8e9 && getenv("WLX_QUIET") == nullptr)
+            fprintf(stderr, "[wlx] slot of %d items x %d rows: ~%.1f GB of device memory\n", B, R, bytes / 1e9);
+    }
     Slot* s = new Slot();
     s->B = B; s->R = R; s->cache_rows = B * R; s->rows_cap = std::max(64, B * R); s->groups_cap = std::max(B, 4);
     s->nframes.assign(B, 0);
@@ -1544,11 +1579,14 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
             finished = h_done[0] != 0;
         } else if (step >= 1) {
             const double ta = gen_trace ? now_us() : 0.0;
-            int spins = 0;
+            int spins = 0, rounds = 0;
             while (h_done[1] < step && h_done[0] == 0) {      // update kernel number `step` (= decode step `step - 1`) has not ended yet
-                __builtin_ia32_pause();
+                // a short pure spin (the word usually moves within one step, 0.1-0.4 ms for one stream), then the core is offered to
+                // other runnable threads between polls (every decoding thread — batch lanes, client threads — used to burn a
+                // core for the whole generate). No sleep: a timer sleep (>= 50 us of slack) could let a 113 us tiny.en step's stream run dry.
+                if (rounds == 0 && spins < 4096) cpu_relax(); else sched_yield();
                 if (++spins >= (1 << 16)) {                    // every few ms: is the stream still alive? (a fault must not hang the caller)
-                    spins = 0;
+                    spins = 0; ++rounds;
                     const hipError_t q = hipStreamQuery(st);
                     if (q == hipSuccess) break;                // drained: the counter is final
                     if (q != hipErrorNotReady) return fail(WLX_ERR_HIP, "decode loop: %s", hipGetErrorString(q));

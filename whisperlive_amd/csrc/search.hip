@@ -426,6 +426,7 @@ __global__ __launch_bounds__(256) void search_update_kernel(const SearchParams* 
                 st.item_done[item] = 1;
                 const int nf = atomicAdd(st.n_finished, 1) + 1;
                 if (nf >= sp.items) { *st.done = 1; __hip_atomic_store(st.done_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+                if (step_no) step_mirror(st, step_no);   // (as search_merge_update3_kernel: every update kernel stores its step number as it ends)
             }
             return;
         }

@@ -51,8 +51,9 @@ def unpack_record(rec: np.ndarray) -> Tuple[List[int], float, float, float]:
 
 def all_gather_records(local: np.ndarray, n_total: int, rank: int, world: int, dist=None, device: str = "cpu") -> np.ndarray:
     """local: int32 [hi-lo, RECORD_INTS] for this rank's block -> int32 [n_total, RECORD_INTS] on every rank.
-    Blocks are padded to the largest block so ONE fixed-size all_gather suffices."""
-    if world == 1 or dist is None:
+    Blocks are padded to the largest block so ONE fixed-size all_gather suffices. With an initialised process group the
+    collective runs at world size 1 too (bench.py --rccl: the RCCL path executed on a one-GPU box); `dist=None` skips it."""
+    if dist is None:
         return local.reshape(n_total, RECORD_INTS)
     import torch
     per = max(shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world))

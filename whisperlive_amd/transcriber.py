@@ -372,29 +372,36 @@ class WhisperModelHIP:
         that asks for more than the thread's slot holds (the reference passes any beam_size through to CTranslate2) gets a wider slot
         (up to the engine's 16 rows per item); the narrower one is closed."""
         rows = max(5, int(rows))
+        # validate BEFORE anything is closed (ADVICE r05): a refused request must leave the thread's slot — resident encoder output,
+        # captured graphs, any EncoderOutput / DeviceFeatures the caller still holds — untouched
+        if rows > 16:
+            raise ValueError(f"beam_size / best_of {rows}: the engine decodes at most 16 rows per audio item")
         s = getattr(self._tls, "slot", None)
+        old = None
         if s is not None and s.sid >= 0 and isinstance(getattr(s, "rows", None), int) and s.rows < rows:
-            with self._slots_lock:
-                self._slots = [x for x in self._slots if x is not s]
-            s.close()
-            s = None
+            old, s = s, None                    # a wider slot is needed: the narrower one is closed once its replacement exists
         if s is None or s.sid < 0:
             me = threading.current_thread()
             with self._slots_lock:
                 self._slots = [x for x in self._slots if x.sid >= 0]
-                s = next((x for x in self._slots if (x._owner is None or not x._owner.is_alive()) and getattr(x, "rows", rows) >= rows), None)
+                s = next((x for x in self._slots if x is not old and (x._owner is None or not x._owner.is_alive()) and getattr(x, "rows", rows) >= rows), None)
                 if s is not None:
                     s._owner = me
             if s is None:
-                if rows > 16:
-                    raise ValueError(f"beam_size / best_of {rows}: the engine decodes at most 16 rows per audio item")
                 # (5 rows per item = the reference's beam_size / best_of; the engine takes up to 64 items x 5 rows = 320 rows per slot)
-                s = self.engine.create_slot(self.max_batch, rows)
+                if self.max_batch * rows > 320:
+                    raise ValueError(f"max_batch {self.max_batch} x {rows} rows per item = {self.max_batch * rows} decoder rows: a slot holds at "
+                                     f"most 320 (64 items x 5 rows); lower beam_size / best_of or max_batch")
+                s = self.engine.create_slot(self.max_batch, rows)        # raises: `old` stays the thread's slot
                 s._enc_generation = 0
                 s._owner = me
                 with self._slots_lock:
                     self._slots.append(s)
             self._tls.slot = s
+            if old is not None:
+                with self._slots_lock:
+                    self._slots = [x for x in self._slots if x is not old]
+                old.close()
         return s
 
     def release_slot(self):

@@ -153,6 +153,8 @@ _default_model: Optional[Callable[[np.ndarray], np.ndarray]] = None      # insta
 _default_weights = None                                                   # Silero weights of the process (loaded once)
 _device_models: Dict[int, Callable[[np.ndarray], np.ndarray]] = {}       # one SileroHIPModel per GPU (clients shard over GPUs)
 _default_lock = threading.Lock()
+_resolve_lock = threading.Lock()        # ONE look-up of the process's Silero weights at a time (it may download for up to 10 s)
+_resolve_failed: Optional[str] = None   # message of a look-up that found nothing: later calls raise at once instead of trying again
 
 
 class VadUnavailable(RuntimeError):
@@ -160,11 +162,12 @@ class VadUnavailable(RuntimeError):
 
 
 def set_default_model(model: Optional[Callable[[np.ndarray], np.ndarray]]):
-    global _default_model, _default_weights
+    global _default_model, _default_weights, _resolve_failed
     with _default_lock:
         _default_model = model
         if model is None:
             _default_weights = None
+            _resolve_failed = None
             for m in _device_models.values():
                 close = getattr(m, "close", None)
                 if close:
@@ -177,7 +180,7 @@ def configure(weights_path: Optional[str] = None, device: int = 0) -> Callable[[
     ``silero_vad.onnx`` the reference downloads (whisper_live/vad.py:112-128) — the latter is converted on the fly by
     ``whisperlive_amd.silero_export`` (stdlib protobuf walk, no onnx / onnxruntime needed). The network runs on the GPU the
     calling transcriber lives on: ``get_default_model(device)`` builds one SileroHIPModel per device from these weights."""
-    global _default_weights
+    global _default_weights, _resolve_failed
     if weights_path is None:
         return get_default_model(device)
     if weights_path.endswith(".npz"):
@@ -187,56 +190,84 @@ def configure(weights_path: Optional[str] = None, device: int = 0) -> Callable[[
         w = check_silero_weights(silero_weights_from_onnx(weights_path))
     with _default_lock:
         _default_weights = w
+        _resolve_failed = None
     logging.info("VAD: Silero weights from %s", weights_path)
     return get_default_model(device)
 
 
+def _find_default_weights():
+    """Where the reference finds its detector (whisperlive_amd/artifacts.py): WLX_SILERO_VAD_NPZ / WLX_SILERO_VAD_ONNX, the reference's
+    own cache file ~/.cache/whisper-live/silero_vad.onnx (whisper_live/vad.py:112-128), the ONNX inside an installed faster-whisper
+    wheel, then a first-use download to that cache path where the deployment allows one (not under WLX_NO_DOWNLOAD / HF_HUB_OFFLINE).
+    A file that is not the Silero network (unknown layer stack) is skipped with a warning, not trusted — that structural check is
+    also what stands between a downloaded file and the model (no checksum is pinned: the reference pins none either). Runs WITHOUT
+    the model lock: a stalled download must not block the VAD look-ups of transcribers whose model already exists."""
+    from . import artifacts
+    cands = artifacts.silero_candidates()
+    if not cands and artifacts.downloads_allowed():
+        got = artifacts.download_silero()
+        if got:
+            cands = [("onnx", got)]
+    for kind, path in cands:
+        try:
+            if kind == "npz":
+                w = load_silero_npz(path)
+            else:
+                from .silero_export import silero_weights_from_onnx
+                w = check_silero_weights(silero_weights_from_onnx(path))
+            logging.info("VAD: Silero (HIP) from %s", path)
+            return w
+        except Exception as e:  # noqa: BLE001 — an unreadable / different file: try the next place
+            logging.warning("VAD: %s is not a usable Silero VAD file (%s: %s)", path, type(e).__name__, e)
+    return None
+
+
 def get_default_model(device: Optional[int] = None) -> Callable[[np.ndarray], np.ndarray]:
-    """The VAD model for a transcriber on GPU `device` (None: WLX_VAD_DEVICE or 0). WLX_SILERO_VAD_NPZ /
-    WLX_SILERO_VAD_ONNX name the weights (the ONNX file is the one the reference downloads). Without them ``use_vad`` FAILS
-    (VadUnavailable) unless WLX_ALLOW_VAD_STANDIN=1 opts into the labelled energy gate — a default deployment must not
+    """The VAD model for a transcriber on GPU `device` (None: WLX_VAD_DEVICE or 0): the model installed with set_default_model /
+    configure, else one SileroHIPModel per device built from the process's Silero weights. The weights are looked up ONCE per
+    process (`_find_default_weights`: environment variables, the reference's cache file, an installed wheel, then a download where
+    allowed), outside the model lock; a look-up that found nothing is remembered, so every later call raises VadUnavailable
+    immediately instead of waiting for another download time-out (configure() / set_default_model(None) reset that). Without
+    weights ``use_vad`` FAILS unless WLX_ALLOW_VAD_STANDIN=1 opts into the labelled energy gate — a default deployment must not
     silently gate audio with something that is not the reference's detector."""
-    global _default_model, _default_weights
+    global _default_model, _default_weights, _resolve_failed
+    dev = int(os.environ.get("WLX_VAD_DEVICE", "0")) if device is None else int(device)
     with _default_lock:
         if _default_model is not None:
             return _default_model
-        dev = int(os.environ.get("WLX_VAD_DEVICE", "0")) if device is None else int(device)
         if dev in _device_models:
             return _device_models[dev]
-        if _default_weights is None:
-            # where the reference finds its detector (whisperlive_amd/artifacts.py): the two variables, the reference's own cache file
-            # ~/.cache/whisper-live/silero_vad.onnx (whisper_live/vad.py:112-128), the ONNX inside an installed faster-whisper wheel,
-            # then a first-use download to that cache path where the deployment allows one. A file that is not the Silero network
-            # (unknown layer stack) is skipped with a warning, not trusted.
-            from . import artifacts
-            cands = artifacts.silero_candidates()
-            if not cands and artifacts.downloads_allowed():
-                got = artifacts.download_silero()
-                if got:
-                    cands = [("onnx", got)]
-            for kind, path in cands:
-                try:
-                    if kind == "npz":
-                        _default_weights = load_silero_npz(path)
+        have = _default_weights is not None
+    if not have:
+        with _resolve_lock:
+            with _default_lock:
+                have, failed = _default_weights is not None, _resolve_failed
+            if not have and failed is None:
+                w = _find_default_weights()
+                with _default_lock:
+                    if w is not None:
+                        _default_weights = w
                     else:
-                        from .silero_export import silero_weights_from_onnx
-                        _default_weights = check_silero_weights(silero_weights_from_onnx(path))
-                    logging.info("VAD: Silero (HIP) from %s", path)
-                    break
-                except Exception as e:  # noqa: BLE001 — an unreadable / different file: try the next place
-                    logging.warning("VAD: %s is not a usable Silero VAD file (%s: %s)", path, type(e).__name__, e)
-            if _default_weights is None and os.environ.get("WLX_ALLOW_VAD_STANDIN") == "1":
-                logging.warning("VAD: WLX_ALLOW_VAD_STANDIN=1 — using the energy-gate stand-in, which is NOT the reference's "
-                                "speech detector (set WLX_SILERO_VAD_ONNX / WLX_SILERO_VAD_NPZ or pass --vad_weights)")
-                _default_model = EnergyGateModel()
-                return _default_model
-            if _default_weights is None:
-                raise VadUnavailable(
-                    "use_vad needs Silero VAD weights: none found in WLX_SILERO_VAD_ONNX / WLX_SILERO_VAD_NPZ, "
-                    "~/.cache/whisper-live/silero_vad.onnx (the file the reference downloads) or an installed faster_whisper / silero_vad "
-                    "package, and no download was possible; pass --vad_weights to the server, or opt into the energy-gate stand-in with "
-                    "WLX_ALLOW_VAD_STANDIN=1")
-        _device_models[dev] = SileroHIPModel(_default_weights, dev)
+                        _resolve_failed = failed = (
+                            "use_vad needs Silero VAD weights: none found in WLX_SILERO_VAD_ONNX / WLX_SILERO_VAD_NPZ, "
+                            "~/.cache/whisper-live/silero_vad.onnx (the file the reference downloads) or an installed faster_whisper / "
+                            "silero_vad package, and no download was possible; pass --vad_weights to the server, or opt into the "
+                            "energy-gate stand-in with WLX_ALLOW_VAD_STANDIN=1")
+                    have = w is not None
+        if not have:
+            if os.environ.get("WLX_ALLOW_VAD_STANDIN") == "1":
+                with _default_lock:
+                    if _default_model is None:
+                        logging.warning("VAD: WLX_ALLOW_VAD_STANDIN=1 — using the energy-gate stand-in, which is NOT the reference's "
+                                        "speech detector (set WLX_SILERO_VAD_ONNX / WLX_SILERO_VAD_NPZ or pass --vad_weights)")
+                        _default_model = EnergyGateModel()
+                    return _default_model
+            raise VadUnavailable(failed)
+    with _default_lock:
+        if _default_model is not None:
+            return _default_model
+        if dev not in _device_models:
+            _device_models[dev] = SileroHIPModel(_default_weights, dev)
         return _device_models[dev]
 
 
