@@ -55,9 +55,11 @@ def test_cpu_baseline_leg_on_a_tiny_model():
     pcm = olm.speech_like_pcm(30.0, seed=1)
     aff = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else None
     base, toks = bench.cpu_baseline(spec, w, pcm, ids, 6, 6, threads=2, repeats=3)
-    assert base["kind"] == "port" and base["runs"] == 3 and len(base["window_s_all_runs"]) == 3 and base["cores"] == 2
-    assert base["value"] == pytest.approx(30.0 / sorted(base["window_s_all_runs"])[1], rel=2e-2)      # the MEDIAN run
-    assert "median of 3 runs on 2 pinned threads" in base["sample"] and "measured in full" in base["sample"] and len(toks) == 6
+    # 3 runs, more (at most 6) while the last three disagree by more than 15 %; the figure is the median of the LAST three
+    assert base["kind"] == "port" and 3 <= base["runs"] <= 6 and len(base["window_s_all_runs"]) == base["runs"] and base["cores"] == 2
+    assert base["value"] == pytest.approx(30.0 / sorted(base["window_s_all_runs"][-3:])[1], rel=2e-2)      # the MEDIAN of the last three
+    assert base["runs"] == 6 or base["spread"] <= 0.15
+    assert f"median of the last 3 of {base['runs']} runs on 2 pinned threads" in base["sample"] and "measured in full" in base["sample"] and len(toks) == 6
     q8, toks8 = bench.cpu_baseline(spec, w, pcm, ids, 3, 6, threads=2, int8="fbgemm")
     assert q8["kind"] == "port-int8" and "scaled to 6" in q8["sample"] and len(toks8) == 3
     if aff is not None:
