@@ -103,9 +103,10 @@ int dec_gemv_slab_split(int M, int K, int N);
 
 // causal self-attention over the KV cache, one wave per (row, head)
 // ident_ancestry: ancrow[r] == r for every row of this pass (decode steps), see dec_self_attn2_kernel
+// long_ctx: some row of this pass attends to more than 256 positions (twice the waves per (row, head): one block of 64 positions each)
 void launch_dec_self_attn(const half_t* q, long ldq, const half_t* Kc, const half_t* Vc, long cache_row_stride,
                           int d, int H, const RowTables& rt, int rows, half_t* out, long ldo,
-                          const int* done, bool ident_ancestry, hipStream_t s);
+                          const int* done, bool ident_ancestry, bool long_ctx, hipStream_t s);
 // cross-attention of R rows per item against the item's 1500 encoder keys, split over keys; groups of R (<=16) rows,
 // group_item[g] = audio item whose K/V group g attends to. Kp / Vp: tile-packed cross K / V of ONE decoder layer
 // (gemm.hip GEMM_CROSS_KV), item_stride halfs per item.

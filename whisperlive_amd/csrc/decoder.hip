@@ -1596,24 +1596,28 @@ void launch_dec_gemv(const GemvParams& p_any, hipStream_t s) {
 #ifndef SA_NW
 #define SA_NW 4          // -DSA_NW=1 (whisperlive_amd/_lib.py build_variant) = the one-wave form, for A/B
 #endif
-template <bool IDENT>
-__global__ __launch_bounds__(64 * SA_NW) void dec_self_attn2_kernel(const half_t* __restrict__ q, long ldq,
+// Round 6: NW is a template parameter. Decode steps and prefill passes whose positions stay below 64 SA_NW (256) launch SA_NW waves as
+// before; past that a wave of the 4-wave form walks a SECOND block behind its first (two dependent trips: a step at positions 257..320
+// cost 405 us against 389 us at 200), so those launches take 2 SA_NW waves — one block of 64 positions per wave up to the 448-position
+// context. For histories of <= 64 SA_NW positions the two forms are bit-identical (same blocks per wave, same merge order).
+template <bool IDENT, int NW>
+__global__ __launch_bounds__(64 * NW) void dec_self_attn2_kernel(const half_t* __restrict__ q, long ldq,
                                                                     const half_t* __restrict__ Kc,
                                                                     const half_t* __restrict__ Vc, long crs, int d,
                                                                     const int* __restrict__ pos,
                                                                     const int* __restrict__ ancrow,
                                                                     const short* __restrict__ anc,
                                                                     half_t* __restrict__ out, long ldo WLX_TR_PARAM) {
-    __shared__ float prob_s[SA_NW][64];
-    __shared__ int crow_s[SA_NW][64];
-    __shared__ float part_s[SA_NW][8][64];
-    __shared__ float ml_s[SA_NW][2];
+    __shared__ float prob_s[NW][64];
+    __shared__ int crow_s[NW][64];
+    __shared__ float part_s[NW][8][64];
+    __shared__ float ml_s[NW][2];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = blockIdx.x, h = blockIdx.y;
     WLX_TR_BEGIN();
     // the cache rows of this wave's FIRST block, requested together with the row's position, before anything depends on either
-    // (w * 64 + lane < 64 SA_NW <= 448: always inside the ancestry row, whatever the history length turns out to be) — without it
+    // (w * 64 + lane < 64 NW <= 512; the ancestry table has one spare row behind its last: inside the allocation, whatever the history length turns out to be) — without it
     // the waves of the later blocks paid a second dependent round trip (position -> ancestry -> K / V)
     const short* ar = anc + (long)(IDENT ? r : ancrow[r]) * WLX_T_TEXT;
     int cr0 = 0;
@@ -1633,7 +1637,7 @@ __global__ __launch_bounds__(64 * SA_NW) void dec_self_attn2_kernel(const half_t
     float mrun = WLX_NEG_INF, lrun = 0.f;
     WLX_TR_MARK(1);
 #pragma unroll 1
-    for (int p0 = w * 64; p0 < len; p0 += 64 * SA_NW) {
+    for (int p0 = w * 64; p0 < len; p0 += 64 * NW) {
         const int p = p0 + lane;
         const bool ok = p < len;
         int cr;
@@ -1690,7 +1694,7 @@ __global__ __launch_bounds__(64 * SA_NW) void dec_self_attn2_kernel(const half_t
         if (lane == 0) { ml_s[w][0] = mrun; ml_s[w][1] = lrun; }
         __syncthreads();                                    // the waves that left at the top do not count
         if (w == 0) {
-            const int nw = nblk < SA_NW ? nblk : SA_NW;
+            const int nw = nblk < NW ? nblk : NW;
             float m = ml_s[0][0];
             for (int k = 1; k < nw; ++k) m = fmaxf(m, ml_s[k][0]);
             float L = 0.f, O = 0.f;
@@ -1707,14 +1711,13 @@ __global__ __launch_bounds__(64 * SA_NW) void dec_self_attn2_kernel(const half_t
 }
 
 void launch_dec_self_attn(const half_t* q, long ldq, const half_t* Kc, const half_t* Vc, long crs, int d, int H,
-                          const RowTables& rt, int rows, half_t* out, long ldo, const int* done, bool ident_ancestry, hipStream_t s) {
+                          const RowTables& rt, int rows, half_t* out, long ldo, const int* done, bool ident_ancestry, bool long_ctx, hipStream_t s) {
     (void)done;   // a step that runs after the search raised `done` only rewrites scratch (engine.hip decoder_pass)
-    if (ident_ancestry)
-        hipLaunchKernelGGL(dec_self_attn2_kernel<true>, dim3(rows, H), dim3(64 * SA_NW), 0, s, q, ldq, Kc, Vc, crs, d, rt.pos,
-                           rt.ancrow, rt.anc, out, ldo WLX_TR_ARG("self_attn"));
-    else
-        hipLaunchKernelGGL(dec_self_attn2_kernel<false>, dim3(rows, H), dim3(64 * SA_NW), 0, s, q, ldq, Kc, Vc, crs, d, rt.pos,
-                           rt.ancrow, rt.anc, out, ldo WLX_TR_ARG("self_attn"));
+#define WLX_SA_GO(ID_, NW_) hipLaunchKernelGGL((dec_self_attn2_kernel<ID_, NW_>), dim3(rows, H), dim3(64 * NW_), 0, s, q, ldq, Kc, Vc, crs, d, rt.pos, \
+                                                rt.ancrow, rt.anc, out, ldo WLX_TR_ARG("self_attn"))
+    if (long_ctx && SA_NW > 1) { if (ident_ancestry) WLX_SA_GO(true, 2 * SA_NW); else WLX_SA_GO(false, 2 * SA_NW); }
+    else { if (ident_ancestry) WLX_SA_GO(true, SA_NW); else WLX_SA_GO(false, SA_NW); }
+#undef WLX_SA_GO
 }
 
 // ------------------------------------------------------------------ decode cross-attention (flash-decoding split over keys)
