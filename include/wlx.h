@@ -239,6 +239,38 @@ void    wlx_vad_destroy(wlx_vad* v);
 int32_t wlx_vad_probs(wlx_vad* v, const float* pcm, int64_t n, float* probs_out, int32_t cap,
                       int32_t* n_windows_out, float* device_ms_out);
 
+/* ---- device-resident PCM ring of ONE client stream (round 6; PRODUCT entry points of the streaming path) ----
+ * The device-side mirror of the session buffer ServeClientBase keeps on the host (whisper_live/backend/base.py:173-234:
+ * `frames_np`, the 45 s cap / 30 s trim of add_frames :191-198, the chunk taken by get_audio_chunk_for_processing :219-234).
+ * Every packet a client sends crosses PCIe ONCE — wlx_ring_append — and everything that reads audio afterwards reads HBM:
+ * the VAD gate (wlx_vad_probs_resident) and the log-mel front end, whose PCM -> LDS loads walk the list of speech ranges the
+ * gate kept (wlx_logmel_ring: replaces faster_whisper.vad.collect_chunks + np.concatenate + a second upload,
+ * transcriber_faster_whisper.py:836-838,862). A ring is independent of slots: the socket thread appends while the
+ * transcription thread reads; calls on one ring are serialised by the library.
+ * Sample positions are ABSOLUTE stream positions (sample 0 = the first sample ever appended): a trim moves `base`,
+ * never the positions a caller already holds. A range that has been trimmed away fails with WLX_ERR_STATE. */
+typedef struct wlx_ring wlx_ring;
+int32_t wlx_ring_create(wlx_engine* e, int64_t capacity_samples /* 0: 64 s */, wlx_ring** out);
+void    wlx_ring_destroy(wlx_ring* r);
+/* add_frames (base.py:173-234): if more than `max_resident` samples are resident, the OLDEST `trim` samples are dropped
+ * first (45 s / 30 s in the reference: pass 720000 / 480000; max_resident <= 0 disables the rule), then the `n` host
+ * samples are appended. Outputs (nullable): samples dropped by this call, first resident position, resident count.
+ * The copy is complete on return. */
+int32_t wlx_ring_append(wlx_ring* r, const float* samples, int64_t n, int64_t max_resident, int64_t trim,
+                        int64_t* dropped_out, int64_t* base_out, int64_t* resident_out);
+int32_t wlx_ring_state(wlx_ring* r, int64_t* base_out, int64_t* resident_out);
+/* wlx_vad_probs on ring samples [start, start + n): no host-to-device copy. Same contract otherwise (zero initial
+ * state, ceil(n / 512) windows, the last one zero-padded) plus `extra_zero_windows` all-zero windows behind them
+ * (faster_whisper.vad pads n to the NEXT multiple of 512 — a whole window of zeros when n already is one — and the
+ * host side asks for the same count, so the two paths segment identically). `v` and `r` must live on the same device. */
+int32_t wlx_vad_probs_resident(wlx_vad* v, wlx_ring* r, int64_t start, int64_t n, int32_t extra_zero_windows,
+                               float* probs_out, int32_t cap, int32_t* n_windows_out, float* device_ms_out);
+/* log-mel of the CONCATENATION of `n_ranges` ring ranges [ranges[2 i], ranges[2 i + 1]) (absolute positions, ascending,
+ * <= 256 of them) into item `item` of the slot: identical features to wlx_logmel on the concatenated samples. The launch
+ * is issued at once (it reads the ring, which the socket thread may trim later). */
+int32_t wlx_logmel_ring(wlx_engine* e, int32_t slot, int32_t item, wlx_ring* r, const int64_t* ranges, int32_t n_ranges,
+                        int32_t* n_frames_out);
+
 /* ==== everything below: TEST / PROFILING hooks (used only by tests/, scripts/ and bench.py's roofline leg; not part of
  * the drop-in boundary; the product entry points end here) ================================================================= */
 /* next-token logits [rows, vocab] of the last decoder step executed on the slot */

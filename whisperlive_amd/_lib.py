@@ -19,6 +19,7 @@ EXPORTS = [
     "wlx_slot_create", "wlx_slot_destroy", "wlx_logmel", "wlx_pcm_put", "wlx_logmel_resident", "wlx_features_get", "wlx_features_set", "wlx_encode",
     "wlx_encoder_output_get", "wlx_generate", "wlx_generate_ex", "wlx_detect_language", "wlx_align", "wlx_timings_get", "wlx_sync",
     "wlx_vad_create", "wlx_vad_destroy", "wlx_vad_probs",
+    "wlx_ring_create", "wlx_ring_destroy", "wlx_ring_append", "wlx_ring_state", "wlx_vad_probs_resident", "wlx_logmel_ring",
     "wlx_debug_logits_get", "wlx_debug_decode_logits", "wlx_debug_search", "wlx_debug_time_decode_step", "wlx_debug_profile_step", "wlx_debug_trace_step",
 ]
 
@@ -221,6 +222,14 @@ def load() -> C.CDLL:
     lib.wlx_vad_destroy.argtypes = [vp]
     lib.wlx_vad_destroy.restype = None
     lib.wlx_vad_probs.argtypes = [vp, f32p, i64, f32p, i32, i32p, f32p]
+    i64p = C.POINTER(C.c_int64)
+    lib.wlx_ring_create.argtypes = [vp, i64, C.POINTER(vp)]
+    lib.wlx_ring_destroy.argtypes = [vp]
+    lib.wlx_ring_destroy.restype = None
+    lib.wlx_ring_append.argtypes = [vp, f32p, i64, i64, i64, i64p, i64p, i64p]
+    lib.wlx_ring_state.argtypes = [vp, i64p, i64p]
+    lib.wlx_vad_probs_resident.argtypes = [vp, vp, i64, i64, i32, f32p, i32, i32p, f32p]
+    lib.wlx_logmel_ring.argtypes = [vp, i32, i32, vp, i64p, i32, i32p]
     lib.wlx_debug_logits_get.argtypes = [vp, i32, f32p, i32, i64]
     lib.wlx_debug_decode_logits.argtypes = [vp, i32, i32p, i32, f32p]
     lib.wlx_debug_search.argtypes = [vp, i32, f32p, i32, i32p, i32, C.POINTER(wlx_gen_opts), i32p, i32, i32p, f32p]
@@ -229,7 +238,7 @@ def load() -> C.CDLL:
     lib.wlx_debug_trace_step.argtypes = [vp, i32, i32, i32, i32, C.POINTER(C.c_uint64), i64, C.c_char_p, i32p]
     for name in EXPORTS:
         fn = getattr(lib, name)
-        if name not in ("wlx_last_error", "wlx_engine_destroy", "wlx_vad_destroy"):
+        if name not in ("wlx_last_error", "wlx_engine_destroy", "wlx_vad_destroy", "wlx_ring_destroy"):
             fn.restype = i32
     if lib.wlx_abi_version() != 1:
         raise WlxError("libwlx.so ABI version mismatch")

@@ -54,6 +54,7 @@ struct Slot {
     bool en_pending = false;
     bool lm_pending = false;
     std::vector<int> lm_items;          // items whose log-mel was requested and not launched yet (engine.hip flush_logmel)
+    bool long_ctx = false;              // the pass being issued has rows that attend to more than 256 positions (decoder.hip dec_self_attn2_kernel: twice the waves); part of the step-graph key
     bool busy_variant = false;          // the decode launches of this slot use the work-saving shapes (three or more live slots on the device; engine.hip device_is_busy)
     std::vector<void*> allocs;
     // features
@@ -62,6 +63,7 @@ struct Slot {
     std::vector<int> nframes;
     std::vector<int64_t> npcm;                       // samples resident per item
     unsigned* gmax = nullptr;
+    long long* d_rng = nullptr;                      // [2 * WLX_LM_MAXRANGES] range table of the last wlx_logmel_ring
     // encoder
     half_t *featT = nullptr, *h1 = nullptr, *ln = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr,
            *attn = nullptr, *h2 = nullptr, *enc16 = nullptr;
@@ -106,6 +108,20 @@ struct Slot {
     int* d_align_tgt = nullptr; float* d_align_prob = nullptr;   // [448]
 };
 
+// Device-resident PCM ring of one client stream (include/wlx.h: wlx_ring_*; engine.hip). Samples [base, base + resident) of the
+// stream live contiguously at buf[0 .. resident): a trim moves the survivors to the front (once per 30 s of audio: <= 1 MB device to
+// device), so every reader sees plain contiguous memory. Writers: the socket thread (append / trim). Readers: kernels of the VAD
+// object's stream and of a slot's stream; `mu` serialises the calls, `last_read` (recorded on the reader's stream behind its launch)
+// is what a trim waits for before it moves data under a reader that was launched but has not run yet.
+struct Ring {
+    std::mutex mu;
+    int device = 0;
+    float* buf = nullptr; size_t cap = 0;
+    int64_t base = 0, resident = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t last_read = nullptr; bool read_pending = false;
+};
+
 struct Engine {
     wlx_spec spec{};
     int device = 0;
@@ -128,3 +144,4 @@ struct Engine {
 }  // namespace wlx
 
 struct wlx_engine : public wlx::Engine {};
+struct wlx_ring : public wlx::Ring {};

@@ -648,6 +648,7 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         CK(hipEventCreate(&s->ev_en0)); CK(hipEventCreate(&s->ev_en1));
         CKR(slot_grow_audio(e, s, 480000));
         CKR(dalloc(s->allocs, &s->gmax, (size_t)B));
+        CKR(dalloc(s->allocs, &s->d_rng, (size_t)2 * WLX_LM_MAXRANGES));
         s->featT_stride = (long)(WLX_N_FRAMES + 2) * sp.n_mels + 64;
         s->h1_stride = (long)(WLX_N_FRAMES + 2) * d;
         CKR(dalloc(s->allocs, &s->featT, (size_t)B * s->featT_stride));
@@ -700,7 +701,7 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         CKR(dalloc(s->allocs, &s->d_ancrow, (size_t)RC));
         CKR(dalloc(s->allocs, &s->d_group_item, (size_t)RC));
         const int CR = std::max(s->cache_rows, RC);
-        CKR(dalloc(s->allocs, &s->d_anc, (size_t)CR * WLX_T_TEXT));
+        CKR(dalloc(s->allocs, &s->d_anc, (size_t)(CR + 1) * WLX_T_TEXT));    // (+1 row: the 8-wave self-attention requests ancestry entries up to 511 of a row before it knows the length)
         CKR(dalloc(s->allocs, &s->d_intok, (size_t)CR * WLX_T_TEXT));
         SearchState& st = s->st;
         CKR(dalloc(s->allocs, &st.step, 1)); CKR(dalloc(s->allocs, &st.done, 1)); CKR(dalloc(s->allocs, &st.n_finished, 1));
@@ -843,6 +844,133 @@ extern "C" int32_t wlx_pcm_put(wlx_engine* e, int32_t slot, int32_t item, const 
     CK(hipMemcpyAsync(dp, pcm, (size_t)n * sizeof(float), hipMemcpyHostToDevice, s->stream));
     CK(hipStreamSynchronize(s->stream));   // the caller's PCM buffer may be reused after return
     s->npcm[item] = n;
+    return WLX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PCM ring (include/wlx.h): whisper_live/backend/base.py:173-234 on the device
+extern "C" int32_t wlx_ring_create(wlx_engine* e, int64_t capacity_samples, wlx_ring** out) {
+    if (!e || !out) return fail(WLX_ERR_ARG, "null argument");
+    if (capacity_samples < 0 || capacity_samples > 16000LL * 3600) return fail(WLX_ERR_ARG, "ring capacity out of range");
+    CK(hipSetDevice(e->device));
+    wlx_ring* r = new wlx_ring();
+    r->device = e->device;
+    r->cap = (size_t)(capacity_samples > 0 ? capacity_samples : 16000LL * 64);
+    hipError_t he = hipMalloc(reinterpret_cast<void**>(&r->buf), r->cap * sizeof(float));
+    if (he == hipSuccess) he = hipStreamCreateWithFlags(&r->stream, hipStreamNonBlocking);
+    if (he == hipSuccess) he = hipEventCreateWithFlags(&r->last_read, hipEventDisableTiming);
+    if (he != hipSuccess) {
+        (void)hipGetLastError();
+        wlx_ring_destroy(r);
+        return fail(WLX_ERR_HIP, "wlx_ring_create: %s", hipGetErrorString(he));
+    }
+    *out = r;
+    return WLX_OK;
+}
+
+extern "C" void wlx_ring_destroy(wlx_ring* r) {
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    if (r->read_pending && r->last_read) (void)hipEventSynchronize(r->last_read);
+    if (r->stream) { (void)hipStreamSynchronize(r->stream); (void)hipStreamDestroy(r->stream); }
+    if (r->last_read) (void)hipEventDestroy(r->last_read);
+    if (r->buf) (void)hipFree(r->buf);
+    delete r;
+}
+
+// readers launched but possibly not run yet: wait for them before data moves under them
+static int ring_wait_readers(Ring* r) {
+    if (r->read_pending) { CK(hipEventSynchronize(r->last_read)); r->read_pending = false; }
+    return WLX_OK;
+}
+
+extern "C" int32_t wlx_ring_append(wlx_ring* r, const float* samples, int64_t n, int64_t max_resident, int64_t trim,
+                                   int64_t* dropped_out, int64_t* base_out, int64_t* resident_out) {
+    if (!r || n < 0 || (n > 0 && !samples)) return fail(WLX_ERR_ARG, "wlx_ring_append: bad argument");
+    if (n > 16000LL * 3600) return fail(WLX_ERR_ARG, "audio chunk too long");
+    std::lock_guard<std::mutex> lk(r->mu);
+    CK(hipSetDevice(r->device));
+    int64_t dropped = 0;
+    if (max_resident > 0 && trim > 0 && r->resident > max_resident) {
+        // add_frames (base.py:191-198): the buffer is past its cap — the oldest `trim` samples go, the rest moves to the front
+        dropped = std::min<int64_t>(trim, r->resident);
+        const int64_t keep = r->resident - dropped;
+        CKR(ring_wait_readers(r));
+        for (int64_t done = 0; done < keep; done += dropped) {                      // pieces of <= `dropped` samples: source and destination never overlap
+            const int64_t m = std::min<int64_t>(dropped, keep - done);
+            CK(hipMemcpyAsync(r->buf + done, r->buf + dropped + done, (size_t)m * sizeof(float), hipMemcpyDeviceToDevice, r->stream));
+        }
+        r->base += dropped;
+        r->resident = keep;
+    }
+    if ((size_t)(r->resident + n) > r->cap) {                                      // a packet larger than the head-room: grow (rare)
+        size_t cap = r->cap;
+        while (cap < (size_t)(r->resident + n)) cap *= 2;
+        float* nb = nullptr;
+        CK(hipMalloc(reinterpret_cast<void**>(&nb), cap * sizeof(float)));
+        CKR(ring_wait_readers(r));
+        CK(hipMemcpyAsync(nb, r->buf, (size_t)r->resident * sizeof(float), hipMemcpyDeviceToDevice, r->stream));
+        CK(hipStreamSynchronize(r->stream));
+        CK(hipFree(r->buf));
+        r->buf = nb; r->cap = cap;
+    }
+    if (n > 0) CK(hipMemcpyAsync(r->buf + r->resident, samples, (size_t)n * sizeof(float), hipMemcpyHostToDevice, r->stream));
+    CK(hipStreamSynchronize(r->stream));            // the caller's buffer may be reused; readers launched after this return see the samples
+    r->resident += n;
+    if (dropped_out) *dropped_out = dropped;
+    if (base_out) *base_out = r->base;
+    if (resident_out) *resident_out = r->resident;
+    return WLX_OK;
+}
+
+extern "C" int32_t wlx_ring_state(wlx_ring* r, int64_t* base_out, int64_t* resident_out) {
+    if (!r) return fail(WLX_ERR_ARG, "null ring");
+    std::lock_guard<std::mutex> lk(r->mu);
+    if (base_out) *base_out = r->base;
+    if (resident_out) *resident_out = r->resident;
+    return WLX_OK;
+}
+
+extern "C" int32_t wlx_logmel_ring(wlx_engine* e, int32_t slot, int32_t item, wlx_ring* r, const int64_t* ranges, int32_t n_ranges,
+                                   int32_t* n_frames_out) {
+    SlotGuard sg_;
+    CKR(slot_acquire(e, slot, sg_));
+    Slot* s = sg_.s;
+    if (!r || !ranges || n_ranges < 1) return fail(WLX_ERR_ARG, "wlx_logmel_ring: bad argument");
+    if (n_ranges > WLX_LM_MAXRANGES) return fail(WLX_ERR_ARG, "wlx_logmel_ring: more than %d ranges", WLX_LM_MAXRANGES);
+    if (item < 0 || item >= s->B) return fail(WLX_ERR_ARG, "bad item %d", item);
+    if (r->device != e->device) return fail(WLX_ERR_ARG, "wlx_logmel_ring: the ring lives on device %d, the engine on %d", r->device, e->device);
+    CK(hipSetDevice(e->device));
+    std::lock_guard<std::mutex> lk(r->mu);
+    long long tab[2 * WLX_LM_MAXRANGES];
+    int64_t total = 0, prev_end = r->base;
+    for (int i = 0; i < n_ranges; ++i) {
+        const int64_t a = ranges[2 * i], b = ranges[2 * i + 1];
+        if (a < prev_end || b <= a) return fail(a < r->base ? WLX_ERR_STATE : WLX_ERR_ARG, "wlx_logmel_ring: range %d = [%lld, %lld) is empty, out of order or no longer resident (ring starts at %lld)",
+                                                i, (long long)a, (long long)b, (long long)r->base);
+        if (b > r->base + r->resident) return fail(WLX_ERR_STATE, "wlx_logmel_ring: range %d ends at %lld, the ring at %lld", i, (long long)b, (long long)(r->base + r->resident));
+        tab[2 * i] = a - r->base; tab[2 * i + 1] = total;
+        total += b - a;
+        prev_end = b;
+    }
+    if (total > 16000LL * 3600) return fail(WLX_ERR_ARG, "audio chunk too long");
+    CKR(flush_logmel(e, s));                         // requests recorded earlier go out first (one of them may be this item's)
+    CKR(slot_grow_audio(e, s, (size_t)total));       // the feature buffers are sized with the audio buffers
+    CK(hipMemcpyAsync(s->d_rng, tab, (size_t)n_ranges * 2 * sizeof(long long), hipMemcpyHostToDevice, s->stream));   // (pageable source: staged before the call returns)
+    const int T = (int)((total + 160) / 160);
+    LogmelBatch lb{};
+    lb.n_items = 1; lb.pcm[0] = r->buf; lb.n[0] = (long)total; lb.feats[0] = s->feats + (size_t)item * e->spec.n_mels * s->feat_ld; lb.T[0] = T;
+    lb.gmax[0] = s->gmax + item; lb.rng[0] = s->d_rng; lb.nr[0] = n_ranges;
+    CK(hipEventRecord(s->ev_lm0, s->stream));
+    launch_logmel_batch(lb, e->spec.n_mels, e->lm, s->feat_ld, s->stream);
+    CK(hipGetLastError());
+    CK(hipEventRecord(s->ev_lm1, s->stream));
+    CK(hipEventRecord(r->last_read, s->stream));     // a later trim waits for this launch before it moves the samples
+    r->read_pending = true;
+    s->lm_pending = true;
+    s->npcm[item] = 0;                               // the item's own PCM buffer does not hold this audio (wlx_logmel_resident would be wrong)
+    s->nframes[item] = T;
+    if (n_frames_out) *n_frames_out = T;
     return WLX_OK;
 }
 
@@ -1113,7 +1241,7 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
             GemvParams pq = qkv_params(l, (l == 0 && fold_embed) ? GEMV_X_EMBED : (slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN));
             pgemv(s.base, pq);
         }
-        plaunch(s.base, "dec_self_attn2_kernel", 4.0 * rows * d * (s->prof ? s->prof->t + 1 : 1), [&] { launch_dec_self_attn(s.qd, d, kc, vc, crs, d, H, rt, rows, s.attnd, d, done, s->anc_ident, st); });
+        plaunch(s.base, "dec_self_attn2_kernel", 4.0 * rows * d * (s->prof ? s->prof->t + 1 : 1), [&] { launch_dec_self_attn(s.qd, d, kc, vc, crs, d, H, rt, rows, s.attnd, d, done, s->anc_ident, s->long_ctx, st); });
         pgemv(s.base, oproj_params(l, slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN));
         slabs_pending = false;
         GemvParams p{};
@@ -1227,6 +1355,7 @@ static int prefill_tokens(Engine* e, Slot* s, int item, int crow, const int* tok
         CK(hipMemcpyAsync(b.d_ancrow, h + 3 * rows, rows * 4, hipMemcpyHostToDevice, s->stream));
         CK(hipMemcpyAsync(b.d_group_item, h + 4 * rows, groups * 4, hipMemcpyHostToDevice, s->stream));
         s->anc_ident = false;                                       // every row reads its history through the prompt's cache row
+        s->long_ctx = pos0 + rows > 256;
         decoder_pass(e, s, rows, 16, groups, false, false, &b);
         CK(hipGetLastError());
         if (nsp_index >= 0 && nsp_index < rows) {
@@ -1254,6 +1383,7 @@ static int prefill_tokens(Engine* e, Slot* s, int item, int crow, const int* tok
         CKR(upload_rows(s, tk, ps, ca, an, gi));
         const bool want_nsp = nsp_index >= c0 && nsp_index < c0 + rows;
         const bool lg = (logits_host != nullptr) || want_nsp;
+        s->long_ctx = pos0 + c0 + rows > 256;
         decoder_pass(e, s, rows, 16, groups, lg, false);
         CK(hipGetLastError());
         if (logits_host) {
@@ -1291,7 +1421,7 @@ static void launch_search(Engine* e, Slot* s, int rows, int groups, bool samplin
 
 static int get_step_graph(Engine* e, Slot* s, int rows, int R, int groups, bool sampling, hipGraphExec_t* out) {
     s->busy_variant = device_is_busy(s);
-    StepGraphKey key{rows, R, groups * 4 + (s->busy_variant ? 2 : 0) + (sampling ? 1 : 0)};
+    StepGraphKey key{rows, R, groups * 8 + (s->long_ctx ? 4 : 0) + (s->busy_variant ? 2 : 0) + (sampling ? 1 : 0)};
     auto it = s->graphs.find(key);
     if (it != s->graphs.end()) { *out = it->second; return WLX_OK; }
     hipGraph_t graph;
@@ -1327,7 +1457,10 @@ static int get_step_graph(Engine* e, Slot* s, int rows, int R, int groups, bool 
     return WLX_OK;
 }
 
-static int run_step(Engine* e, Slot* s, int rows, int R, int groups, bool sampling) {
+// max_pos: the largest position any row of this step sits at (its self-attention covers max_pos + 1 positions): past 256 the step's
+// self-attention launches take twice the waves (decoder.hip dec_self_attn2_kernel) — a second captured graph per (rows, R, groups)
+static int run_step(Engine* e, Slot* s, int rows, int R, int groups, bool sampling, int max_pos) {
+    s->long_ctx = max_pos >= 256;
     if (e->use_graph) {
         hipGraphExec_t exec;
         CKR(get_step_graph(e, s, rows, R, groups, sampling, &exec));
@@ -1411,10 +1544,11 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
     const int R = sampling ? std::max(1, o->num_hypotheses) : o->beam_size;
     const int rows = batch * R, V = e->spec.vocab;
     hipStream_t st = s->stream;
-    int max_steps = 0;
+    int max_steps = 0, max_plen = 0;
     bool apply_ts = true;
     for (int b = 0; b < batch; ++b) {
         const int pl = plens[b];
+        max_plen = std::max(max_plen, pl);
         if (pl < 1 || pl >= o->max_length) return fail(WLX_ERR_ARG, "item %d: prompt length %d vs max_length %d", b, pl, o->max_length);
         const int32_t* pr = prompts + (size_t)b * pstride;
         for (int i = 0; i < pl; ++i) {
@@ -1503,6 +1637,7 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
                 CK(hipMemcpyAsync(pb.d_ancrow, h + 3 * prow, prow * 4, hipMemcpyHostToDevice, st));
                 CK(hipMemcpyAsync(pb.d_group_item, h + 4 * prow, nb * 4, hipMemcpyHostToDevice, st));
                 s->anc_ident = false;
+                s->long_ctx = false;                                    // (joint prefill: prompts of <= 16 rows)
                 decoder_pass(e, s, prow, 16, nb, false, false, &pb);
                 CK(hipGetLastError());
                 for (int bi = 0; bi < nb; ++bi) {
@@ -1563,7 +1698,7 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
             CK(hipGetLastError());
         } else {
             const double ta = gen_trace ? now_us() : 0.0;
-            CKR(run_step(e, s, rows, R, batch, sampling));
+            CKR(run_step(e, s, rows, R, batch, sampling, max_plen - 1 + step));
             if (gen_trace) tg_launch += now_us() - ta;
         }
         ++steps_run;
@@ -1706,6 +1841,7 @@ extern "C" int32_t wlx_detect_language(wlx_engine* e, int32_t slot, int32_t batc
     for (int b = 0; b < batch; ++b) { ca[b] = an[b] = b * s->R; gi[b] = b; anc[(size_t)(b * s->R) * WLX_T_TEXT] = (short)(b * s->R); }
     CKR(set_anc_rows(s, anc, 0, s->cache_rows));
     CKR(upload_rows(s, tk, ps, ca, an, gi));
+    s->long_ctx = false;
     decoder_pass(e, s, batch, 1, batch, true, false);
     CK(hipMemcpyAsync(s->d_lang_ids, lang_ids, (size_t)n_lang * 4, hipMemcpyHostToDevice, st));
     launch_lang_probs(s->logits, s->ldl, batch, s->d_lang_ids, n_lang, s->d_probs, st);
@@ -1856,6 +1992,7 @@ extern "C" int32_t wlx_align(wlx_engine* e, int32_t slot, int32_t item, const in
         rc = upload_rows(s, tk, ps, ca, an, gi);
         if (rc != WLX_OK) break;
         cap.row0 = c0;
+        s->long_ctx = c0 + rows > 256;
         decoder_pass(e, s, rows, 16, groups, true, false);
         if (hipMemcpyAsync(s->d_align_tgt, tgt.data(), (size_t)rows * 4, hipMemcpyHostToDevice, st) != hipSuccess) { rc = WLX_ERR_HIP; break; }
         launch_token_prob_rows(s->logits, s->ldl, eot, rows, s->d_align_tgt, s->d_align_prob, st);
@@ -1917,6 +2054,7 @@ extern "C" int32_t wlx_debug_time_decode_step(wlx_engine* e, int32_t slot, int32
     if (rows > 16 && (rows % s->R != 0 || rows / s->R > s->B)) return fail(WLX_ERR_ARG, "more than 16 rows: a multiple of the slot's rows per item");
     if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "decode before encode");
     s->busy_variant = device_is_busy(s);     // (the launch shapes a step captured now would use)
+    s->long_ctx = t >= 256;
     CK(hipSetDevice(e->device));
     hipStream_t st = s->stream;
     // one item, `rows` beams all at position t with identity history (timing only: cache content is whatever is there);
@@ -1965,6 +2103,7 @@ extern "C" int32_t wlx_debug_trace_step(wlx_engine* e, int32_t slot, int32_t row
     if (rows > 16 && (rows % s->R != 0 || rows / s->R > s->B)) return fail(WLX_ERR_ARG, "more than 16 rows: a multiple of the slot's rows per item");
     if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "decode before encode");
     CK(hipSetDevice(e->device));
+    s->long_ctx = t >= 256;
     hipStream_t st = s->stream;
     const int tR = rows > 16 ? s->R : rows, tG = rows / tR;
     std::vector<int> tk(rows, 0), ps(rows, t), ca(rows), an(rows), gi(tG, 0);
@@ -2025,6 +2164,7 @@ extern "C" int32_t wlx_debug_profile_step(wlx_engine* e, int32_t slot, int32_t r
     if (rows > 16 && (rows % s->R != 0 || rows / s->R > s->B)) return fail(WLX_ERR_ARG, "more than 16 rows: a multiple of the slot's rows per item");
     if (s->enc_batch < 1) return fail(WLX_ERR_STATE, "decode before encode");
     s->busy_variant = device_is_busy(s);     // (the launch shapes a step captured now would use)
+    s->long_ctx = t >= 256;
     CK(hipSetDevice(e->device));
     hipStream_t st = s->stream;
     // up to 16 rows: one item with `rows` beams; more: rows / R items of R beams each, as a batched decode has them

@@ -22,9 +22,14 @@ struct LogmelConsts {          // device pointers, built once per engine
 };
 // up to WLX_LM_MAXB items per launch (blockIdx.y = item): per item the PCM, its length, the feature matrix, T = (n+160)/160 and a uint scratch
 #define WLX_LM_MAXB 16
+// An item's samples are pcm[0 .. n), or — round 6, the PCM ring — the CONCATENATION of nr ranges of `pcm`: rng = device table of
+// nr x {first sample of the range in pcm, position of that sample in the concatenation} (int64 pairs, positions ascending from 0);
+// the loads that bring a tile's samples into LDS walk the table (a tile of 8 frames spans at most a few ranges).
+#define WLX_LM_MAXRANGES 256
 struct LogmelBatch {
     int n_items;
     const float* pcm[WLX_LM_MAXB]; long n[WLX_LM_MAXB]; float* feats[WLX_LM_MAXB]; int T[WLX_LM_MAXB]; unsigned* gmax[WLX_LM_MAXB];
+    const long long* rng[WLX_LM_MAXB]; int nr[WLX_LM_MAXB];
 };
 void launch_logmel_batch(const LogmelBatch& lb, int n_mels, const LogmelConsts& c, long ld, hipStream_t s);
 // pcm [n] f32 device -> feats [n_mels][ld] f32 device (T = (n+160)/160 columns valid); gmax: 1 uint scratch

@@ -53,6 +53,8 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelBatch lb, int n_mels,
     float* __restrict__ feats = lb.feats[item];
     const int T = lb.T[item];
     unsigned* __restrict__ gmax = lb.gmax[item];
+    const long long* __restrict__ rng = lb.rng[item];
+    const int nr = lb.nr[item];
     if ((int)blockIdx.x * LM_FT >= T) return;
     __shared__ __attribute__((aligned(16))) float xw[LM_FT][LM_NFFT];
     __shared__ __attribute__((aligned(16))) float2 tw[LM_NFFT];
@@ -67,7 +69,16 @@ __global__ __launch_bounds__(256) void logmel_kernel(LogmelBatch lb, int n_mels,
     for (int i = tid; i < LM_FT * LM_NFFT; i += 256) {
         int f = i / LM_NFFT, j = i - f * LM_NFFT;
         long src = reflect_idx((long)(t0 + f) * LM_HOP + j - 200, L);
-        float v = (src < n) ? pcm[src] : 0.0f;
+        float v = 0.0f;
+        if (src < n) {
+            long phys = src;
+            if (nr > 0) {              // the PCM ring: sample `src` of the concatenated speech ranges lives at rng[2 q] + (src - rng[2 q + 1])
+                int q = 0;
+                for (int i = 1; i < nr; ++i) q = (src >= (long)rng[2 * i + 1]) ? i : q;
+                phys = (long)rng[2 * q] + (src - (long)rng[2 * q + 1]);
+            }
+            v = pcm[phys];
+        }
         xw[f][j] = v * window[j];
     }
     __syncthreads();

@@ -462,3 +462,40 @@ extern "C" int32_t wlx_vad_probs(wlx_vad* v, const float* pcm, int64_t n, float*
     if (device_ms_out) VCK(hipEventElapsedTime(device_ms_out, v->ev0, v->ev1));
     return WLX_OK;
 }
+
+// The same on samples that are already in HBM: [start, start + n) of a client's PCM ring (engine.hip wlx_ring_*, include/wlx.h) — the
+// gate of a streaming session reads the ring the socket thread filled, no second host-to-device copy.
+extern "C" int32_t wlx_vad_probs_resident(wlx_vad* v, wlx_ring* r, int64_t start, int64_t n, int32_t extra_zero_windows, float* probs_out, int32_t cap,
+                                          int32_t* n_windows_out, float* device_ms_out) {
+    if (!v || !r || !n_windows_out || (n > 0 && !probs_out)) return set_error(WLX_ERR_ARG, "wlx_vad_probs_resident: null argument");
+    if (n < 0) return set_error(WLX_ERR_ARG, "wlx_vad_probs_resident: negative sample count");
+    if (r->device != v->device) return set_error(WLX_ERR_ARG, "wlx_vad_probs_resident: the ring lives on device %d, the VAD model on %d", r->device, v->device);
+    if (extra_zero_windows < 0 || extra_zero_windows > 4) return set_error(WLX_ERR_ARG, "wlx_vad_probs_resident: extra_zero_windows out of range");
+    const long long T = (n + VAD_WINDOW - 1) / VAD_WINDOW + extra_zero_windows;
+    *n_windows_out = (int32_t)T;
+    if (device_ms_out) *device_ms_out = 0.0f;
+    if (T == 0) return WLX_OK;
+    if (T > cap) return set_error(WLX_ERR_ARG, "wlx_vad_probs_resident: %lld windows do not fit the output buffer (%d)", T, cap);
+    std::lock_guard<std::mutex> lk(v->mu);
+    std::lock_guard<std::mutex> lr(r->mu);          // no append / trim while the kernels read (the call waits for them below)
+    if (start < r->base || start + n > r->base + r->resident)
+        return set_error(WLX_ERR_STATE, "wlx_vad_probs_resident: [%lld, %lld) is not resident (ring holds [%lld, %lld))", (long long)start,
+                         (long long)(start + n), (long long)r->base, (long long)(r->base + r->resident));
+    VCK(hipSetDevice(v->device));
+    (void)hipGetLastError();
+    int rc = vad_reserve(v, n + (long long)extra_zero_windows * VAD_WINDOW);
+    if (rc) return rc;
+    const float* pcm = r->buf + (start - r->base);
+    VCK(hipEventRecord(v->ev0, v->stream));
+    const int fe_blocks = (int)((T + VAD_WT - 1) / VAD_WT);
+    hipLaunchKernelGGL(vad_frontend_kernel, dim3(fe_blocks), dim3(VAD_FE_THREADS), 0, v->stream, pcm, (long long)n, (int)T, v->W, v->d_gx);
+    hipLaunchKernelGGL(vad_lstm_kernel, dim3(1), dim3(512), 0, v->stream, v->d_gx, v->W.whhP, v->d_hs, (int)T);
+    hipLaunchKernelGGL(vad_out_kernel, dim3((int)((T + 3) / 4)), dim3(256), 0, v->stream, v->d_hs, v->W.out_w, v->W.out_b, v->d_probs, (int)T);
+    VCK(hipGetLastError());
+    VCK(hipEventRecord(v->ev1, v->stream));
+    VCK(hipMemcpyAsync(v->h_pin, v->d_probs, (size_t)T * sizeof(float), hipMemcpyDeviceToHost, v->stream));
+    VCK(hipStreamSynchronize(v->stream));
+    memcpy(probs_out, v->h_pin, (size_t)T * sizeof(float));
+    if (device_ms_out) VCK(hipEventElapsedTime(device_ms_out, v->ev0, v->ev1));
+    return WLX_OK;
+}

@@ -89,10 +89,45 @@ class HipWhisperEngine:
         except Exception:
             pass
 
+    def create_ring(self, capacity_samples: int = 0) -> "PcmRing":
+        """A device-resident PCM ring for one client stream (include/wlx.h wlx_ring_*)."""
+        h = C.c_void_p()
+        check(self.lib.wlx_ring_create(self._h, int(capacity_samples), C.byref(h)))
+        return PcmRing(self, h)
+
     def create_slot(self, max_batch: int = 1, max_rows_per_item: int = 5) -> "Slot":
         sid = C.c_int32(-1)
         check(self.lib.wlx_slot_create(self._h, max_batch, max_rows_per_item, C.byref(sid)))
         return Slot(self, sid.value, max_batch, max_rows_per_item)
+
+
+class PcmRing:
+    """The device-side mirror of ServeClientBase.frames_np (whisper_live/backend/base.py:173-234): a client's packets are appended
+    ONCE, the VAD gate and the log-mel front end read them in HBM. Positions are absolute stream sample positions."""
+    MAX_RESIDENT = 45 * 16000          # base.py:191 (45 s) ...
+    TRIM = 30 * 16000                  # ... :192-193 (the oldest 30 s go)
+
+    def __init__(self, engine: "HipWhisperEngine", handle):
+        self.engine, self.lib, self._h = engine, engine.lib, handle
+        self.device = getattr(engine, "device", 0)
+
+    def append(self, samples: np.ndarray, max_resident: Optional[int] = None, trim: Optional[int] = None) -> Tuple[int, int, int]:
+        """-> (samples dropped by this call, first resident position, resident count)"""
+        x = np.ascontiguousarray(samples, dtype=np.float32).reshape(-1)
+        d, b, r = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        check(self.lib.wlx_ring_append(self._h, _f32p(x), x.shape[0], self.MAX_RESIDENT if max_resident is None else int(max_resident),
+                                       self.TRIM if trim is None else int(trim), C.byref(d), C.byref(b), C.byref(r)))
+        return d.value, b.value, r.value
+
+    def state(self) -> Tuple[int, int]:
+        b, r = C.c_int64(0), C.c_int64(0)
+        check(self.lib.wlx_ring_state(self._h, C.byref(b), C.byref(r)))
+        return b.value, r.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.wlx_ring_destroy(self._h)
+            self._h = None
 
 
 class Slot:
@@ -118,6 +153,13 @@ class Slot:
     def pcm_put(self, pcm: np.ndarray, item: int = 0):
         pcm = np.ascontiguousarray(pcm, dtype=np.float32)
         check(self.lib.wlx_pcm_put(self.engine._h, self.sid, item, _f32p(pcm), pcm.shape[0]))
+
+    def logmel_ring(self, ring: "PcmRing", ranges: Sequence[Tuple[int, int]], item: int = 0) -> int:
+        """log-mel of the concatenation of ring ranges [(start, end), ...] (absolute positions) -> frames; see wlx_logmel_ring"""
+        rg = np.asarray(ranges, dtype=np.int64).reshape(-1, 2)
+        nf = C.c_int32(0)
+        check(self.lib.wlx_logmel_ring(self.engine._h, self.sid, item, ring._h, rg.ctypes.data_as(C.POINTER(C.c_int64)), rg.shape[0], C.byref(nf)))
+        return nf.value
 
     def logmel_resident(self, item: int = 0) -> int:
         nf = C.c_int32(0)

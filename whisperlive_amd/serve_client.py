@@ -16,6 +16,7 @@ a slot per client thread the lock is not needed for correctness at all and is on
 from __future__ import annotations
 
 import json
+import os
 import logging
 import queue
 import threading
@@ -72,13 +73,20 @@ class ServeClientBase:
     def add_frames(self, frame_np: np.ndarray):
         with self.lock:
             buf = self.frames_np
+            trimmed = 0
             if buf is not None and buf.shape[0] > self.MAX_BUFFER_DURATION_S * self.RATE:
                 self.frames_offset += float(self.BUFFER_TRIM_DURATION_S)
-                buf = buf[int(self.BUFFER_TRIM_DURATION_S * self.RATE):]
+                trimmed = int(self.BUFFER_TRIM_DURATION_S * self.RATE)
+                buf = buf[trimmed:]
                 if self.timestamp_offset < self.frames_offset:      # nothing was committed in the dropped audio
                     self.timestamp_offset = self.frames_offset
             self.frames_np = frame_np.copy() if buf is None else np.concatenate((buf, frame_np), axis=0)
+            self._frames_appended(frame_np, trimmed)
         self.frames_ready.set()
+
+    def _frames_appended(self, frame_np: np.ndarray, trimmed: int):
+        """Hook, called under `self.lock` right after `frames_np` took the packet (`trimmed` samples were dropped from its front
+        first): backends that keep a device-side mirror of the buffer update it here."""
 
     def clip_audio_if_no_valid_segment(self):
         with self.lock:
@@ -91,6 +99,8 @@ class ServeClientBase:
         with self.lock:
             take = max(0, (self.timestamp_offset - self.frames_offset) * self.RATE)
             chunk = self.frames_np[int(take):].copy()
+            # where the chunk starts in the stream (absolute sample position): what a device-side mirror of the buffer is indexed by
+            self._chunk_abs = (int(round(self.frames_offset * self.RATE)) + int(take), chunk.shape[0])
         return chunk, chunk.shape[0] / self.RATE
 
     def get_audio_chunk_duration(self, input_bytes) -> float:
@@ -127,7 +137,12 @@ class ServeClientBase:
         self.on_transcription_thread_exit()
         logging.info("Exiting speech to text thread")
 
+    def _resident(self, input_sample):
+        """Hook: the chunk in the form the backend's transcriber prefers (ServeClientHIP: a ResidentAudio over its device PCM ring)."""
+        return input_sample
+
     def _transcribe_locked(self, input_sample, kw):
+        input_sample = self._resident(input_sample)
         if self.serialize:
             with ServeClientHIP.SINGLE_MODEL_LOCK:
                 return self.transcriber.transcribe(input_sample, **kw)
@@ -340,6 +355,7 @@ class ServeClientHIP(ServeClientBase):
         self.hotwords = hotwords
         self.compute_type = "float16"
         self.device_index = device_index
+        self._ring = None
         self.serialize = serialize_single_model
         if model is None and transcriber is None:
             return
@@ -381,6 +397,45 @@ class ServeClientHIP(ServeClientBase):
             logging.info(f"Detected language {self.language} with probability {info.language_probability}")
             self.websocket.send(json.dumps({"uid": self.client_uid, "language": self.language,
                                             "language_prob": info.language_probability}))
+
+    # ---- device-resident PCM ring (round 6): the packets cross PCIe once, in add_frames; VAD and log-mel read HBM ----------------
+    _ring = None                           # None: not created yet; False: off for this session; else the PcmRing (whisperlive_amd/engine.py)
+
+    def _frames_appended(self, frame_np, trimmed):
+        """Mirror the session buffer on the transcriber's GPU (whisperlive_amd.engine.PcmRing: the same 45 s cap / 30 s trim, decided
+        HERE and checked there). Any failure switches the mirror off for the session: the host path needs nothing from it."""
+        if self._ring is False:
+            return
+        try:
+            if self._ring is None:
+                eng = getattr(getattr(self, "transcriber", None), "engine", None)
+                make = getattr(eng, "create_ring", None)
+                if make is None or os.environ.get("WLX_PCM_RING", "1") == "0" or (ServeClientHIP.BATCH_WORKER or ServeClientHIP.BATCH_WORKERS):
+                    self._ring = False
+                    return
+                self._ring = make()
+                self._ring_expect = 0
+            dropped, base, resident = self._ring.append(frame_np)
+            self._ring_expect += frame_np.shape[0] - dropped
+            if dropped != trimmed or resident != self.frames_np.shape[0] or base != int(round(self.frames_offset * self.RATE)):
+                raise RuntimeError(f"ring out of step with frames_np: dropped {dropped} vs {trimmed}, resident {resident} vs "
+                                   f"{self.frames_np.shape[0]}, base {base} vs {self.frames_offset * self.RATE}")
+        except Exception as e:  # noqa: BLE001
+            logging.warning(f"device PCM ring disabled for {self.client_uid}: {e}")
+            ring, self._ring = self._ring, False
+            if ring:
+                try:
+                    ring.close()
+                except Exception:  # noqa: BLE001
+                    pass
+
+    def _resident(self, input_sample):
+        """`input_sample` as a ResidentAudio when it is the chunk get_audio_chunk_for_processing just took and the ring holds it."""
+        ring, ca = self._ring, getattr(self, "_chunk_abs", None)
+        if not ring or ca is None or ca[1] != input_sample.shape[0]:
+            return input_sample
+        from .transcriber import ResidentAudio
+        return ResidentAudio(ring, ca[0], ca[1], input_sample)
 
     def transcribe_audio(self, input_sample):
         worker = ServeClientHIP.BATCH_WORKER or ServeClientHIP.BATCH_WORKERS.get(self.device_index)
@@ -426,6 +481,10 @@ class ServeClientHIP(ServeClientBase):
         release = getattr(type(self.transcriber), "release_slot", None) if hasattr(self, "transcriber") else None
         if release is not None:
             self.transcriber.release_slot()            # the engine slot goes back to the per-GPU pool
+        with self.lock:
+            ring, self._ring = self._ring, False
+        if ring:
+            ring.close()
 
     def handle_transcription_output(self, result, duration):
         segments = []

@@ -31,6 +31,7 @@ import numpy as np
 
 from . import vad as _vad
 from . import word_timing as _wt
+from ._lib import WlxError as _WlxError
 from .engine import GenerationResult, HipWhisperEngine, Slot, TokenIds
 from .specs import WhisperSpec, get_spec, spec_from_state_dict
 from .tokenizer import LANGUAGE_CODES, Tokenizer
@@ -100,6 +101,18 @@ class DeviceFeatures:
 
     def numpy(self) -> np.ndarray:
         return self.slot.features(self.item)
+
+
+@dataclass
+class ResidentAudio:
+    """A chunk of a client's stream that is resident in a device PCM ring (whisperlive_amd.engine.PcmRing): samples
+    [start, start + n) in absolute stream positions, plus the host copy the session holds anyway (whisper_live/backend/base.py:219-234
+    hands `transcribe_audio` a numpy chunk) — the fallback when the range has been trimmed away meanwhile or the VAD model has no
+    device path. `transcribe(ResidentAudio(...))` then moves NO audio over PCIe: the gate and the log-mel read the ring."""
+    ring: "object"
+    start: int
+    n: int
+    host: np.ndarray
 
 
 @dataclass
@@ -484,6 +497,9 @@ class WhisperModelHIP:
             self.logger.warning("The current model is English-only but the multilingual parameter is set to True; "
                                 "setting to False instead.")
             multilingual = False
+        resident = None
+        if isinstance(audio, ResidentAudio):
+            resident, audio = audio, audio.host
         if not isinstance(audio, np.ndarray):
             # path / bytes / file object, like the reference's decode_audio (:821); WAV and FLAC are read natively
             # (whisperlive_amd/audio_io.py), anything else must arrive as 16 kHz float32 PCM
@@ -495,21 +511,52 @@ class WhisperModelHIP:
         duration = audio.shape[0] / sr
         duration_after_vad = duration
         speech_chunks = None
+        # the resident form of the same chunk (ResidentAudio): ring ranges the log-mel kernel will walk; None = the host path
+        ranges = [(resident.start, resident.start + resident.n)] if resident is not None and resident.n == audio.shape[0] else None
         if vad_filter and clip_timestamps == "0":
             if vad_parameters is None:
                 vad_parameters = VadOptions()
             elif isinstance(vad_parameters, dict):
                 vad_parameters = VadOptions(**vad_parameters)
-            speech_chunks = _vad.get_speech_timestamps(audio, vad_parameters, model=self._vad_model())
-            chunks, _meta = _vad.collect_chunks(audio, speech_chunks)
-            audio = np.concatenate(chunks, axis=0)
-            duration_after_vad = audio.shape[0] / sr
-        if audio.shape[0] == 0:
+            vad_model = self._vad_model()
+            if ranges is not None and hasattr(vad_model, "probs_resident") and getattr(vad_model, "device", None) == getattr(resident.ring, "device", -1):
+                try:
+                    speech_chunks = _vad.get_speech_timestamps_resident(resident.ring, resident.start, resident.n, vad_parameters, model=vad_model)
+                except _WlxError as e:             # trimmed away under us (a backlog of > 45 s): the host copy is still whole
+                    self.logger.debug("resident VAD fell back to the host chunk: %s", e)
+                    ranges = None
+            else:
+                ranges = None
+            if ranges is None:
+                speech_chunks = _vad.get_speech_timestamps(audio, vad_parameters, model=vad_model)
+                chunks, _meta = _vad.collect_chunks(audio, speech_chunks)
+                audio = np.concatenate(chunks, axis=0)
+                n_after = audio.shape[0]
+            else:                                   # collect_chunks + np.concatenate, as ring ranges
+                ranges = [(resident.start + c["start"], resident.start + c["end"]) for c in speech_chunks if c["end"] > c["start"]]
+                n_after = sum(b - a for a, b in ranges)
+                if len(ranges) > 256:               # (include/wlx.h wlx_logmel_ring takes <= 256 ranges)
+                    chunks, _meta = _vad.collect_chunks(audio, speech_chunks)
+                    audio, ranges = np.concatenate(chunks, axis=0), None
+            duration_after_vad = n_after / sr
+        else:
+            n_after = audio.shape[0]
+        if n_after == 0:
             return None, None                                 # reference patch, :860-861
         temps_ = temperature if isinstance(temperature, (list, tuple)) else [temperature]
         slot = self._slot(rows=max(int(beam_size), int(best_of) if any(t > 0 for t in temps_) else 1))
         with slot.lock:
-            n_frames = slot.logmel(audio)                      # PCM -> HBM -> log-mel, stays on the device
+            n_frames = None
+            if ranges is not None:
+                try:
+                    n_frames = slot.logmel_ring(resident.ring, ranges)      # PCM already in HBM: the kernel walks the speech ranges
+                except _WlxError as e:
+                    self.logger.debug("resident log-mel fell back to the host chunk: %s", e)
+                    if speech_chunks is not None:
+                        chunks, _meta = _vad.collect_chunks(audio, speech_chunks)
+                        audio = np.concatenate(chunks, axis=0)
+            if n_frames is None:
+                n_frames = slot.logmel(audio)                  # PCM -> HBM -> log-mel, stays on the device
             features = DeviceFeatures(slot, n_frames)
             all_language_probs = None
             if language is None:

@@ -140,6 +140,21 @@ class SileroHIPModel:
         self.last_device_ms = float(ms.value)
         return probs[: n_out.value].copy()
 
+    def probs_resident(self, ring, start: int, n: int) -> np.ndarray:
+        """The probabilities `self(np.pad(x, (0, 512 - n % 512)))` would return for x = ring samples [start, start + n) — computed from the
+        device-resident ring (whisperlive_amd.engine.PcmRing), no host-to-device copy (include/wlx.h wlx_vad_probs_resident)."""
+        import ctypes as C
+        n = int(n)
+        extra = 1 if n % WINDOW == 0 else 0            # faster_whisper.vad pads to the NEXT multiple: a whole zero window when n is one already
+        cap = n // WINDOW + 2
+        probs = np.empty(cap, np.float32)
+        n_out, ms = C.c_int32(0), C.c_float(0.0)
+        f32p = C.POINTER(C.c_float)
+        self._lib.check(self.lib.wlx_vad_probs_resident(self.handle, ring._h, int(start), n, extra, probs.ctypes.data_as(f32p), cap,
+                                                        C.byref(n_out), C.byref(ms)))
+        self.last_device_ms = float(ms.value)
+        return probs[: n_out.value].copy()
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.wlx_vad_destroy(self.handle)
@@ -355,6 +370,15 @@ def get_speech_timestamps(audio: np.ndarray, vad_options: Optional[VadOptions] =
     padded = np.pad(audio.astype(np.float32, copy=False), (0, WINDOW - n % WINDOW))
     probs = (model or get_default_model())(padded)
     return speech_segments_from_probs(probs, n, opt, sampling_rate)
+
+
+def get_speech_timestamps_resident(ring, start: int, n: int, vad_options: Optional[VadOptions] = None, sampling_rate: int = 16000,
+                                   model=None) -> List[Dict[str, int]]:
+    """get_speech_timestamps for audio that lives in a device PCM ring: samples [start, start + n). `model` must be a SileroHIPModel
+    (anything else has no device path: the caller falls back to the host audio)."""
+    opt = vad_options or VadOptions()
+    probs = model.probs_resident(ring, start, n)
+    return speech_segments_from_probs(probs, int(n), opt, sampling_rate)
 
 
 def collect_chunks(audio: np.ndarray, chunks: List[Dict[str, int]], sampling_rate: int = 16000,
