@@ -45,6 +45,7 @@ struct GemvParams {
     int Mtot;                                // (lean kernel) 0, or the rows of the whole pass, walked in row chunks, see dec_gemv2_kernel
     int chunk;                               // (set by the launcher) rows per chunk: 48 (prompt prefill, grid.z) or 16 (batched decode steps)
     int busy_device;                         // (set by the engine) three or more slots are live on this device: prefer work-saving launch shapes (gemv2_cfg)
+    int wide_rows;                           // (set by the engine) a wide pass (>= 64 rows, LayerNorm as its own launch): fp16-rows-in projections take 64-row tiles
     int rt_nz, rt_tiles, rt_magic;           // (set by the launcher) 16-row chunks folded into blockIdx.x: chunks, live n-tile workgroups, 65536 / rt_nz + 1
     int K, KT, N;                            // K real, KT = Kpad/32, N real outputs
     int KTW;                                 // (set by the launcher) k-tiles per wave, even
@@ -91,6 +92,9 @@ static inline WlxTrace trace_next(const char* name) {
 #define WLX_TR_ARG(name)
 #endif
 void launch_dec_gemv(const GemvParams& p, hipStream_t s);
+// LayerNorm of M fp32 rows -> fp16 rows, the arithmetic of the lean kernel's prologue (wide passes: decoder.hip dec_ln_rows_kernel)
+bool dec_ln_rows_ok(int d);
+void launch_dec_ln_rows(const float* X, long ldx, const float* gamma, const float* beta, half_t* out, long ldo, int M, int d, hipStream_t s);
 // kernel name (as rocprofv3 prints it) the launcher picks for these parameters — profiling hook
 const char* dec_gemv_kernel_name(const GemvParams& p);
 // WLX_DECODE_V1=1 selects the first-generation decode kernels (kept as the in-tree A/B reference)
@@ -103,10 +107,9 @@ int dec_gemv_slab_split(int M, int K, int N);
 
 // causal self-attention over the KV cache, one wave per (row, head)
 // ident_ancestry: ancrow[r] == r for every row of this pass (decode steps), see dec_self_attn2_kernel
-// long_ctx: some row of this pass attends to more than 256 positions (twice the waves per (row, head): one block of 64 positions each)
 void launch_dec_self_attn(const half_t* q, long ldq, const half_t* Kc, const half_t* Vc, long cache_row_stride,
                           int d, int H, const RowTables& rt, int rows, half_t* out, long ldo,
-                          const int* done, bool ident_ancestry, bool long_ctx, hipStream_t s);
+                          const int* done, bool ident_ancestry, hipStream_t s);
 // cross-attention of R rows per item against the item's 1500 encoder keys, split over keys; groups of R (<=16) rows,
 // group_item[g] = audio item whose K/V group g attends to. Kp / Vp: tile-packed cross K / V of ONE decoder layer
 // (gemm.hip GEMM_CROSS_KV), item_stride halfs per item.
