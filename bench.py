@@ -436,11 +436,23 @@ def make_bench_transcriber(eng, spec, ids, decode_steps, vad_model=None, max_bat
             return super().generate(encoder_output, prompts, **kw)
 
     class BenchTranscriber(WhisperModelHIP):
+        stage_log = []                 # per transcribe() call: wall ms and the device stages (HIP events on the slot stream; VAD: its own events)
+
         def transcribe(self, audio, **kw):
             kw.update(temperature=0.0, compression_ratio_threshold=None, log_prob_threshold=None, no_speech_threshold=None)
+            t0 = time.perf_counter()
             segs, info = super().transcribe(audio, **kw)
+            wall = 1e3 * (time.perf_counter() - t0)
             if info is not None:      # random weights give a flat language distribution; real speech locks the language (> 0.5)
                 info.language_probability = max(info.language_probability, 0.99)
+                try:
+                    tm = self._slot().timings()
+                    vm = self.vad_model
+                    BenchTranscriber.stage_log.append(dict(wall_ms=wall, vad_ms=float(getattr(vm, "last_device_ms", 0.0)) if kw.get("vad_filter") else 0.0,
+                                                           logmel_ms=tm["logmel_ms"], encode_ms=tm["encode_ms"], generate_ms=tm["generate_ms"],
+                                                           decode_steps=tm["decode_steps"]))
+                except Exception:  # noqa: BLE001 — an extra; the leg's own counters do not depend on it
+                    pass
             return segs, info
 
     tr = BenchTranscriber("bench", engine=eng, hf_tokenizer=synthetic_tokenizer(spec.vocab), vad_model=vad_model, max_batch=max_batch)
@@ -485,6 +497,19 @@ def stream_leg(eng, spec, ids, decode_steps, pcm_fn, clients=1, batch=False, mod
     finally:
         BatchInferenceWorker.TEMPERATURES = saved_t
         vm.close()
+    try:       # where a chunk's latency goes (all chunks of both runs): medians of the device stages, the rest is host + synchronisation
+        from whisperlive_amd.transcriber import WhisperModelHIP as _W
+        logs = [c for k in _W.__subclasses__() for c in getattr(k, "stage_log", [])]
+        if logs:
+            med = {k: float(np.median([c[k] for c in logs])) for k in ("wall_ms", "vad_ms", "logmel_ms", "encode_ms", "generate_ms", "decode_steps")}
+            med["host_and_sync_ms"] = med["wall_ms"] - med["vad_ms"] - med["logmel_ms"] - med["encode_ms"] - med["generate_ms"]
+            med["chunks"] = len(logs)
+            res["stage_ms_per_chunk"] = med
+        for k in _W.__subclasses__():
+            if hasattr(k, "stage_log"):
+                k.stage_log = []
+    except Exception as e:  # noqa: BLE001
+        res["stage_ms_per_chunk"] = {"error": f"{type(e).__name__}: {e}"}
     res["vad"] = dict(model="Silero architecture on the GPU, seeded energy-following weights", threshold=0.5,
                       speech_spans_in_24s_probe=len(spans), audio_kept_fraction=kept)
     res["config"] = (f"configs[{1 if clients == 1 else 2}]: {clients} WebSocket stream{'s' if clients > 1 else ''} -> TranscriptionServer -> "

@@ -1145,7 +1145,7 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     // two tiles per workgroup are an optimisation, not a requirement: where their reduction buffer plus the staged rows pass
     // a CU's LDS (large-v3's first MLP projection at 41..48 rows: 49 + 124 KiB) one tile per workgroup still runs lean —
     // this shape used to fall back to the first-generation kernel (48-row prompt-prefill chunks of large-v3)
-    if (c.NTB == 2 && p.out_mode == GEMV_OUT_GELU_F16 && c.shm + xs_bytes > WLX_G2_LDS_MAX) {
+    if (c.NTB == 2 && p.out_mode == GEMV_OUT_GELU_F16 && p.in_mode == GEMV_IN_LN && c.shm + xs_bytes > WLX_G2_LDS_MAX) {
         c.NTB = 1;
         c.shm = sizeof(float) * (size_t)c.nw * c.NTB * c.MT * 256;
     }

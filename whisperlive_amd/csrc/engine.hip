@@ -1225,8 +1225,10 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
     // WIDE passes (round 6): from WLX_WIDE_MIN_ROWS rows (default 64: batched steps of 13+ items, the one-pass prompt prefill) the LayerNorms
     // run as their own launches (dec_ln_rows_kernel -> fp16 rows) and every K = d_model projection takes fp16 rows in on 64-row tiles — a
     // weight tile is fetched from L2 once per 64 rows instead of once per 16 and nothing is normalised N / 16 times (decoder.hip gemv_chunked).
-    static const int wide_min = [] { const char* v = getenv("WLX_WIDE_MIN_ROWS"); const int c = v ? atoi(v) : 64; return c <= 0 ? (1 << 30) : std::max(c, 49); }();
-    bool wide = rows >= wide_min && !s->align && dec_ln_rows_ok(d);
+    static const int wide_min = [] { const char* v = getenv("WLX_WIDE_MIN_ROWS"); const int c = v ? atoi(v) : 128; return c <= 0 ? (1 << 30) : std::max(c, 49); }();
+    // (decode steps only: the one-pass prompt prefill gains 0.1 ms of a 30.4 ms conditioned window from it, profiles/r6c_wide_rows_cond_*, and its
+    // prompt K / V would change in their last bits — the 223-step decode of tests/test_gpu_long_context.py holds a near-tie 24 tokens in)
+    bool wide = rows >= wide_min && !alt && !s->align && dec_ln_rows_ok(d);
     if (wide) {
         GemvParams t = oproj_params(0, GEMV_X_PLAIN);
         t.wide_rows = 1;
