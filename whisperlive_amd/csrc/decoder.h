@@ -45,7 +45,6 @@ struct GemvParams {
     int Mtot;                                // (lean kernel) 0, or the rows of the whole pass, walked in row chunks, see dec_gemv2_kernel
     int chunk;                               // (set by the launcher) rows per chunk: 48 (prompt prefill, grid.z) or 16 (batched decode steps)
     int busy_device;                         // (set by the engine) three or more slots are live on this device: prefer work-saving launch shapes (gemv2_cfg)
-    int wide_rows;                           // (set by the engine) a wide pass (>= 64 rows, LayerNorm as its own launch): fp16-rows-in projections take 64-row tiles
     int rt_nz, rt_tiles, rt_magic;           // (set by the launcher) 16-row chunks folded into blockIdx.x: chunks, live n-tile workgroups, 65536 / rt_nz + 1
     int K, KT, N;                            // K real, KT = Kpad/32, N real outputs
     int KTW;                                 // (set by the launcher) k-tiles per wave, even
@@ -92,9 +91,6 @@ static inline WlxTrace trace_next(const char* name) {
 #define WLX_TR_ARG(name)
 #endif
 void launch_dec_gemv(const GemvParams& p, hipStream_t s);
-// LayerNorm of M fp32 rows -> fp16 rows, the arithmetic of the lean kernel's prologue (wide passes: decoder.hip dec_ln_rows_kernel)
-bool dec_ln_rows_ok(int d);
-void launch_dec_ln_rows(const float* X, long ldx, const float* gamma, const float* beta, half_t* out, long ldo, int M, int d, hipStream_t s);
 // kernel name (as rocprofv3 prints it) the launcher picks for these parameters — profiling hook
 const char* dec_gemv_kernel_name(const GemvParams& p);
 // WLX_DECODE_V1=1 selects the first-generation decode kernels (kept as the in-tree A/B reference)

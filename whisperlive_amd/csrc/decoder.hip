@@ -389,67 +389,6 @@ const char* g_trace_names[512];
 //   * everything rarely needed (ragged K, M > 16, d_model not a multiple of 256) stays in the older kernels.
 __device__ __forceinline__ float wave_sum_dpp(float v) { return dpp_wave_sum(v); }   // common.h: 6 v_add_f32_dpp
 
-// ------------------------------------------------------------------ LayerNorm of the rows, on its own (round 6: wide passes)
-// A pass of >= 64 rows (batched decode steps of 13+ items, the one-pass prompt prefill) runs its projections on 64-row tiles (MT = 4, below):
-// a 16-column workgroup then holds 64 rows x K, and the LayerNorm prologue of the lean kernel — every 16-column workgroup normalising ITS
-// rows again, its fp16 rows in LDS — neither fits a CU's LDS at d_model 1280 nor is worth repeating N / 16 times. The rows are normalised
-// ONCE, here, one wave per row with the arithmetic of the prologue (same lane layout, same association, DPP sums: identical fp16 rows), and
-// the projections take fp16 rows in.
-template <int LNV>
-__global__ __launch_bounds__(256) void dec_ln_rows_kernel(const float* __restrict__ X, long ldx, const float* __restrict__ gamma,
-                                                          const float* __restrict__ beta, half_t* __restrict__ out, long ldo, int M WLX_TR_PARAM) {
-    constexpr bool LNT = (LNV == 15);                      // d_model 384 = 1.5 x 256 (see dec_gemv2_kernel)
-    constexpr int NV = LNT ? 2 : LNV;
-    const int lane = threadIdx.x & 63;
-    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
-    WLX_TR_BEGIN();
-    if (r >= M) return;
-    const bool tail_on = !LNT || lane < 32;
-    const int tback = LNT ? (tail_on ? 0 : lane) : 0;
-    const float4* x4 = reinterpret_cast<const float4*>(X + (long)r * ldx) + lane;
-    const float4* g4 = reinterpret_cast<const float4*>(gamma) + lane;
-    const float4* b4 = reinterpret_cast<const float4*>(beta) + lane;
-    float4 x[NV], gq[NV], bq[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) { const int tb = (j == NV - 1) ? tback : 0; x[j] = x4[64 * j - tb]; gq[j] = g4[64 * j - tb]; bq[j] = b4[64 * j - tb]; }
-    constexpr float invK = LNT ? (1.0f / 384.0f) : 1.0f / (256.0f * NV);
-    if constexpr (LNT) { if (!tail_on) x[NV - 1] = make_float4(0.f, 0.f, 0.f, 0.f); }
-    float sm = 0.f;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) sm += (x[j].x + x[j].y) + (x[j].z + x[j].w);
-    const float mean = wave_sum_dpp(sm) * invK;
-    float q = 0.f;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        x[j].x -= mean; x[j].y -= mean; x[j].z -= mean; x[j].w -= mean;
-        if constexpr (LNT) { if (j == NV - 1 && !tail_on) x[j] = make_float4(0.f, 0.f, 0.f, 0.f); }
-        q += (x[j].x * x[j].x + x[j].y * x[j].y) + (x[j].z * x[j].z + x[j].w * x[j].w);
-    }
-    const float rstd = rsqrtf(wave_sum_dpp(q) * invK + 1e-5f);
-    half_t* dst = out + (long)r * ldo + lane * 4;
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-        const f16x4 hv = {(half_t)(x[j].x * rstd * gq[j].x + bq[j].x), (half_t)(x[j].y * rstd * gq[j].y + bq[j].y),
-                          (half_t)(x[j].z * rstd * gq[j].z + bq[j].z), (half_t)(x[j].w * rstd * gq[j].w + bq[j].w)};
-        if (j < NV - 1 || tail_on) *reinterpret_cast<f16x4*>(dst + 256 * j) = hv;
-    }
-    WLX_TR_END(trc);
-}
-bool dec_ln_rows_ok(int d) { return d == 384 || (d % 256 == 0 && d / 256 >= 2 && d / 256 <= 5); }
-void launch_dec_ln_rows(const float* X, long ldx, const float* gamma, const float* beta, half_t* out, long ldo, int M, int d, hipStream_t s) {
-    const dim3 grid((M + 3) / 4), block(256);
-#define WLX_LNR(LNV_) hipLaunchKernelGGL((dec_ln_rows_kernel<LNV_>), grid, block, 0, s, X, ldx, gamma, beta, out, ldo, M WLX_TR_ARG("ln_rows"))
-    switch (d) {
-        case 384: WLX_LNR(15); break;
-        case 512: WLX_LNR(2); break;
-        case 768: WLX_LNR(3); break;
-        case 1024: WLX_LNR(4); break;
-        default: WLX_LNR(5); break;
-    }
-#undef WLX_LNR
-}
-
-
 // copy M rows x K fp16 (16-byte units) global -> LDS rows of stride ldxs, two units per thread in flight per trip (a rolled
 // load->store loop pays one full L2 round trip per unit; M = 5 needs one trip for K = 768 / 256 threads and K = 3072 / 1024)
 // `after_first_loads` runs once, between the first trip's global loads and its LDS stores (every thread runs it, also
@@ -1055,15 +994,12 @@ struct Gemv2Cfg { bool ok, xstage; int nw, CH, NCH, LNV, NTB, MT; size_t shm; };
 static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     Gemv2Cfg c{};
     c.ok = false;
-    if (g_decode_v1 || p.M > 64 || p.M < 1) return c;
-    if (p.M > 48 && !(p.in_mode == GEMV_IN_F16 && p.xsrc == GEMV_X_PLAIN && p.out_mode != GEMV_OUT_SLAB)) return c;   // four row tiles: the fp16-rows-in forms of a wide pass only
+    if (g_decode_v1 || p.M > 48 || p.M < 1) return c;
     if (p.bias ? (p.N & 15) != 0 : p.out_mode != GEMV_OUT_F32) return c;      // bias <=> not the vocabulary projection
     const bool combo = (p.in_mode == GEMV_IN_LN && (p.out_mode == GEMV_OUT_QKV || p.out_mode == GEMV_OUT_F16 ||
                                                     p.out_mode == GEMV_OUT_GELU_F16 || p.out_mode == GEMV_OUT_F32)) ||
                        (p.in_mode != GEMV_IN_LN && p.out_mode == GEMV_OUT_RESID) ||
-                       (p.in_mode == GEMV_IN_F16 && p.out_mode == GEMV_OUT_SLAB) ||
-                       // wide passes (round 6): LayerNorm as its own launch (dec_ln_rows_kernel), every projection fp16 rows in, 64-row tiles
-                       (p.in_mode == GEMV_IN_F16 && p.wide_rows && (p.out_mode == GEMV_OUT_QKV || p.out_mode == GEMV_OUT_F16 || p.out_mode == GEMV_OUT_GELU_F16));
+                       (p.in_mode == GEMV_IN_F16 && p.out_mode == GEMV_OUT_SLAB);
     if (!combo || p.K != p.KT * 32) return c;
     // sources other than the plain rows: one row tile, and only where the kernel is instantiated for them
     if (p.xsrc != GEMV_X_PLAIN) {
@@ -1104,9 +1040,7 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
         best_nch = 1; c.nw = 6; c.CH = 2; c.NCH = 1;
     }
     if (best_nch == (1 << 30)) return c;
-    if (p.in_mode == GEMV_IN_F16 && p.out_mode != GEMV_OUT_RESID && p.out_mode != GEMV_OUT_SLAB && p.M <= 48) return c;   // (those epilogues behind fp16 rows: four row tiles only)
     if (p.in_mode != GEMV_IN_F16 && c.NCH != 1) return c;
-    if (p.M > 48 && c.NCH != 1) return c;                                    // four row tiles: one chunk of k-tiles per wave (the chunk loop double-buffers both operands: registers)
     c.LNV = 0;
     if (p.in_mode == GEMV_IN_LN) {
         if (p.K == 384) c.LNV = 15;                 // 1.5 x 256: see dec_gemv2_kernel
@@ -1136,16 +1070,13 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     if (f16_wide && p.Mtot > 0 && p.rt_nz > 0 && p.M <= 16 && p.in_mode == GEMV_IN_F16 && p.out_mode == GEMV_OUT_RESID && p.xsrc == GEMV_X_PLAIN && ((p.N + 15) / 16) % 2 == 0) c.NTB = 2;   // (one row tile per chunk: the only two-tile instantiation)
     // (measured and dropped, profiles/r4t_*: two tiles for the N = d_model LayerNorm + query projection under a busy device — no change;
     // four tiles for the residual projections — spills at their 1024-thread launch bound, -17 %)
-    // wide passes (64-row tiles, fp16 rows in): two column tiles per workgroup for the wide projections (>= 128 tiles) — half the workgroups
-    // re-read the same 64 rows x K of activations
-    if (p.wide_rows && p.in_mode == GEMV_IN_F16 && p.Mtot > 0 && p.rt_nz > 0 && p.M > 48) c.NTB = ((p.N + 15) / 16 >= 128 && ((p.N + 15) / 16) % 2 == 0) ? 2 : 1;
     c.MT = (p.M + 15) / 16;
     c.shm = sizeof(float) * (size_t)c.nw * c.NTB * c.MT * 256;
     const size_t xs_bytes = (size_t)p.M * (KTf * 32 + 8) * sizeof(half_t);    // fp16 activation rows
     // two tiles per workgroup are an optimisation, not a requirement: where their reduction buffer plus the staged rows pass
     // a CU's LDS (large-v3's first MLP projection at 41..48 rows: 49 + 124 KiB) one tile per workgroup still runs lean —
     // this shape used to fall back to the first-generation kernel (48-row prompt-prefill chunks of large-v3)
-    if (c.NTB == 2 && p.out_mode == GEMV_OUT_GELU_F16 && p.in_mode == GEMV_IN_LN && c.shm + xs_bytes > WLX_G2_LDS_MAX) {
+    if (c.NTB == 2 && p.out_mode == GEMV_OUT_GELU_F16 && c.shm + xs_bytes > WLX_G2_LDS_MAX) {
         c.NTB = 1;
         c.shm = sizeof(float) * (size_t)c.nw * c.NTB * c.MT * 256;
     }
@@ -1199,20 +1130,6 @@ static bool gemv2_launch_qkv_xs(const GemvParams& p, const Gemv2Cfg& c, dim3 gri
 }
 template <int CH, int MT>
 static bool gemv2_launch_other(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, dim3 block, hipStream_t s) {
-    if constexpr (MT == 4) {
-        // wide passes: fp16 rows in, 64-row tiles, one or two column tiles per workgroup, every epilogue
-        if (p.in_mode != GEMV_IN_F16 || p.xsrc != GEMV_X_PLAIN) return false;
-#define WLX_G2W(OUT_) do { if (c.NTB == 2) g2_launch<CH, 1, GEMV_IN_F16, OUT_, 2, 4, GEMV_X_PLAIN>(grid, block, c.shm, s, p); \
-                           else g2_launch<CH, 1, GEMV_IN_F16, OUT_, 1, 4, GEMV_X_PLAIN>(grid, block, c.shm, s, p); } while (0)
-        switch (p.out_mode) {
-            case GEMV_OUT_RESID: WLX_G2W(GEMV_OUT_RESID); return true;
-            case GEMV_OUT_QKV: WLX_G2W(GEMV_OUT_QKV); return true;
-            case GEMV_OUT_F16: WLX_G2W(GEMV_OUT_F16); return true;
-            case GEMV_OUT_GELU_F16: WLX_G2W(GEMV_OUT_GELU_F16); return true;
-            default: return false;
-        }
-#undef WLX_G2W
-    } else
     if (p.in_mode == GEMV_IN_F16) {
         if (p.out_mode == GEMV_OUT_SLAB) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_SLAB, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
         if (p.xsrc == GEMV_X_SLABS) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, MT, GEMV_X_SLABS>(grid, block, c.shm, s, p); return true; }
@@ -1243,8 +1160,7 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
         block.x = 64 * std::max(c.nw, std::min(c.MT > 1 ? 8 : 16, want));
     }
 #define WLX_G2_LN(CH_, LNV_) (c.MT == 1 ? gemv2_launch_ln<CH_, LNV_, 1>(p, c, grid, block, s) : c.MT == 2 ? gemv2_launch_ln<CH_, LNV_, 2>(p, c, grid, block, s) : gemv2_launch_ln<CH_, LNV_, 3>(p, c, grid, block, s))
-#define WLX_G2_OT(CH_) (c.MT == 1 ? gemv2_launch_other<CH_, 1>(p, c, grid, block, s) : c.MT == 2 ? gemv2_launch_other<CH_, 2>(p, c, grid, block, s) : \
-                        c.MT == 3 ? gemv2_launch_other<CH_, 3>(p, c, grid, block, s) : gemv2_launch_other<CH_, 4>(p, c, grid, block, s))
+#define WLX_G2_OT(CH_) (c.MT == 1 ? gemv2_launch_other<CH_, 1>(p, c, grid, block, s) : c.MT == 2 ? gemv2_launch_other<CH_, 2>(p, c, grid, block, s) : gemv2_launch_other<CH_, 3>(p, c, grid, block, s))
     if (p.in_mode == GEMV_IN_LN && p.xsrc != GEMV_X_PLAIN) {
         if (c.CH == 4 && c.LNV == 3) return gemv2_launch_qkv_xs<4, 3>(p, c, grid, block, s);
         if (c.CH == 3 && c.LNV == 3) return gemv2_launch_qkv_xs<3, 3>(p, c, grid, block, s);
@@ -1313,15 +1229,6 @@ static GemvParams gemv_chunked(const GemvParams& p) {
     if (rt_chunk_env) rt_chunk = rt_chunk_env;
     GemvParams q = p;
     if (p.Mtot != 0 || p.in_mode == GEMV_IN_XATTN) return q;
-    // wide passes (round 6): the fp16-rows-in projections with K = one chunk of k-tiles per wave (every K = d_model projection) on 64-row tiles
-    // folded into blockIdx.x like the 16-row tiles — a weight tile is fetched from L2 once per 64 rows instead of once per 16 (large-v3 at
-    // 160 rows: ten row tiles re-read every weight tile, 57 % of the step). The MLP output projection (K = 4 d_model: two or
-    // four chunks per wave) keeps the policy above.
-    if (p.wide_rows && !g_decode_v1 && p.in_mode == GEMV_IN_F16 && p.xsrc == GEMV_X_PLAIN && p.out_mode != GEMV_OUT_SLAB && p.M > 48 && p.M <= rt_max) {
-        GemvParams w = p;
-        w.Mtot = p.M; w.M = 64; w.chunk = 64; w.rt_nz = (p.M + 63) / 64;
-        if (gemv2_ok(w, nullptr)) return w;
-    }
     // Which projections: measured per kernel at 20 / 40 / 60 rows (profiles/r4a-c_*): row tiles win wherever the launch has few
     // column tiles (N = d_model: 7.1 -> 4.2 us at 60 rows, large-v3 6.7 -> 4.8 us at 40) and for Whisper-small's wide ones
     // (first MLP projection 10.3 -> 6.9 us); large-v3's N = 3 d / 4 d projections (10-13 MB of weights re-read per row tile
@@ -1337,6 +1244,12 @@ static GemvParams gemv_chunked(const GemvParams& p) {
     else if (p.M > 48 && p.xsrc != GEMV_X_EMBED) { q.Mtot = p.M; q.M = 48; q.chunk = 48; }
     return q;
 }
+// (Round 6, measured and dropped — "wide passes": from 64 / 128 rows the LayerNorms as their own launch (fp16 rows, the prologue's arithmetic) and
+// every K = d_model projection with fp16 rows in on 64-ROW tiles (MT = 4, one or two column tiles per workgroup), so that a weight tile is fetched
+// from L2 once per 64 rows instead of once per 16. Parity green (210 GPU tests). Whisper-small at 120 / 240 rows: step 1.007 / 1.442 ms against
+// 0.913 / 1.365 ms on the 16-row tiles; large-v3 at 80 / 160 rows: 3.61 / 4.85 against 3.06 / 5.03 ms — the three LayerNorm launches per layer
+// (2 us each) and the 64-row workgroups' lower occupancy cost what the saved L2 re-reads give back; only large-v3 at 160 rows gains (3.6 %).
+// profiles/r6c_wide_rows_*, r6d_wide_rows_*; DESIGN.md §7.3 B4. The 16-row tiles stay.)
 static bool vocab2_ok(const GemvParams& p);   // (dec_vocab_kernel, below)
 bool dec_gemv_is_lean(const GemvParams& p) { return vocab2_ok(p) || gemv2_ok(gemv_chunked(p), nullptr); }
 
@@ -1686,12 +1599,12 @@ void launch_dec_gemv(const GemvParams& p_any, hipStream_t s) {
 // (ancestry -> K / V -> softmax): a step at positions 225..288 (a window conditioned on the reference's full prompt) cost
 // 6.4 us per layer here against 2.9 us at t = 32. Histories of <= 64 positions run exactly as before on wave 0 — the other
 // waves leave at once, and ended waves do not count at the barrier.
+// (Round 6, measured and dropped: twice the waves — one block of 64 positions per wave up to the 448-position context — for passes whose
+// positions pass 256. A step at positions 200 / 300 / 447 costs 398 / 412 / 425 us either way (profiles/r6b_step_by_position.txt): what
+// grows with the history is the K fetch (lane = position: every load instruction touches 64 cache lines), not the second trip.)
 #ifndef SA_NW
 #define SA_NW 4          // -DSA_NW=1 (whisperlive_amd/_lib.py build_variant) = the one-wave form, for A/B
 #endif
-// (Round 6, measured and dropped: twice the waves — one block of 64 positions per wave up to the 448-position context — for passes whose
-// positions pass 256. The step at positions 200 / 300 / 447 costs 398 / 412 / 425 us either way (profiles/r6b_step_by_position.txt): what
-// grows with the history is the K fetch (lane = position: every load instruction touches 64 cache lines), not the second trip.)
 template <bool IDENT>
 __global__ __launch_bounds__(64 * SA_NW) void dec_self_attn2_kernel(const half_t* __restrict__ q, long ldq,
                                                                     const half_t* __restrict__ Kc,

@@ -73,7 +73,6 @@ struct Slot {
     // decoder
     half_t *kc = nullptr, *vc = nullptr;             // self cache [L][cache_rows][448][d]
     float* xd = nullptr; half_t *qd = nullptr, *attnd = nullptr, *hd = nullptr;
-    half_t* lnd = nullptr;                           // [rows_cap][d] fp16 LayerNorm rows of a wide pass (decoder.hip dec_ln_rows_kernel)
     float* slab = nullptr;                           // [WLX_FC2_KS][48][d] partial sums of the K-split MLP output projection (decoder.hip GEMV_OUT_SLAB)
     half_t* part_o = nullptr;
     float *part_ml = nullptr, *logits = nullptr;
@@ -84,7 +83,6 @@ struct Slot {
     struct DecBufs {
         float* xd; half_t *qd, *attnd, *hd; float* slab; int slab_rows; half_t* part_o; float* part_ml;
         int *d_token, *d_pos, *d_cache, *d_ancrow, *d_group_item;
-        half_t* lnd;
     };
     DecBufs pf{};
     bool pf_ok = false;                 // every projection of this model runs on the lean kernel in row chunks (decided at creation)

@@ -670,7 +670,6 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         const int RC = s->rows_cap;
         CKR(dalloc(s->allocs, &s->xd, (size_t)RC * d));
         CKR(dalloc(s->allocs, &s->qd, (size_t)RC * d));
-        CKR(dalloc(s->allocs, &s->lnd, (size_t)RC * d));
         CKR(dalloc(s->allocs, &s->attnd, (size_t)RC * d));
         CKR(dalloc(s->allocs, &s->hd, (size_t)RC * F));
         CKR(dalloc(s->allocs, &s->slab, (size_t)WLX_FC2_KS * RC * d));
@@ -682,7 +681,6 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
             b.slab_rows = (int)PR;
             CKR(dalloc(s->allocs, &b.xd, PR * d)); CKR(dalloc(s->allocs, &b.qd, PR * d)); CKR(dalloc(s->allocs, &b.attnd, PR * d));
             CKR(dalloc(s->allocs, &b.hd, PR * F)); CKR(dalloc(s->allocs, &b.slab, (size_t)WLX_FC2_KS * PR * d));
-            CKR(dalloc(s->allocs, &b.lnd, PR * d));
             CKR(dalloc(s->allocs, &b.part_o, PG * e->H * WLX_XSPLIT * 16 * 64));
             CKR(dalloc(s->allocs, &b.part_ml, PG * e->H * WLX_XSPLIT * 16 * 2));
             CKR(dalloc(s->allocs, &b.d_token, PR)); CKR(dalloc(s->allocs, &b.d_pos, PR)); CKR(dalloc(s->allocs, &b.d_cache, PR));
@@ -1166,12 +1164,11 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
     struct View {
         Slot* base; float* xd; half_t *qd, *attnd, *hd; float* slab; long slab_rows; half_t* part_o; float* part_ml;
         int *d_token, *d_pos, *d_cache, *d_ancrow, *d_group_item;
-        half_t* lnd;
         Slot* operator->() const { return base; }
     } s{s_, alt ? alt->xd : s_->xd, alt ? alt->qd : s_->qd, alt ? alt->attnd : s_->attnd, alt ? alt->hd : s_->hd,
         alt ? alt->slab : s_->slab, alt ? (long)alt->slab_rows : (long)s_->rows_cap, alt ? alt->part_o : s_->part_o, alt ? alt->part_ml : s_->part_ml,
         alt ? alt->d_token : s_->d_token, alt ? alt->d_pos : s_->d_pos, alt ? alt->d_cache : s_->d_cache,
-        alt ? alt->d_ancrow : s_->d_ancrow, alt ? alt->d_group_item : s_->d_group_item, alt ? alt->lnd : s_->lnd};
+        alt ? alt->d_ancrow : s_->d_ancrow, alt ? alt->d_group_item : s_->d_group_item};
     hipStream_t st = s->stream;
     // The decoder pass only rewrites scratch and re-appends the same K/V at the same position when it runs once
     // more after the search has raised `done` (the host runs at most one step ahead), so the second-generation
@@ -1222,39 +1219,18 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
     // workgroup — and those launches are bound by load instructions per CU (60 rows, small.en: first projection 9.8 us with
     // slabs, 7.0 us without; large-v3 at 40 rows: 11.4 -> 8.7 us).
     if (rows > 16 && !alt) KS = 0;
-    // WIDE passes (round 6): from WLX_WIDE_MIN_ROWS rows (default 64: batched steps of 13+ items, the one-pass prompt prefill) the LayerNorms
-    // run as their own launches (dec_ln_rows_kernel -> fp16 rows) and every K = d_model projection takes fp16 rows in on 64-row tiles — a
-    // weight tile is fetched from L2 once per 64 rows instead of once per 16 and nothing is normalised N / 16 times (decoder.hip gemv_chunked).
-    static const int wide_min = [] { const char* v = getenv("WLX_WIDE_MIN_ROWS"); const int c = v ? atoi(v) : 128; return c <= 0 ? (1 << 30) : std::max(c, 49); }();
-    // (decode steps only: the one-pass prompt prefill gains 0.1 ms of a 30.4 ms conditioned window from it, profiles/r6c_wide_rows_cond_*, and its
-    // prompt K / V would change in their last bits — the 223-step decode of tests/test_gpu_long_context.py holds a near-tie 24 tokens in)
-    bool wide = rows >= wide_min && !alt && !s->align && dec_ln_rows_ok(d);
-    if (wide) {
-        GemvParams t = oproj_params(0, GEMV_X_PLAIN);
-        t.wide_rows = 1;
-        GemvParams tq = t; tq.out_mode = GEMV_OUT_QKV; tq.N = 3 * d; tq.bias = e->dec[0].bqkv;
-        GemvParams tg = t; tg.out_mode = GEMV_OUT_GELU_F16; tg.N = F; tg.bias = e->dec[0].b1;
-        wide = dec_gemv_is_lean(t) && dec_gemv_is_lean(tq) && dec_gemv_is_lean(tg);
-    }
-    if (wide) KS = 0;                       // (the K-split MLP projection hands partial-sum slabs to LayerNorm prologues: not in a wide pass)
     if (KS && !(dec_gemv_is_lean(qkv_params(0, GEMV_X_SLABS)) && dec_gemv_is_lean(oproj_params(0, GEMV_X_SLABS)))) KS = 0;
     // (batched steps, 17..64 rows: the folded form gathers ONE row per wave and trip — two trips per 16-row tile, the second behind the
     // weight stream — and has no four-tile instantiation: 13.6 us at 60 rows against 2.4 + 5.9 us for the embedding launch + the plain
     // four-tile projection, profiles/r4s_decode_step.txt.)
     // (prefill passes of more than 64 rows keep the embedding launch, as they always did: the folded form's K split over the waves — one
     // row per wave — differs from the plain LayerNorm projection's, i.e. another summation order for the prompt rows' layer-0 K / V)
-    const bool fold_embed = !wide && (rows <= 16 || (alt != nullptr && rows <= 64)) && dec_gemv_is_lean(qkv_params(0, GEMV_X_EMBED));
+    const bool fold_embed = (rows <= 16 || (alt != nullptr && rows <= 64)) && dec_gemv_is_lean(qkv_params(0, GEMV_X_EMBED));
     // (Measured and closed: ONE LayerNorm launch per layer phase + fp16-rows-in projections instead of the LayerNorm prologue in every
     // 16-column workgroup — for batched decode steps in round 4, for the prompt-prefill pass in round 5 (conditioned window 30.88 vs
     // 30.89 ms, profiles/r5a_*): no gain either way; the kernel left the library.)
     if (!fold_embed)
         plaunch(s.base, "dec_embed_kernel", (double)rows * d * (2 + 4), [&] { launch_dec_embed(e->tok_emb16, e->dec_pos, d, rt, rows, s.xd, done, st); });
-    // a LayerNorm-fronted projection of a wide pass: the LayerNorm launch, then the projection with the fp16 rows in
-    auto ln_then = [&](GemvParams p) {
-        plaunch(s.base, "dec_ln_rows_kernel", 6.0 * rows * d, [&] { launch_dec_ln_rows(p.X, p.ldx, p.gamma, p.beta, s.lnd, d, rows, d, st); });
-        p.in_mode = GEMV_IN_F16; p.Xh = s.lnd; p.ldxh = d; p.X = nullptr; p.gamma = p.beta = nullptr; p.xsrc = GEMV_X_PLAIN; p.wide_rows = 1;
-        pgemv(s.base, p);
-    };
     bool slabs_pending = false;             // the residual stream is xd + slabs until the next residual update writes the sum back
     for (int l = 0; l < sp.dec_layers; ++l) {
         const DecLayerW& w = e->dec[l];
@@ -1263,10 +1239,10 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
         // LN1 + QKV, K/V appended to the self-attention cache
         {
             GemvParams pq = qkv_params(l, (l == 0 && fold_embed) ? GEMV_X_EMBED : (slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN));
-            if (wide) ln_then(pq); else pgemv(s.base, pq);
+            pgemv(s.base, pq);
         }
         plaunch(s.base, "dec_self_attn2_kernel", 4.0 * rows * d * (s->prof ? s->prof->t + 1 : 1), [&] { launch_dec_self_attn(s.qd, d, kc, vc, crs, d, H, rt, rows, s.attnd, d, done, s->anc_ident, st); });
-        { GemvParams po = oproj_params(l, slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN); po.wide_rows = wide ? 1 : 0; pgemv(s.base, po); }
+        pgemv(s.base, oproj_params(l, slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN));
         slabs_pending = false;
         GemvParams p{};
         // LN2 + cross-attention query + cross-attention partials: one fused launch when the shape allows and nobody needs
@@ -1286,7 +1262,7 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
             p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_F16; p.M = rows; p.K = d; p.KT = d / 32; p.N = d;
             p.Wp = w.Wcq; p.bias = w.bcq; p.X = s.xd; p.ldx = d; p.gamma = w.ln2_g; p.beta = w.ln2_b;
             p.Yh = s.qd; p.ldyh = d; p.qscale = 0.125f; p.done = done;
-            if (wide) ln_then(p); else pgemv(s.base, p);
+            pgemv(s.base, p);
             if (s->align) {     // word alignment: raw q.k of this layer's alignment heads for the rows of this chunk
                 const Slot::AlignCapture& a = *s->align;
                 for (int hi = 0; hi < a.n_heads; ++hi)
@@ -1307,14 +1283,13 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
             plaunch(s.base, "dec_xattn_combine_kernel", 0.0, [&] { launch_dec_xattn_combine(s.part_o, s.part_ml, rows, H, R, s.attnd, d, st); });
             p.in_mode = GEMV_IN_F16; p.Xh = s.attnd; p.ldxh = d;
         }
-        p.wide_rows = wide ? 1 : 0;
         pgemv(s.base, p);
         // LN3 + MLP
         p = GemvParams{};
         p.in_mode = GEMV_IN_LN; p.out_mode = GEMV_OUT_GELU_F16; p.M = rows; p.K = d; p.KT = d / 32; p.N = F;
         p.Wp = w.W1; p.bias = w.b1; p.X = s.xd; p.ldx = d; p.gamma = w.ln3_g; p.beta = w.ln3_b;
         p.Yh = s.hd; p.ldyh = F; p.qscale = 1.f; p.done = done;
-        if (wide) ln_then(p); else pgemv(s.base, p);
+        pgemv(s.base, p);
         p = GemvParams{};
         p.in_mode = GEMV_IN_F16; p.out_mode = GEMV_OUT_RESID; p.M = rows; p.K = F; p.KT = F / 32; p.N = d;
         p.Wp = w.W2; p.bias = w.b2; p.Xh = s.hd; p.ldxh = F; p.Xres = s.xd; p.ldxres = d; p.qscale = 1.f; p.done = done;
