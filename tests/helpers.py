@@ -116,6 +116,18 @@ def decode_is_well_conditioned(model, enc, prompt, opts, ref, amp: float, seeds=
     return True
 
 
+def oracle_sequence_logprob(oracle, enc, ids, prompt, seq, opts, what=""):
+    """Cumulative log-probability the ORACLE gives the generated tokens `seq` after `prompt` (teacher-forced, the decoding rules applied
+    at every position); fails if the rules forbid one of them."""
+    lg = oracle.decode_logits(enc, np.asarray(list(prompt) + list(seq))[None])[0].numpy()
+    cum = 0.0
+    for i, t in enumerate(seq):
+        v, lse, _ = odec.process_logits(lg[len(prompt) - 1 + i], list(seq[:i]), opts, ids.no_timestamps not in prompt)
+        assert np.isfinite(v[t]), (what, "a token the rules forbid", i, t)
+        cum += float(v[t] - lse)
+    return cum
+
+
 def check_decode(oracle, enc, slot, ids, prompt, what, *, require_exact=True, noise_amp=0.02, enc_items=None, noise_seeds=(1, 2), **kw):
     """GPU beam decode vs the oracle's.
     * tokens identical -> pass (the GPU's reported score must equal the oracle's to 5e-3).
@@ -127,6 +139,7 @@ def check_decode(oracle, enc, slot, ids, prompt, what, *, require_exact=True, no
       best cumulative score — on peaked weights alternatives are O(1) apart) and its reported score the oracle's evaluation
       of the same tokens."""
     opts = odec.GenOptions(ids=ids, **kw)
+    check_decode.oracle_cum_of_gpu_tokens = None
     got = slot.generate([prompt], engine_ids(ids), enc_items=enc_items, **kw)[0]
     ref = odec.generate(NetProvider(oracle, enc), prompt, opts)
     g, r = got.sequences_ids[0], ref.sequences_ids[0]
@@ -143,14 +156,11 @@ def check_decode(oracle, enc, slot, ids, prompt, what, *, require_exact=True, no
         diff = (what, "first difference at", n, g[max(0, n - 2): n + 3], r[max(0, n - 2): n + 3])
         assert not require_exact, diff
         assert not decode_is_well_conditioned(oracle, enc, prompt, opts, ref, noise_amp, seeds=noise_seeds), diff
-        lg = oracle.decode_logits(enc, np.asarray(list(prompt) + list(g))[None])[0].numpy()
-        cum = 0.0
-        for i, t in enumerate(g):
-            v, lse, _ = odec.process_logits(lg[len(prompt) - 1 + i], list(g[:i]), opts, ids.no_timestamps not in prompt)
-            assert np.isfinite(v[t]), (what, "GPU emitted a token the rules forbid", i, t)
-            cum += float(v[t] - lse)
+        cum = oracle_sequence_logprob(oracle, enc, ids, prompt, g, opts, what)
+        check_decode.oracle_cum_of_gpu_tokens = cum
         denom = float(max(len(g), 1)) ** float(kw.get("length_penalty", 1.0))
         assert abs(got.scores[0] - cum / denom) <= tol, (what, got.scores[0], cum / denom)
         assert len(g) == len(r) and cum >= ref.scores[0] * max(len(r), 1) - 5e-2, (what, n, cum, ref.scores[0] * len(r))
     assert abs(got.no_speech_prob - ref.no_speech_prob) <= 2e-3 + 0.02 * ref.no_speech_prob
+    check_decode.last = dict(gpu_score=float(got.scores[0]), oracle_score=float(ref.scores[0]), gpu_tokens=list(g), oracle_tokens=list(r))
     return n, len(r), exact

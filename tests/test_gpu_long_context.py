@@ -109,10 +109,17 @@ def test_223_token_prompt_decode_to_max_length_448(peaked):
     n, total, exact = check_decode(oracle, enc, slot, ids, p, "small.en peaked 223-token prompt to max_length", require_exact=False,
                                     beam_size=5, patience=1.0, max_length=448, suppress_tokens=sorted(H.default_suppress(ids) + [ids.eot]))
     assert total == 448 - len(p)
-    # (the oracle's own result flips under +-0.02 of logit noise somewhere in these 223 steps, so check_decode holds a diverging
-    # GPU sequence to the near-tie standard above; measured on MI355X in rounds 3 and 4: 223 / 223 tokens. A regression that
-    # diverges early must not hide behind the near-tie rule: at least 200 tokens of common prefix.)
-    assert exact or n >= 200, n
+    # (the oracle's own result flips under +-0.02 of logit noise somewhere in these 223 steps, so check_decode holds a diverging GPU
+    # sequence to the near-tie standard above: an equally good hypothesis UNDER THE ORACLE — within 5e-2 of the oracle's best cumulative
+    # score — and its reported score the oracle's evaluation of its tokens. Measured on MI355X in rounds 3-5: 223 / 223 tokens. Round 6
+    # moved the prompt K / V in their last bits (the one-pass prefill without the K-split MLP projection) and the final ranking of two
+    # beams that part 24 tokens in fell the other way: the GPU's hypothesis scores 0.03 BETTER under the oracle than the oracle's own
+    # beam-search result (a beam search is not exhaustive). A regression that diverges early must still not hide behind the near-tie
+    # rule: either >= 200 tokens of common prefix, or a sequence the oracle scores at least as high as its own result (- 1e-2).)
+    ref_cum = check_decode.last["oracle_score"] * total
+    gpu_cum = check_decode.oracle_cum_of_gpu_tokens
+    print("223-step decode: common prefix", n, "oracle's cumulative log-prob of its own result", ref_cum, "of the GPU's tokens", gpu_cum)
+    assert exact or n >= 200 or (gpu_cum is not None and gpu_cum >= ref_cum - 1e-2), (n, ref_cum, gpu_cum)
 
 
 def test_flat_weights_long_prompt_near_tie_standard(gpu):
@@ -345,9 +352,20 @@ def test_three_items_with_different_prompts_batched_equal_singles(peaked):
                 n += 1
             print("item", i, "prompt", len(prompts[i]), "tokens", len(b), "batched == single for the first", n)
             # 15 rows and 5 rows are different launches of the same kernels (another K split over the waves of a workgroup: a
-            # different fp32 summation order), so over the 218 / 248 steps of the two short-prompt items a near-tie may fall
-            # the other way; every item must agree for at least the 24 steps the long-prompt item runs, that one entirely
-            assert n >= 24, (i, n, a[max(0, n - 2): n + 3], b[max(0, n - 2): n + 3])
+            # different fp32 summation order), so a near-tie may fall the other way. Either the two agree for at least the 24 steps
+            # the long-prompt item runs, or they are equally good hypotheses UNDER THE ORACLE (round 6: the bare "24 tokens" guard
+            # held by luck of the seed — it broke when the prefill's prompt K / V moved in their last bits): both sequences
+            # teacher-forced through the oracle on the item's own encoder output, cumulative log-probabilities within 5e-2
+            # (tests/helpers.py::check_decode's standard) and each run's reported score the oracle's evaluation of its tokens.
+            if n < 24:
+                T_i = Ts[i]
+                enc_i = oracle.encode(olm.pad_or_trim(sb.features(i)[:, : T_i - 1])[None])
+                opts = odec.GenOptions(ids=ids, **kw)
+                ca = H.oracle_sequence_logprob(oracle, enc_i, ids, prompts[i], a, opts, f"item {i} single")
+                cb = H.oracle_sequence_logprob(oracle, enc_i, ids, prompts[i], b, opts, f"item {i} batched")
+                print("item", i, "diverges at", n, "oracle cumulative log-prob: single", ca, "batched", cb)
+                assert len(a) == len(b) and abs(ca - cb) <= 5e-2, (i, n, ca, cb)
+                assert abs(one.scores[0] - ca / max(len(a), 1)) <= 5e-3 and abs(res[i].scores[0] - cb / max(len(b), 1)) <= 5e-3
             if a == b:
                 assert abs(one.scores[0] - res[i].scores[0]) <= 1e-3
             assert abs(one.no_speech_prob - res[i].no_speech_prob) <= 1e-4 + 1e-3 * one.no_speech_prob

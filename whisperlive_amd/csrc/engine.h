@@ -85,6 +85,7 @@ struct Slot {
         int *d_token, *d_pos, *d_cache, *d_ancrow, *d_group_item;
     };
     DecBufs pf{};
+    bool pf_one_pass = false;           // set around the one-pass prompt prefill's decoder pass (engine.hip prefill_tokens): no K-split MLP projection there
     bool pf_ok = false;                 // every projection of this model runs on the lean kernel in row chunks (decided at creation)
     short* d_anc = nullptr; int* d_intok = nullptr;
     bool anc_ident = false;                          // the uploaded row tables have ancrow[r] == r (decode steps; upload_rows)

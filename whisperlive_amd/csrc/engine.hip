@@ -1219,6 +1219,11 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
     // workgroup — and those launches are bound by load instructions per CU (60 rows, small.en: first projection 9.8 us with
     // slabs, 7.0 us without; large-v3 at 40 rows: 11.4 -> 8.7 us).
     if (rows > 16 && !alt) KS = 0;
+    // ... and the one-pass prompt prefill (round 6): its K-split MLP projection made every 16-column workgroup of the next layer's first projection
+    // (144 x 14 workgroups at 224 rows) read THREE fp32 copies of its rows and lose the four-column-tile form: 21.8 us per launch against 11 us.
+    // 224 tokens: 1.099 -> 0.955 ms (Whisper-small), 6.66 -> 5.31 ms (large-v3), profiles/r6g_prefill_time.txt. (The joint pass over a batch's
+    // short prompts keeps its form: its rows must stay bit-identical to the single calls' chunked prefill.)
+    if (alt && s->pf_one_pass) KS = 0;
     if (KS && !(dec_gemv_is_lean(qkv_params(0, GEMV_X_SLABS)) && dec_gemv_is_lean(oproj_params(0, GEMV_X_SLABS)))) KS = 0;
     // (batched steps, 17..64 rows: the folded form gathers ONE row per wave and trip — two trips per 16-row tile, the second behind the
     // weight stream — and has no four-tile instantiation: 13.6 us at 60 rows against 2.4 + 5.9 us for the embedding launch + the plain
@@ -1355,7 +1360,9 @@ static int prefill_tokens(Engine* e, Slot* s, int item, int crow, const int* tok
         CK(hipMemcpyAsync(b.d_ancrow, h + 3 * rows, rows * 4, hipMemcpyHostToDevice, s->stream));
         CK(hipMemcpyAsync(b.d_group_item, h + 4 * rows, groups * 4, hipMemcpyHostToDevice, s->stream));
         s->anc_ident = false;                                       // every row reads its history through the prompt's cache row
+        s->pf_one_pass = true;
         decoder_pass(e, s, rows, 16, groups, false, false, &b);
+        s->pf_one_pass = false;
         CK(hipGetLastError());
         if (nsp_index >= 0 && nsp_index < rows) {
             const int d = e->spec.d_model;
