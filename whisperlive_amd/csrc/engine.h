@@ -119,7 +119,7 @@ struct Ring {
     float* buf = nullptr; size_t cap = 0;
     int64_t base = 0, resident = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t last_read = nullptr; bool read_pending = false;
+    hipEvent_t last_read = nullptr; bool read_pending = false; hipStream_t last_read_stream = nullptr;
 };
 
 struct Engine {

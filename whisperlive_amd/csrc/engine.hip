@@ -954,6 +954,9 @@ extern "C" int32_t wlx_logmel_ring(wlx_engine* e, int32_t slot, int32_t item, wl
         prev_end = b;
     }
     if (total > 16000LL * 3600) return fail(WLX_ERR_ARG, "audio chunk too long");
+    // a reader launched from ANOTHER stream may still be pending: its event is about to be re-recorded on this stream, so this stream first
+    // waits for it (the new record then stands for both; one session = one slot = one stream makes this the rare case)
+    if (r->read_pending && r->last_read_stream != s->stream) CK(hipStreamWaitEvent(s->stream, r->last_read, 0));
     CKR(flush_logmel(e, s));                         // requests recorded earlier go out first (one of them may be this item's)
     CKR(slot_grow_audio(e, s, (size_t)total));       // the feature buffers are sized with the audio buffers
     CK(hipMemcpyAsync(s->d_rng, tab, (size_t)n_ranges * 2 * sizeof(long long), hipMemcpyHostToDevice, s->stream));   // (pageable source: staged before the call returns)
@@ -967,6 +970,7 @@ extern "C" int32_t wlx_logmel_ring(wlx_engine* e, int32_t slot, int32_t item, wl
     CK(hipEventRecord(s->ev_lm1, s->stream));
     CK(hipEventRecord(r->last_read, s->stream));     // a later trim waits for this launch before it moves the samples
     r->read_pending = true;
+    r->last_read_stream = s->stream;
     s->lm_pending = true;
     s->npcm[item] = 0;                               // the item's own PCM buffer does not hold this audio (wlx_logmel_resident would be wrong)
     s->nframes[item] = T;
