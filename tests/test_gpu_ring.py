@@ -154,3 +154,68 @@ def test_transcribe_resident_audio_end_to_end(eng):
                 assert gi.duration_after_vad < gi.duration
     finally:
         m.close(); vm.close(); ring.close()
+
+
+def test_ring_readers_against_a_concurrent_writer(eng):
+    """The socket thread appends (and trims) while the transcription thread reads: a reader that was launched before a trim must see the samples it
+    was launched on (the trim waits for it), a range that is gone must fail loudly, nothing may deadlock. 6 s of wall time: a writer at ~40x real
+    time (trims every ~0.75 s), a reader that snapshots a range under the session lock and runs VAD + log-mel on it outside the lock."""
+    import threading
+    import time
+    from whisperlive_amd import vad
+    ring = eng.create_ring()
+    slot = eng.create_slot(1, 5)
+    one = eng.create_slot(1, 5)
+    vm = vad.SileroHIPModel(energy_following_vad_weights(3), device=0)
+    host = HostBuffer()
+    lock = threading.Lock()
+    stop = threading.Event()
+    errs = []
+
+    def writer():
+        try:
+            i = 0
+            while not stop.is_set():
+                pkt = speech_like_pcm(0.256, seed=1000 + i % 50)
+                with lock:
+                    want = host.add(pkt)
+                    dropped, base, resident = ring.append(pkt)
+                    assert (dropped, base, resident) == (want, host.base, host.buf.shape[0])
+                i += 1
+                time.sleep(0.004)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    th = threading.Thread(target=writer, daemon=True)
+    th.start()
+    ok = gone = 0
+    t_end = time.time() + 6.0
+    rng = np.random.default_rng(5)
+    try:
+        while time.time() < t_end and not errs:
+            with lock:
+                if host.buf is None or host.buf.shape[0] < 40000:
+                    continue
+                n = int(rng.integers(16000, min(host.buf.shape[0], 16000 * 30)))
+                off = int(rng.integers(0, host.buf.shape[0] - n + 1))
+                start = host.base + off
+                ref = host.buf[off: off + n].copy()
+            try:
+                probs = vm.probs_resident(ring, start, n)
+                T = slot.logmel_ring(ring, [(start, start + n // 2), (start + n // 2 + 7, start + n)])
+                got = slot.features()
+            except WlxError as e:
+                assert "resident" in str(e), e
+                gone += 1
+                continue
+            cat = np.concatenate([ref[: n // 2], ref[n // 2 + 7:]])
+            assert one.logmel(cat) == T and np.array_equal(got, one.features())
+            assert np.array_equal(probs, vm(np.pad(ref, (0, vad.WINDOW - n % vad.WINDOW))))
+            ok += 1
+    finally:
+        stop.set()
+        th.join(10)
+        vm.close(); slot.close(); one.close(); ring.close()
+    assert not errs, errs
+    assert not th.is_alive() and ok >= 20, (ok, gone)
+    print("ring under a concurrent writer: reads checked", ok, "ranges already trimmed away", gone, "trims", host.base // 480000)
