@@ -713,6 +713,10 @@ static bool gemm3_ok(const GemmParams& p, int zbatch) {
     if ((long)p.M * p.lda * 2 >= (1L << 31) || (long)p.N * p.KT * 64 >= (1L << 31)) return false;   // 32-bit buffer offsets
     // measured (profiles/r4k_encode_shape_times.txt, Whisper-small): 2 windows (M = 3000) 2.77 ms here vs 2.60 on the 64 x 96 tile, 3 windows
     // (M = 4500) 3.10 vs 3.64, 12 windows 7.75 vs 11.8
+    // round 6: the cross-K/V GEMM of ONE window (N = 2 d_model x decoder layers: 18432 columns for Whisper-small = 6 x 72 tiles of 256 x 256) has the
+    // tile count this form wants at M = 1500 too — the layer GEMMs (N <= 4 d_model: 54-72 tiles on 256 CUs) do not. Encoder of one window
+    // 1.485 -> 1.450 ms (small.en), 7.22 -> 7.07 ms (large-v3), same bits (profiles/r6k_cross_kv_gemm3_ab.txt; WLX_CKV_GEMM3 was that A/B's switch)
+    if (mode != 2 && p.mode == GEMM_CROSS_KV && p.M >= 1024 && p.N >= 8192) return true;
     return mode == 2 ? p.M >= 256 : p.M >= 4000;
 }
 static void gemm3_go(const GemmParams& p0, hipStream_t s) {
