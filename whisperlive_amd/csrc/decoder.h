@@ -66,9 +66,6 @@ struct GemvParams {
     int d; float qscale; half_t* Kc; half_t* Vc; long cache_row_stride;
     const int* row_cache; const int* row_pos;
     const int* done;
-    // fused producer -> consumer launch (decoder.hip dec_oproj_cq_kernel; lean kernel, GEMV_OUT_RESID, one tile pair per workgroup): the residual
-    // tile is stored write-through and the workgroup counts itself in on pub_cnt. Null in every ordinary launch.
-    unsigned* pub_cnt;
     // residual-stream source (GemvXsrc) of the LN prologue / RESID epilogue, and the K-split form (GEMV_OUT_SLAB)
     int xsrc;
     float* slab; long slab_stride;           // [WLX_FC2_KS][rows][ldslab = N of the producer] fp32 partial sums; floats between slabs
@@ -121,12 +118,6 @@ bool dec_cq_cross_attn_eligible(int d, int H, int R);
 void launch_dec_cq_cross_attn(const float* X, long ldx, const float* gamma, const float* beta, const half_t* Wp, const float* bias,
                               float qscale, int d, const half_t* Kp, const half_t* Vp, long item_stride, int H, int R, int groups,
                               int rows, const int* group_item, half_t* part_o, float* part_ml, hipStream_t s);
-// attention output projection (pa: GEMV_IN_F16 / GEMV_OUT_RESID, <= 16 rows) + the fused kernel above in ONE launch, the dependency carried inside it
-// (decoder.hip dec_oproj_cq_kernel). pub_cnt: this launch's counter (zero at entry); zero_cnt: the next fused launch's counter, zeroed here.
-// Returns false when the shapes do not take the fused form: the caller then launches the two kernels.
-bool launch_dec_oproj_cq(const GemvParams& pa, const float* X, long ldx, const float* gamma, const float* beta, const half_t* Wp, const float* bias,
-                         float qscale, int d, const half_t* Kp, const half_t* Vp, long item_stride, int H, int R, int groups, int rows,
-                         const int* group_item, half_t* part_o, float* part_ml, unsigned* pub_cnt, unsigned* zero_cnt, hipStream_t s);
 // combine of the cross attention's split partials into fp16 rows out[M][H*64] (batched rows: see decoder.hip)
 void launch_dec_xattn_combine(const half_t* part_o, const float* part_ml, int M, int H, int R, half_t* out, long ldo, hipStream_t s);
 // raw cross-attention scores of head h (tile-packed K of one layer AND item) for `rows` query rows -> out[rows][1536] fp32

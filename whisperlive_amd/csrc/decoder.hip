@@ -389,31 +389,14 @@ const char* g_trace_names[512];
 //   * everything rarely needed (ragged K, M > 16, d_model not a multiple of 256) stays in the older kernels.
 __device__ __forceinline__ float wave_sum_dpp(float v) { return dpp_wave_sum(v); }   // common.h: 6 v_add_f32_dpp
 
-// the block a kernel body runs as: the launch's own block, or — in a fused launch, where several kernels' workgroups share one grid — the
-// block it WOULD have been in its own launch
-struct VBlk { int x, y, z, nthr; };
-// agent-scope (write-through / L1-bypassing) 16-byte accesses as two 8-byte relaxed atomics: the producer -> consumer hand-off INSIDE a launch
-// (MI355X guide, Guideline 16 R1: sc1 stores on the producer, sc1 loads on the consumer, a counter in between)
-__device__ __forceinline__ void st_agent_f32x4(float* p, float4 v) {
-    unsigned long long* q = reinterpret_cast<unsigned long long*>(p);
-    __hip_atomic_store(q, (unsigned long long)__float_as_uint(v.x) | ((unsigned long long)__float_as_uint(v.y) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(q + 1, (unsigned long long)__float_as_uint(v.z) | ((unsigned long long)__float_as_uint(v.w) << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ float4 ld_agent_f32x4(const float* p) {
-    const unsigned long long* q = reinterpret_cast<const unsigned long long*>(p);
-    const unsigned long long a = __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long b = __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return make_float4(__uint_as_float((unsigned)a), __uint_as_float((unsigned)(a >> 32)), __uint_as_float((unsigned)b), __uint_as_float((unsigned)(b >> 32)));
-}
-
 // copy M rows x K fp16 (16-byte units) global -> LDS rows of stride ldxs, two units per thread in flight per trip (a rolled
 // load->store loop pays one full L2 round trip per unit; M = 5 needs one trip for K = 768 / 256 threads and K = 3072 / 1024)
 // `after_first_loads` runs once, between the first trip's global loads and its LDS stores (every thread runs it, also
 // threads without a unit): the caller requests its weight stream there, behind the activation loads.
 template <class F>
-__device__ __forceinline__ void stage_rows_f16(const half_t* __restrict__ X, long ldx, int M, int K, half_t* xs, int ldxs, int nthr,
+__device__ __forceinline__ void stage_rows_f16(const half_t* __restrict__ X, long ldx, int M, int K, half_t* xs, int ldxs,
                                                F&& after_first_loads) {
-    const int kv8 = K >> 3, total = M * kv8;
+    const int kv8 = K >> 3, total = M * kv8, nthr = blockDim.x;
     {   // first trip, peeled: clamped units so every thread issues (and the hook sits at one program point)
         const int u0 = (threadIdx.x < total) ? (int)threadIdx.x : total - 1;
         const int u1 = (u0 + nthr < total) ? u0 + nthr : u0;
@@ -457,7 +440,7 @@ __device__ __forceinline__ void stage_rows_f16(const half_t* __restrict__ X, lon
 template <int CH, int LNV, int IN, int OUT, int NTB, int MT, int XS>
 // (<= 8 waves wherever the kernel holds more than one row tile of fragments: 256 VGPRs per lane — at 16 waves the
 // two- and three-tile residual projections spilled, 36-180 bytes of scratch per lane)
-__device__ __forceinline__ void dec_gemv2_body(const GemvParams& p_in, const VBlk vb) {
+__global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1) ? 512 : 1024) void dec_gemv2_kernel(GemvParams p_in) {
     // Row chunks (prompt prefill, round 3): a pass over up to 448 rows runs every projection as ONE launch whose grid.z walks
     // chunks of 48 rows (three MFMA row tiles, the widest this kernel holds); a chunk is this kernel on rebased row pointers.
     // Decode steps launch with Mtot = 0 and skip the block (a scalar branch).
@@ -468,11 +451,11 @@ __device__ __forceinline__ void dec_gemv2_body(const GemvParams& p_in, const VBl
     // workgroup) made every one of the N / 16 workgroups normalise / stage ALL rows on N / 16 CUs (60 rows, d_model 768:
     // 7.1 us per residual projection at 0.04 of the HBM peak); row tiles spread the same work over 4x the CUs.
     GemvParams p = p_in;
-    int tile = vb.x;
+    int tile = blockIdx.x;
     if (p_in.Mtot > 0) {
-        int zc = vb.z;
+        int zc = (int)blockIdx.z;
         if (p_in.rt_nz > 0) {
-            const int lin = vb.x, t = lin >> 3;
+            const int lin = (int)blockIdx.x, t = lin >> 3;
             const int tq = (int)(((unsigned)t * (unsigned)p_in.rt_magic) >> 16);      // t / rt_nz (host: magic = 65536 / nz + 1, exact for t < 32768)
             zc = t - tq * p_in.rt_nz;
             tile = tq * 8 + (lin & 7);
@@ -518,7 +501,7 @@ __device__ __forceinline__ void dec_gemv2_body(const GemvParams& p_in, const VBl
     // of load INSTRUCTIONS a CU issues, which is what bounds these launches (~11 ns per wave-level load): no gain.)
     const bool streams = (IN != GEMV_IN_XATTN) || wave < nw;               // this wave streams weights and runs MFMAs (helper waves: XATTN only)
     const int kx0 = (streams ? wave : 0) * p.KTW;                          // first k-tile of this wave inside its K slice
-    const int ks0 = (OUT == GEMV_OUT_SLAB) ? vb.y * p.KTS : 0;  // first k-tile of this workgroup's K slice
+    const int ks0 = (OUT == GEMV_OUT_SLAB) ? (int)blockIdx.y * p.KTS : 0;  // first k-tile of this workgroup's K slice
     const int kw0 = ks0 + kx0;                                             // ... of this wave, inside the weight matrix
     const half_t* wp = p.Wp + ((long)(tile * NTB) * p.KT + kw0) * 512 + lane * 8;
     const long wstep = (long)p.KT * 512;                                   // next n-tile
@@ -567,7 +550,7 @@ __device__ __forceinline__ void dec_gemv2_body(const GemvParams& p_in, const VBl
         for (int sl = 0; sl < WLX_FC2_KS; ++sl)
             slab_e[sl] = *reinterpret_cast<const float4*>(p.slab + sl * p.slab_stride + (long)row_e * p.ldxres + n_e);
     }
-    if constexpr (OUT == GEMV_OUT_SLAB) { if (vb.y != 0) bias_e = make_float4(0.f, 0.f, 0.f, 0.f); }   // the bias once: slice 0
+    if constexpr (OUT == GEMV_OUT_SLAB) { if (blockIdx.y != 0) bias_e = make_float4(0.f, 0.f, 0.f, 0.f); }   // the bias once: slice 0
 
     f32x4 acc[NTB][MT];
 #pragma unroll
@@ -585,7 +568,7 @@ __device__ __forceinline__ void dec_gemv2_body(const GemvParams& p_in, const VBl
             // as the weights; a CU retires one per ~11 ns), the cooperative copy M * K / 8 / 64 = 30.
             const int Ks = (OUT == GEMV_OUT_SLAB) ? p.KTS * 32 : p.K;      // columns of the rows this workgroup multiplies
             const int ldxs = Ks + 8;
-            stage_rows_f16(p.Xh + ks0 * 32, p.ldxh, p.M, Ks, xs, ldxs, vb.nthr, [&]() { if (WLX_X_FIRST) load_weights(); });
+            stage_rows_f16(p.Xh + ks0 * 32, p.ldxh, p.M, Ks, xs, ldxs, [&]() { if (WLX_X_FIRST) load_weights(); });
             WLX_TR_MARK(1);
             __syncthreads();
             xr[0] = xs + crow[0] * ldxs + kx0 * 32 + g * 8;                 // lanes of rows >= M re-read a valid row (never stored)
@@ -881,7 +864,7 @@ __device__ __forceinline__ void dec_gemv2_body(const GemvParams& p_in, const VBl
         };
         combine(tid, true);
 #pragma unroll 1
-        for (int it0 = tid + vb.nthr; it0 < n_it; it0 += vb.nthr) combine(it0, false);
+        for (int it0 = tid + blockDim.x; it0 < n_it; it0 += blockDim.x) combine(it0, false);
         WLX_TR_MARK(1);
         __syncthreads();
         if (!streams) return;                                               // helper waves are done (no later barrier needs them: ended waves leave the barrier count)
@@ -927,7 +910,7 @@ __device__ __forceinline__ void dec_gemv2_body(const GemvParams& p_in, const VBl
             for (int sl = 0; sl < WLX_FC2_KS; ++sl)
                 slab_e[sl] = *reinterpret_cast<const float4*>(p.slab + sl * p.slab_stride + (long)rr * p.ldxres + n_p);
         }
-        if constexpr (OUT == GEMV_OUT_SLAB) { if (vb.y != 0) bias_e = make_float4(0.f, 0.f, 0.f, 0.f); }
+        if constexpr (OUT == GEMV_OUT_SLAB) { if (blockIdx.y != 0) bias_e = make_float4(0.f, 0.f, 0.f, 0.f); }
         if constexpr (OUT == GEMV_OUT_QKV) { rc_e = p.row_cache[rr]; rp_e = p.row_pos[rr]; }
     }
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -955,11 +938,10 @@ __device__ __forceinline__ void dec_gemv2_body(const GemvParams& p_in, const VBl
 #pragma unroll
                 for (int sl = 0; sl < WLX_FC2_KS; ++sl) { res_e.x += slab_e[sl].x; res_e.y += slab_e[sl].y; res_e.z += slab_e[sl].z; res_e.w += slab_e[sl].w; }
             }
-            const float4 xo = make_float4(res_e.x + o0, res_e.y + o1, res_e.z + o2, res_e.w + o3);
-            if (p.pub_cnt) st_agent_f32x4(p.Xres + (long)c * p.ldxres + n_e, xo);     // (fused launch: write-through, read by the consumer half of the SAME launch)
-            else *reinterpret_cast<float4*>(p.Xres + (long)c * p.ldxres + n_e) = xo;
+            *reinterpret_cast<float4*>(p.Xres + (long)c * p.ldxres + n_e) =
+                make_float4(res_e.x + o0, res_e.y + o1, res_e.z + o2, res_e.w + o3);
         } else if constexpr (OUT == GEMV_OUT_SLAB) {                        // this K slice's partial tile; summed by the consumers
-            *reinterpret_cast<float4*>(p.slab + vb.y * p.slab_stride + (long)c * p.ldxres + n_e) = make_float4(o0, o1, o2, o3);
+            *reinterpret_cast<float4*>(p.slab + blockIdx.y * p.slab_stride + (long)c * p.ldxres + n_e) = make_float4(o0, o1, o2, o3);
         } else {   // GEMV_OUT_QKV: the 16-column tile lies entirely in q, k or v (d % 16 == 0)
             if (n_e < p.d) {
                 const f16x4 h = {(half_t)(o0 * p.qscale), (half_t)(o1 * p.qscale), (half_t)(o2 * p.qscale), (half_t)(o3 * p.qscale)};
@@ -973,21 +955,8 @@ __device__ __forceinline__ void dec_gemv2_body(const GemvParams& p_in, const VBl
         }
     }
     }
-    if constexpr (OUT == GEMV_OUT_RESID && NP == 1) {
-        // fused producer -> consumer launch (dec_oproj_cq_kernel): this workgroup's tile of the residual stream is out (wave 0 stored it,
-        // write-through); count it in. The consumer workgroups of the same launch poll the counter.
-        if (p.pub_cnt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) __hip_atomic_fetch_add(p.pub_cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
     WLX_TR_MARK(5);
     WLX_TR_END_WAVES(p.trc);
-}
-
-template <int CH, int LNV, int IN, int OUT, int NTB, int MT, int XS>
-__global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1) ? 512 : 1024) void dec_gemv2_kernel(GemvParams p_in) {
-    dec_gemv2_body<CH, LNV, IN, OUT, NTB, MT, XS>(p_in, VBlk{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, (int)blockDim.x});
 }
 
 // one launch of an instantiation; workgroups that need more than the default 64 KiB of dynamic LDS (batched rows of the
@@ -1873,17 +1842,12 @@ __global__ __launch_bounds__(XA_TPS * 64) void dec_cross_attn_kernel(const half_
 // repeats are L2 hits, not HBM reads. What it buys: one launch boundary (1.6 us) and one launch's fixed latency per
 // layer; what it costs: ~200 load instructions per CU instead of ~60 (2.2 us of issue at ~11 ns each).
 // Eligibility (launcher): d_model = 256 * LNV with KT % 6 == 0 — Whisper-small; other sizes keep the two launches.
-// FUSED (round 6, dec_oproj_cq_kernel): the body as the CONSUMER half of a launch whose producer half (the attention output projection) writes
-// the residual rows this kernel normalises. Everything that does not depend on those rows — LayerNorm parameters, the head's 96 KiB of query
-// weights, the wave's K / V tile: ~27 of the ~33 wave-level loads, 2.3 us of a 5 us workgroup (profiles/r6i_decode_step_trace.txt) — is
-// requested at entry, UNDER the producer; then one lane polls the producers' counter, and the rows are fetched with agent-scope loads.
-template <int LNV, int KPW, bool FUSED>
-__device__ __forceinline__ void dec_cq_cross_attn_body(
-    const int bidx, const float* __restrict__ X, long ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
+template <int LNV, int KPW>
+__global__ __launch_bounds__(XA_TPS * 64) void dec_cq_cross_attn_kernel(
+    const float* __restrict__ X, long ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
     const half_t* __restrict__ Wp, const float* __restrict__ bias, float qscale, int KT,
     const half_t* __restrict__ Kp, const half_t* __restrict__ Vp, long item_stride, int H, int R, int rows,
-    const int* __restrict__ group_item, half_t* __restrict__ part_o, float* __restrict__ part_ml,
-    const unsigned* wait_cnt, unsigned wait_n WLX_TR_PARAM) {
+    const int* __restrict__ group_item, half_t* __restrict__ part_o, float* __restrict__ part_ml WLX_TR_PARAM) {
     constexpr int TPS = XA_TPS;
     static_assert(TPS == 6, "six waves: KT/6 k-tiles of the query projection and one key tile each");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -1892,7 +1856,7 @@ __device__ __forceinline__ void dec_cq_cross_attn_body(
     WLX_TR_BEGIN();
     // ---- (head, split) of this workgroup: the 8 splits of a head share blockIdx % 8, i.e. one XCD
     const int per_grp = H * WLX_XSPLIT;
-    const int grp = bidx / per_grp, wg = bidx - grp * per_grp;
+    const int grp = blockIdx.x / per_grp, wg = blockIdx.x - grp * per_grp;
     int h, sp;
     {
         const int x = wg & 7, j = wg >> 3, full = H >> 3, rem = H & 7;
@@ -1917,7 +1881,7 @@ __device__ __forceinline__ void dec_cq_cross_attn_body(
     // LayerNorm (which everything else waits for) started 2.6 us into a 5.9 us launch
     const int nrow = (rows - grp * R < R) ? rows - grp * R : R;           // live rows of this group
     float4 x0[LNV];
-    if constexpr (!FUSED) {
+    {
         const int r0 = (wave < nrow) ? wave : nrow - 1;
         const float4* x4 = reinterpret_cast<const float4*>(X + (long)(grp * R + r0) * ldx) + lane;
 #pragma unroll
@@ -1950,19 +1914,6 @@ __device__ __forceinline__ void dec_cq_cross_attn_body(
 #pragma unroll
     for (int dt = 0; dt < 4; ++dt) vf[dt] = ld_f16x8(Vp + toff + dt * 512);
     const float4 bq4 = *reinterpret_cast<const float4*>(bias + h * 64 + (wave & 3) * 16 + g * 4);
-    if constexpr (FUSED) {
-        // the producers' tiles are complete when their counter reads wait_n: ONE lane polls (relaxed, agent scope; bounded: a broken protocol
-        // must not wedge the GPU — it shows as wrong rows), the workgroup waits at the barrier, then every wave fetches its row past L1
-        if (tid == 0) {
-            unsigned spins = 0;
-            while (__hip_atomic_load(wait_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < wait_n && ++spins < (1u << 22)) __builtin_amdgcn_s_sleep(1);
-        }
-        __syncthreads();
-        const int r0 = (wave < nrow) ? wave : nrow - 1;
-        const float* xr = X + (long)(grp * R + r0) * ldx + lane * 4;
-#pragma unroll
-        for (int j = 0; j < LNV; ++j) x0[j] = ld_agent_f32x4(xr + 256 * j);
-    }
     {   // LayerNorm: wave w normalises rows w, w + 6, ... of the group
         constexpr float invK = 1.0f / (256.0f * LNV);
         auto ln_row = [&](float4 (&x)[LNV], int r, bool keep) {
@@ -1993,7 +1944,7 @@ __device__ __forceinline__ void dec_cq_cross_attn_body(
             const float4* x4 = reinterpret_cast<const float4*>(X + (long)(grp * R + r) * ldx) + lane;
             float4 x[LNV];
 #pragma unroll
-            for (int j = 0; j < LNV; ++j) { if constexpr (FUSED) x[j] = ld_agent_f32x4(reinterpret_cast<const float*>(x4 + 64 * j)); else x[j] = x4[64 * j]; }
+            for (int j = 0; j < LNV; ++j) x[j] = x4[64 * j];
             ln_row(x, r, true);
         }
     }
@@ -2095,45 +2046,6 @@ __device__ __forceinline__ void dec_cq_cross_attn_body(
     WLX_TR_END(trc);
 }
 
-template <int LNV, int KPW>
-__global__ __launch_bounds__(XA_TPS * 64) void dec_cq_cross_attn_kernel(
-    const float* __restrict__ X, long ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const half_t* __restrict__ Wp, const float* __restrict__ bias, float qscale, int KT,
-    const half_t* __restrict__ Kp, const half_t* __restrict__ Vp, long item_stride, int H, int R, int rows,
-    const int* __restrict__ group_item, half_t* __restrict__ part_o, float* __restrict__ part_ml WLX_TR_PARAM) {
-#ifdef WLX_TRACE
-    dec_cq_cross_attn_body<LNV, KPW, false>((int)blockIdx.x, X, ldx, gamma, beta, Wp, bias, qscale, KT, Kp, Vp, item_stride, H, R, rows, group_item, part_o, part_ml, nullptr, 0u, trc);
-#else
-    dec_cq_cross_attn_body<LNV, KPW, false>((int)blockIdx.x, X, ldx, gamma, beta, Wp, bias, qscale, KT, Kp, Vp, item_stride, H, R, rows, group_item, part_o, part_ml, nullptr, 0u);
-#endif
-}
-
-// ------------------------------------------------------------------ fused launch: attention output projection => LayerNorm + cross-attention (round 6)
-// ONE launch of nA + nB workgroups: the first nA run the lean residual projection (dec_gemv2_body<6, 1, F16, RESID, 1, 1, XS>, 4 waves; the other two
-// waves of the 6-wave block leave at once), the rest the fused cross-attention body with FUSED = true. The dependency between them — the
-// projection's residual tiles — is carried inside the launch: write-through stores + one counter (GemvParams::pub_cnt), polled by one lane per
-// consumer workgroup. What it buys: the consumer's 2.3 us of weight / K / V requests run under the producer instead of behind a launch boundary.
-// Every workgroup of the launch must be resident together (nA + nB = 144 of 256 CUs for one item: the launcher checks); same arithmetic, same
-// order as the two launches: identical results.
-template <int XS>
-__global__ __launch_bounds__(XA_TPS * 64) void dec_oproj_cq_kernel(GemvParams pa, int nA,
-    const float* __restrict__ X, long ldx, const float* __restrict__ gamma, const float* __restrict__ beta,
-    const half_t* __restrict__ Wp, const float* __restrict__ bias, float qscale, int KT,
-    const half_t* __restrict__ Kp, const half_t* __restrict__ Vp, long item_stride, int H, int R, int rows,
-    const int* __restrict__ group_item, half_t* __restrict__ part_o, float* __restrict__ part_ml, unsigned* zero_cnt WLX_TR_PARAM) {
-    if ((int)blockIdx.x < nA) {
-        if (threadIdx.x >= 256) return;                       // (the projection's block: 4 waves)
-        if (blockIdx.x == 0 && threadIdx.x == 0 && zero_cnt) __hip_atomic_store(zero_cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the NEXT fused launch's counter
-        dec_gemv2_body<6, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, 1, XS>(pa, VBlk{(int)blockIdx.x, 0, 0, 256});
-        return;
-    }
-#ifdef WLX_TRACE
-    dec_cq_cross_attn_body<3, 4, true>((int)blockIdx.x - nA, X, ldx, gamma, beta, Wp, bias, qscale, KT, Kp, Vp, item_stride, H, R, rows, group_item, part_o, part_ml, pa.pub_cnt, (unsigned)nA, trc);
-#else
-    dec_cq_cross_attn_body<3, 4, true>((int)blockIdx.x - nA, X, ldx, gamma, beta, Wp, bias, qscale, KT, Kp, Vp, item_stride, H, R, rows, group_item, part_o, part_ml, pa.pub_cnt, (unsigned)nA);
-#endif
-}
-
 // eligibility: d_model 768 (LNV = 3, KT = 24 = 6 waves x 4 k-tiles), groups of <= 16 rows; WLX_NO_FUSED_CQ=1 forces the
 // two separate launches (A/B)
 bool dec_cq_cross_attn_eligible(int d, int H, int R) {
@@ -2143,40 +2055,6 @@ bool dec_cq_cross_attn_eligible(int d, int H, int R) {
     const size_t shm = sizeof(float) * (xs_floats + (size_t)XA_TPS * 16 * 68 + XA_TPS * 16 * 2) + 16 * 72 * sizeof(half_t);
     return shm <= 64 * 1024;
 }
-// the fused launch; false = not applicable to these shapes (the caller launches the two kernels)
-bool launch_dec_oproj_cq(const GemvParams& pa0, const float* X, long ldx, const float* gamma, const float* beta, const half_t* Wp, const float* bias,
-                         float qscale, int d, const half_t* Kp, const half_t* Vp, long item_stride, int H, int R, int groups, int rows,
-                         const int* group_item, half_t* part_o, float* part_ml, unsigned* pub_cnt, unsigned* zero_cnt, hipStream_t s) {
-    if (pa0.in_mode != GEMV_IN_F16 || pa0.out_mode != GEMV_OUT_RESID || pa0.M < 1 || pa0.M > 16 || pa0.Mtot != 0 || !pub_cnt) return false;
-    if (pa0.xsrc != GEMV_X_PLAIN && pa0.xsrc != GEMV_X_SLABS) return false;
-    if (!dec_cq_cross_attn_eligible(d, H, R)) return false;
-    const GemvParams pc = gemv_chunked(pa0);
-    Gemv2Cfg c;
-    if (pc.Mtot != 0 || !gemv2_ok(pc, &c)) return false;
-    if (!(c.CH == 6 && c.nw == 4 && c.NCH == 1 && c.NTB == 1 && c.MT == 1 && c.xstage)) return false;      // the one projection form the fused kernel instantiates
-    GemvParams p = pc;
-    p.KTW = c.CH * c.NCH; p.NCH = c.NCH; p.xstage = 1; p.nwm = c.nw; p.pub_cnt = pub_cnt;
-    const int nA = (p.N + 15) / 16, nB = H * WLX_XSPLIT * groups;
-    static const int n_cu = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount; return n; }();
-    if ((nA & 7) || nA + nB > n_cu) return false;             // (the consumers' head -> XCD map wants nA % 8 == 0; every workgroup resident together)
-    const int KT = d / 32;
-    const size_t xs_floats = (size_t)((R * (d + 8) * 2 + 15) / 16) * 4;
-    const size_t shm_b = sizeof(float) * (xs_floats + (size_t)XA_TPS * 16 * 68 + XA_TPS * 16 * 2) + 16 * 72 * sizeof(half_t);
-    const size_t shm = std::max(c.shm, shm_b);
-    if (shm > 64 * 1024) return false;
-#ifdef WLX_TRACE
-    { static thread_local char nm[512][48]; const int q = g_trace_seq < 512 ? g_trace_seq : 511;
-      snprintf(nm[q], 48, "oproj(fused) N%d K%d", p.N, p.K); p.trc = trace_next(nm[q]); }
-#endif
-    if (p.xsrc == GEMV_X_SLABS)
-        hipLaunchKernelGGL((dec_oproj_cq_kernel<GEMV_X_SLABS>), dim3(nA + nB), dim3(XA_TPS * 64), shm, s, p, nA, X, ldx, gamma, beta, Wp, bias, qscale, KT, Kp, Vp,
-                           item_stride, H, R, rows, group_item, part_o, part_ml, zero_cnt WLX_TR_ARG("cq(fused)"));
-    else
-        hipLaunchKernelGGL((dec_oproj_cq_kernel<GEMV_X_PLAIN>), dim3(nA + nB), dim3(XA_TPS * 64), shm, s, p, nA, X, ldx, gamma, beta, Wp, bias, qscale, KT, Kp, Vp,
-                           item_stride, H, R, rows, group_item, part_o, part_ml, zero_cnt WLX_TR_ARG("cq(fused)"));
-    return true;
-}
-
 void launch_dec_cq_cross_attn(const float* X, long ldx, const float* gamma, const float* beta, const half_t* Wp, const float* bias,
                               float qscale, int d, const half_t* Kp, const half_t* Vp, long item_stride, int H, int R, int groups,
                               int rows, const int* group_item, half_t* part_o, float* part_ml, hipStream_t s) {

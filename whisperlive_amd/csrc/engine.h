@@ -62,7 +62,6 @@ struct Slot {
     std::vector<int> nframes;
     std::vector<int64_t> npcm;                       // samples resident per item
     unsigned* gmax = nullptr;
-    unsigned* d_oc_cnt = nullptr;                    // [dec_layers] counters of the fused projection -> cross-attention launches (decoder.hip dec_oproj_cq_kernel)
     long long* d_rng = nullptr;                      // [2 * WLX_LM_MAXRANGES] range table of the last wlx_logmel_ring
     // encoder
     half_t *featT = nullptr, *h1 = nullptr, *ln = nullptr, *q = nullptr, *k = nullptr, *vt = nullptr,

@@ -649,7 +649,6 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         CKR(slot_grow_audio(e, s, 480000));
         CKR(dalloc(s->allocs, &s->gmax, (size_t)B));
         CKR(dalloc(s->allocs, &s->d_rng, (size_t)2 * WLX_LM_MAXRANGES));
-        CKR(dalloc(s->allocs, &s->d_oc_cnt, (size_t)std::max(1, L)));
         s->featT_stride = (long)(WLX_N_FRAMES + 2) * sp.n_mels + 64;
         s->h1_stride = (long)(WLX_N_FRAMES + 2) * d;
         CKR(dalloc(s->allocs, &s->featT, (size_t)B * s->featT_stride));
@@ -1252,7 +1251,7 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
             pgemv(s.base, pq);
         }
         plaunch(s.base, "dec_self_attn2_kernel", 4.0 * rows * d * (s->prof ? s->prof->t + 1 : 1), [&] { launch_dec_self_attn(s.qd, d, kc, vc, crs, d, H, rt, rows, s.attnd, d, done, s->anc_ident, st); });
-        const GemvParams po = oproj_params(l, slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN);
+        pgemv(s.base, oproj_params(l, slabs_pending ? GEMV_X_SLABS : GEMV_X_PLAIN));
         slabs_pending = false;
         GemvParams p{};
         // LN2 + cross-attention query + cross-attention partials: one fused launch when the shape allows and nobody needs
@@ -1262,26 +1261,7 @@ static void decoder_pass(Engine* e, Slot* s_, int rows, int R, int groups, bool 
         // (not for the one-pass prompt prefill: with 14+ groups every (split, head, group) workgroup re-reads its head's 96 KiB of
         // query weights — 224 tokens: 1.49 ms fused, 1.32 ms as projection + attention, profiles/r3l_prefill_fused_cq.txt)
         const bool fused = !s->align && rows <= 48 && dec_cq_cross_attn_eligible(d, H, R);
-        // round 6: the attention output projection and that fused kernel as ONE launch (single streams: <= 16 rows, one item) — the
-        // consumer's weight / K / V requests run under the producer (decoder.hip dec_oproj_cq_kernel). WLX_FUSE_OC=0/1 (A/B).
-        static const bool fuse_oc = [] { const char* v = getenv("WLX_FUSE_OC"); return v && v[0] == '1'; }();
-        bool oc_done = false;
-        if (fuse_oc && fused && rows <= 16 && groups == 1 && !alt && !s->busy_variant) {
-            GemvParams pf = po;
-            pf.busy_device = 0;
-            const int L = sp.dec_layers;
-            auto go = [&] { return launch_dec_oproj_cq(pf, s.xd, d, w.ln2_g, w.ln2_b, w.Wcq, w.bcq, 0.125f, d, ckl, cvl, (long)WLX_T_AUDIO_PAD * d, H, R, groups, rows,
-                                                       s.d_group_item, s.part_o, s.part_ml, s->d_oc_cnt + l, s->d_oc_cnt + (l + 1) % L, st); };
-            if (!s->prof) oc_done = go();
-            else {
-                // (profiler: listed / replayed under its own name; a shape that does not take the fused form is decided without launching)
-                if (s->prof->list_only) { s->prof->recs.push_back(ProfRec{"dec_oproj_cq_kernel", gemv_bytes(po) + 2.0 * d * d + 4.0 * groups * WLX_T_AUDIO * d}); oc_done = true; }
-                else if (s->prof->only == "dec_oproj_cq_kernel") oc_done = go();
-                else oc_done = true;
-            }
-        }
-        if (!oc_done) pgemv(s.base, po);
-        if (fused && !oc_done)
+        if (fused)
             plaunch(s.base, "dec_cq_cross_attn_kernel", 2.0 * d * d + 4.0 * groups * WLX_T_AUDIO * d, [&] {
                 launch_dec_cq_cross_attn(s.xd, d, w.ln2_g, w.ln2_b, w.Wcq, w.bcq, 0.125f, d, ckl, cvl, (long)WLX_T_AUDIO_PAD * d, H, R,
                                          groups, rows, s.d_group_item, s.part_o, s.part_ml, st);
