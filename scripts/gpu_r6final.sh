@@ -23,4 +23,12 @@ timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/rocprof" -o wlx --output-f
 cd "$REPO"
 f=$(find "$OUT/rocprof" -name '*kernel_stats.csv' | head -1); [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_bench_command.csv" && head -12 "$f" | cut -c1-160
 find "$OUT/rocprof" -name '*kernel_trace.csv' -delete; find "$OUT/rocprof" -name '*.db' -delete
+# counter passes, each in its own run (kernel-trace only beside --pmc): MFMA counters of the single-window encoder; L2 hit / miss of the single-stream decode
+cd /tmp
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F16 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d "$OUT/pmc_mfma_b1" -o wlx --output-format csv -- python "$REPO/scripts/encode_only.py" small.en 2 1 > "$OUT/pmc_mfma_b1.log" 2>&1; echo "pmc mfma rc=$?"
+python "$REPO/scripts/pmc_summary.py" "$OUT/pmc_mfma_b1" 2>/dev/null | grep -E "gemm3|gemm2|attn_encoder|layernorm" > "$OUT/pmc_mfma_encoder_b1.csv"; cut -c1-150 "$OUT/pmc_mfma_encoder_b1.csv" | head -24
+timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace -d "$OUT/pmc_tcc" -o wlx --output-format csv -- python "$REPO/bench.py" --pmc-child > "$OUT/pmc_tcc.log" 2>&1; echo "pmc tcc rc=$?"
+python "$REPO/scripts/pmc_summary.py" "$OUT/pmc_tcc" 2>/dev/null | grep -E "dec_|search" > "$OUT/pmc_tcc_decode.csv"; cut -c1-150 "$OUT/pmc_tcc_decode.csv" | head -30
+cd "$REPO"
+find "$OUT" -name '*counter_collection.csv' -delete; find "$OUT" -name '*kernel_trace.csv' -delete; find "$OUT" -name '*.db' -delete
 echo "total $(( $(date +%s) - t0 )) s"; du -sh "$OUT"
