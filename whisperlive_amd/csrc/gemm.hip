@@ -354,13 +354,21 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
         if (nt >= NT_total) nt = NT_total - 1;
         asrc[j] = p.Wp + ((long)nt * KT + kk) * 512 + lane * 8;
     }
+    // Activation pieces (round 6): FULL 128-byte row segments — a piece = 8 rows x 128 B = both k-tiles of the stage — into the swizzled image the
+    // large-M form uses (LDS row p = (r % 8) * 2 + r / 8 of a 16-row tile holds row r, 16-byte slot s holds segment s ^ (r & 7); the permutation sits on
+    // the per-lane SOURCE address, the LDS side of an LDS-DMA is lane-linear). The fragment-shaped pieces this form had (16 rows x 64 B, one k-tile)
+    // touch 16 cache lines per wave-level request for the same KiB. Same fragments into the same MFMAs: identical results.
+    static_assert(KS == 2, "a stage = two k-tiles = one 128-byte segment per activation row");
 #pragma unroll
     for (int j = 0; j < CB; ++j) {
-        const int f = wave + 4 * j, mi = f / KS, kk = f % KS;
-        int row = mb + mi * 16 + c;
+        const int f = wave + 4 * j, mi = f >> 1, ph = f & 1;
+        const int r = ((lane >> 3) & 1) * 8 + ph * 4 + (lane >> 4);           // row of the 16-row tile this lane fetches
+        int row = mb + mi * 16 + r;
         if (row >= p.M) row = p.M - 1;
-        bsrc[j] = A + (long)row * p.lda + kk * 32 + g * 8;
+        bsrc[j] = A + (long)row * p.lda + (((lane & 7) ^ (r & 7)) << 3);
     }
+    const int boff0 = (((c & 7) << 1) + (c >> 3)) * 8 + ((0 + g) ^ (c & 7));    // f16x8 units inside a 16-row tile image: k-tile 0 / 1 of the stage
+    const int boff1 = (((c & 7) << 1) + (c >> 3)) * 8 + ((4 + g) ^ (c & 7));
     auto issue = [&](int st, int buf) {         // this wave's pieces of stage `st` -> ring buffer `buf`
         f16x8* dst = ring + (long)buf * (FA + FB) * 64;
 #pragma unroll
@@ -390,13 +398,14 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p) {
         __builtin_amdgcn_s_barrier();
         if (st + DEPTH - 1 < S) issue(st + DEPTH - 1, wbuf);
         const f16x8* src = ring + (long)rbuf * (FA + FB) * 64 + lane;
+        const f16x8* bsw = ring + (long)rbuf * (FA + FB) * 64 + FA * 64;
 #pragma unroll
         for (int kk = 0; kk < KS; ++kk) {
             f16x8 wf[WNT], af[WMT];
 #pragma unroll
             for (int ni = 0; ni < WNT; ++ni) wf[ni] = src[((wn * WNT + ni) * KS + kk) * 64];
 #pragma unroll
-            for (int mi = 0; mi < WMT; ++mi) af[mi] = src[(FA + (wm * WMT + mi) * KS + kk) * 64];
+            for (int mi = 0; mi < WMT; ++mi) af[mi] = bsw[(wm * WMT + mi) * 128 + (kk ? boff1 : boff0)];
 #pragma unroll
             for (int ni = 0; ni < WNT; ++ni)
 #pragma unroll
