@@ -800,29 +800,33 @@ int gemm_prepare_device() {      // once per engine, on the engine's device (wlx
     return (int)e;
 }
 
-// Tile shape of the second form, per GEMM (round 5). One window (M = 1500) on the 64 x 96 tile alone: the N = 3 d / 4 d projections are
-// 576 / 768 workgroups against the 512 that are resident together (two 64-80 KiB rings per CU x 256 CUs), i.e. TWO rounds of a
-// latency-bound stage loop — 22-27 us per launch where the N = d projection with the same K (192 workgroups, one round) takes 10 us
-// (profiles/r5d_encoder_launches_*.txt). Three shapes that all keep two workgroups per CU are instantiated — 64 x 96 (ring of 4, 80 KiB),
-// 96 x 96 (ring of 3, 72 KiB), 128 x 128 (ring of 2, 64 KiB) — and the launch takes the one with the smallest
-// rounds x (cost of one stage of that shape); ties go to the smaller tile. Results do not depend on the shape (same products, same K order).
+// Tile shape of the second form, per GEMM (round 5; cost model re-fitted in round 6). One window (M = 1500) on the 64 x 96 tile alone: the N = 3 d / 4 d
+// projections are 576 / 768 workgroups against the 512 that are resident together (two 64-80 KiB rings per CU x 256 CUs), i.e. TWO rounds of a
+// latency-bound stage loop. Three shapes that all keep two workgroups per CU are instantiated — 64 x 96 (ring of 4, 80 KiB), 96 x 96 (ring of 3,
+// 72 KiB), 128 x 128 (ring of 2, 64 KiB). Results do not depend on the shape (same products, same K order).
+//   The cost model (round 6, profiles/r6p_gemm2_shapes_by_grid.txt: every shape forced for every GEMM of small.en and large-v3, after the
+// full-line activation pieces): a launch takes (stages) x (time of one stage of the shape with ONE workgroup on the CU: 0.42 / 0.50 / 0.86 us) x
+// (occupancy), where every full round of 2 x CUs workgroups counts h2 = 1.43 / 1.45 / 1.17 — two co-resident workgroups share the CU's fill and LDS
+// paths, so they take almost twice one workgroup's time on the small tiles and overlap better on the MFMA-denser 128 x 128 — and the last, partial
+// round 1 (<= one workgroup per CU) or h2. The round-5 model (rounds of 2 x CUs, equal weight) put large-v3's N = d projections (320 workgroups)
+// on 64 x 96 at 34 us where 96 x 96 (224 workgroups, one per CU) takes 27 us. All six measured (model, GEMM) cases now get their fastest shape.
 // WLX_GEMM2_SHAPE=0/1/2 (A/B builds) forces one shape for every launch.
 static int gemm2_pick(const GemmParams& p, int zbatch) {
     static const int forced = [] { const char* e = wlx_ab("WLX_GEMM2_SHAPE"); return e ? atoi(e) : -1; }();
     if (forced >= 0 && forced <= 2) return forced;
-    static const int slots = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount; return 2 * n; }();
+    static const int cus = [] { int dev = 0, n = 256; (void)hipGetDevice(&dev); hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) n = pr.multiProcessorCount; return n; }();
     static const int wnt[3] = {2, 3, 4}, wmt[3] = {3, 3, 4};
-    // relative cost of one stage (two k-tiles): a fixed wait + barrier + issue part and the MFMAs / LDS reads of the wave tile (measured
-    // stage times: 64 x 96 ~0.7 us; the larger tiles by their MFMA count, profiles/r5e_*)
-    static const double stage[3] = {0.45 + 0.02 * 12, 0.45 + 0.02 * 18, 0.45 + 0.02 * 32};
+    static const double t1[3] = {0.42, 0.50, 0.86}, h2[3] = {1.43, 1.45, 1.17}, fixed[3] = {0.0, 0.0, 1.5};
     const bool scatter = p.mode == GEMM_QKV || p.mode == GEMM_CROSS_KV;
+    const double stages = (double)(p.KT / 2);
     int best = 0;
     double best_cost = 1e300;
     for (int i = 0; i < 3; ++i) {
         if (scatter && p.d % (32 * wnt[i]) != 0) continue;             // the LDS-transposed epilogue needs q / k / v boundaries on tile boundaries
         const long wgs = (long)((p.N + 32 * wnt[i] - 1) / (32 * wnt[i])) * ((p.M + 32 * wmt[i] - 1) / (32 * wmt[i])) * zbatch;
-        const long rounds = (wgs + slots - 1) / slots;
-        const double cost = (double)rounds * stage[i];
+        const long full = wgs / (2 * cus), rem = wgs - full * 2 * cus;
+        const double occ = (double)full * h2[i] + (rem == 0 ? 0.0 : rem <= cus ? 1.0 : h2[i]);
+        const double cost = fixed[i] + stages * t1[i] * occ;
         if (cost < best_cost - 1e-9) { best_cost = cost; best = i; }
     }
     return best;
