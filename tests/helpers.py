@@ -134,10 +134,12 @@ def check_decode(oracle, enc, slot, ids, prompt, what, *, require_exact=True, no
     * tokens differ, require_exact (a case PINNED as well-conditioned by scripts/scan_peaked_seeds.py: the oracle's own result
       survives +-0.02 of noise on every logit, far above any BLAS summation-order difference between hosts) -> fail. No
       near-tie escape.
-    * tokens differ, not pinned: the noise test runs now. A well-conditioned case fails; otherwise (a near-tie on the oracle's
-      own decision path) the GPU's sequence must be an equally good hypothesis UNDER THE ORACLE (within 5e-2 of the oracle's
-      best cumulative score — on peaked weights alternatives are O(1) apart) and its reported score the oracle's evaluation
-      of the same tokens."""
+    * tokens differ, not pinned: a near-tie has to be SHOWN. Either the oracle's cumulative log-probability of the GPU's tokens is
+      within 2 * noise_amp of its own best (the most a +-noise_amp perturbation of ONE step's logits moves the difference of two
+      hypotheses: such a pair is a near-tie by the noise criterion's own definition, whether or not two random seeds happen to
+      flip it), or the noise test flips the oracle's result. A well-conditioned case fails. In both cases the GPU's sequence must
+      be an equally good hypothesis UNDER THE ORACLE (within 5e-2 of the oracle's best cumulative score — on peaked weights
+      alternatives are O(1) apart) and its reported score the oracle's evaluation of the same tokens."""
     opts = odec.GenOptions(ids=ids, **kw)
     check_decode.oracle_cum_of_gpu_tokens = None
     got = slot.generate([prompt], engine_ids(ids), enc_items=enc_items, **kw)[0]
@@ -155,12 +157,15 @@ def check_decode(oracle, enc, slot, ids, prompt, what, *, require_exact=True, no
     else:
         diff = (what, "first difference at", n, g[max(0, n - 2): n + 3], r[max(0, n - 2): n + 3])
         assert not require_exact, diff
-        assert not decode_is_well_conditioned(oracle, enc, prompt, opts, ref, noise_amp, seeds=noise_seeds), diff
         cum = oracle_sequence_logprob(oracle, enc, ids, prompt, g, opts, what)
         check_decode.oracle_cum_of_gpu_tokens = cum
         denom = float(max(len(g), 1)) ** float(kw.get("length_penalty", 1.0))
+        ref_cum = ref.scores[0] * float(max(len(r), 1)) ** float(kw.get("length_penalty", 1.0))
+        print(what, "oracle cumulative log-prob: its own best", ref_cum, "the GPU's tokens", cum)
+        if not (len(g) == len(r) and abs(ref_cum - cum) <= 2.0 * noise_amp):
+            assert not decode_is_well_conditioned(oracle, enc, prompt, opts, ref, noise_amp, seeds=noise_seeds), diff
         assert abs(got.scores[0] - cum / denom) <= tol, (what, got.scores[0], cum / denom)
-        assert len(g) == len(r) and cum >= ref.scores[0] * max(len(r), 1) - 5e-2, (what, n, cum, ref.scores[0] * len(r))
+        assert len(g) == len(r) and cum >= ref_cum - 5e-2, (what, n, cum, ref_cum)
     assert abs(got.no_speech_prob - ref.no_speech_prob) <= 2e-3 + 0.02 * ref.no_speech_prob
     check_decode.last = dict(gpu_score=float(got.scores[0]), oracle_score=float(ref.scores[0]), gpu_tokens=list(g), oracle_tokens=list(r))
     return n, len(r), exact

@@ -1586,10 +1586,10 @@ void launch_dec_gemv(const GemvParams& p_any, hipStream_t s) {
 // One wave per (row, head); positions 0..pos[row]; the history of a row is read through the ancestry table.
 // Flash-style over blocks of 64 positions so one rolled loop serves every length (code size is latency here: the
 // two-pass form was 4.6 KiB of straight-line code, ~1.8 us of cold instruction fetch per launch):
-//   per block: lane p looks up the cache row of position p (one dependent trip), then the K rows (lane = position, whole
-//   128-byte row) AND the V rows (lane = (position group pg, 8-dim chunk dc)) are requested together — one more trip —,
-//   scores by in-lane dot product, block max / sum by DPP, probabilities through LDS to the (pg, dc) lanes, which
-//   accumulate their 8 dims over their 8 positions with the running-max rescale.
+//   per block: lane p looks up the cache row of position p (one dependent trip), then the K and the V rows are requested together — one
+//   more trip —, both as lane = (position group pg, 8-dim chunk dc): 8 positions x a whole 128-byte row per load instruction (round 6; the
+//   K rows were lane = position before), scores = 8 dims in the lane + a 3-step DPP butterfly over the 8 dc lanes, block max / sum by DPP,
+//   and the (pg, dc) lanes accumulate their 8 dims over their 8 positions with the running-max rescale (their probabilities are in-lane).
 //   tail: the 8 position groups are summed through LDS, lane d writes output dim d.
 // IDENT: the rows read their history through their OWN ancestry row (every decode step; prefill rows share one): the
 // ancestry row address then needs no table lookup, so the first block's cache-row lookup is requested at once, next to
@@ -1613,7 +1613,6 @@ __global__ __launch_bounds__(64 * SA_NW) void dec_self_attn2_kernel(const half_t
                                                                     const int* __restrict__ ancrow,
                                                                     const short* __restrict__ anc,
                                                                     half_t* __restrict__ out, long ldo WLX_TR_PARAM) {
-    __shared__ float prob_s[SA_NW][64];
     __shared__ int crow_s[SA_NW][64];
     __shared__ float part_s[SA_NW][8][64];
     __shared__ float ml_s[SA_NW][2];
@@ -1630,13 +1629,15 @@ __global__ __launch_bounds__(64 * SA_NW) void dec_self_attn2_kernel(const half_t
     const int len = pos[r] + 1;
     const int nblk = (len + 63) >> 6;
     if (w >= nblk) return;                                  // (wave 0 always stays: len >= 1)
-    float* prob = prob_s[w];
     int* crow = crow_s[w];
-    f16x8 qv[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) qv[i] = ld_f16x8(q + (long)r * ldq + h * WLX_HEAD_DIM + i * 8);
     const int pg = lane >> 3, dc = lane & 7;
     const int hoff = h * WLX_HEAD_DIM;
+    float qf[8];                                            // this lane's 8 query dims (dc * 8 ..)
+    {
+        const f16x8 qv = ld_f16x8(q + (long)r * ldq + hoff + dc * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) qf[e] = (float)qv[e];
+    }
     const int icrs = (int)crs;                             // 32-bit element offsets: cache_rows * 448 * d < 2^31
     float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     float mrun = WLX_NEG_INF, lrun = 0.f;
@@ -1648,41 +1649,47 @@ __global__ __launch_bounds__(64 * SA_NW) void dec_self_attn2_kernel(const half_t
         int cr;
         if (IDENT && p0 == w * 64) cr = ok ? cr0 : __builtin_amdgcn_readlane(cr0, 0);  // (a masked lane: any valid row — the block's first position's)
         else cr = ar[ok ? p : len - 1];
-        crow[lane] = cr;
-        // K row of position p (lane = position); the LDS write above is visible to this same wave after the wait below
-        const half_t* kp = Kc + (unsigned)(cr * icrs + (ok ? p : len - 1) * d + hoff);
-        f16x8 kv[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) kv[i] = ld_f16x8(kp + i * 8);
-        // V chunks: positions p0 + u*8 + pg, dims dc*8 .. dc*8+7
-        f16x8 vv[8];
+        crow[lane] = cr;                                    // (visible to this same wave after the wait the reads below carry)
+        // K AND V chunks, the same element offsets in both caches: lane (pg, dc) takes dims dc*8 .. dc*8+7 of positions p0 + u*8 + pg, so a
+        // load instruction covers 8 positions x one whole 128-byte row each = 8 cache lines. (Through round 5 the K rows were read lane =
+        // position, 16 bytes of 64 different lines per instruction, eight times over: the step grew 48 us from position 8 to 447, twice what the
+        // bytes cost — profiles/r6b_step_by_position.txt.)
+        f16x8 kk[8], vv[8];
+        bool okp[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int pp = p0 + u * 8 + pg;
-            const int pc = (pp < len) ? pp : len - 1;
-            vv[u] = ld_f16x8(Vc + (unsigned)(crow[u * 8 + pg] * icrs + pc * d + hoff + dc * 8));
+            okp[u] = pp < len;
+            const unsigned off = (unsigned)(crow[u * 8 + pg] * icrs + (okp[u] ? pp : len - 1) * d + hoff + dc * 8);
+            kk[u] = ld_f16x8(Kc + off);
+            vv[u] = ld_f16x8(Vc + off);
         }
-        float sc = 0.f;
+        // scores: 8 dims in the lane, then the 8 dc lanes of a position summed by a 3-step butterfly (all 8 end with the same bits)
+        float sc[8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int u = 0; u < 8; ++u) {
+            float a = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sc = fmaf((float)kv[i][e], (float)qv[i][e], sc);
-        sc = ok ? sc : WLX_NEG_INF;
-        const float bmax = dpp_wave_max(sc);
-        const float mnew = fmaxf(mrun, bmax);               // finite: position p0 is valid
+            for (int e = 0; e < 8; ++e) a = fmaf((float)kk[u][e], qf[e], a);
+            sc[u] = a;
+        }
+        WLX_DPP_SUM8x8(sc);
+        float bm = WLX_NEG_INF;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { sc[u] = okp[u] ? sc[u] : WLX_NEG_INF; bm = fmaxf(bm, sc[u]); }
+        const float mnew = fmaxf(mrun, dpp_wave_max(bm));   // finite: position p0 is valid
         const float alpha = __expf(mrun - mnew);
-        const float pe = __expf(sc - mnew);                 // 0 for masked lanes
-        lrun = lrun * alpha + dpp_wave_sum(pe);
+        float pe[8], bs = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { pe[u] = __expf(sc[u] - mnew); bs += pe[u]; }   // 0 for masked positions
+        lrun = lrun * alpha + dpp_wave_sum(dc == 0 ? bs : 0.f);                      // (each position once: its dc = 0 lane)
         mrun = mnew;
-        prob[lane] = pe;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] *= alpha;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const float pr = prob[u * 8 + pg];
+        for (int u = 0; u < 8; ++u)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = fmaf(pr, (float)vv[u][e], o[e]);
-        }
+            for (int e = 0; e < 8; ++e) o[e] = fmaf(pe[u], (float)vv[u][e], o[e]);
     }
     WLX_TR_MARK(2);
     // sum the 8 position groups: part[pg][dim]; lane d then owns output dim d
