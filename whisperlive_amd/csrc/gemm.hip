@@ -860,11 +860,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     const float4* xr = reinterpret_cast<const float4*>(x + (long)row * ldx);
     const int n4 = d >> 2;
     float4 v[8];  // d <= 2048
+    float4 gv[8], bv[8];                 // gamma / beta requested WITH the row (round 6): they were loaded in the last loop, a second dependent
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);      // round trip behind the two reductions, in a kernel that is one trip long
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        int j = lane + i * 64;
+        if (j < n4) { v[i] = xr[j]; gv[i] = g4[j]; bv[i] = b4[j]; }
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         int j = lane + i * 64;
-        if (j < n4) { v[i] = xr[j]; s += v[i].x + v[i].y + v[i].z + v[i].w; }
+        if (j < n4) s += v[i].x + v[i].y + v[i].z + v[i].w;
     }
     const float mean = wave_sum(s) / (float)d;
     float q = 0.f;
@@ -877,13 +885,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         }
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)d + 1e-5f);
-    const float4* g4 = reinterpret_cast<const float4*>(gamma);
-    const float4* b4 = reinterpret_cast<const float4*>(beta);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         int j = lane + i * 64;
         if (j < n4) {
-            float4 gg = g4[j], bb = b4[j];
+            const float4 gg = gv[i], bb = bv[i];
             float o0 = (v[i].x - mean) * rstd * gg.x + bb.x;
             float o1 = (v[i].y - mean) * rstd * gg.y + bb.y;
             float o2 = (v[i].z - mean) * rstd * gg.z + bb.z;
