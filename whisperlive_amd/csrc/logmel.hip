@@ -166,20 +166,21 @@ void launch_logmel(const float* pcm, long n, int n_mels, const LogmelConsts& c, 
 // strides, the windows' (seek, seg) in a by-value table (12 launches of 10 us in front of a 12-window encoder -> one)
 __global__ __launch_bounds__(256) void prep_window_kernel(const float* __restrict__ feats0, long ld, int n_mels, long item_stride,
                                                           PrepWindows w, half_t* __restrict__ featT0, long featT_stride) {
-    __shared__ float tile[128][65];
+    // 32 frames per block (round 6; 64 before: 47 workgroups per window, a 10.7 us launch that is one latency chain long — 94 halve its trips)
+    __shared__ float tile[128][33];
     const int item = blockIdx.y;
     const float* __restrict__ feats = feats0 + (long)item * item_stride;
     half_t* __restrict__ featT = featT0 + (long)item * featT_stride;
     const int seek = w.seek[item], seg = w.seg[item];
-    const int tb = blockIdx.x * 64;  // 64 frames per block
+    const int tb = blockIdx.x * 32;
     const int tid = threadIdx.x;
-    for (int i = tid; i < n_mels * 64; i += 256) {
-        int m = i >> 6, tl = i & 63;
+    for (int i = tid; i < n_mels * 32; i += 256) {
+        int m = i >> 5, tl = i & 31;
         int t = tb + tl;
         tile[m][tl] = (t < seg) ? feats[(long)m * ld + seek + t] : 0.0f;
     }
     __syncthreads();
-    for (int i = tid; i < n_mels * 64; i += 256) {
+    for (int i = tid; i < n_mels * 32; i += 256) {
         int tl = i / n_mels, m = i - tl * n_mels;
         int t = tb + tl;
         if (t < WLX_N_FRAMES) featT[(long)(1 + t) * n_mels + m] = (half_t)tile[m][tl];
@@ -188,7 +189,7 @@ __global__ __launch_bounds__(256) void prep_window_kernel(const float* __restric
 
 void launch_prep_windows(const float* feats0, long ld, int n_mels, long item_stride, const PrepWindows& w, int items,
                          half_t* featT0, long featT_stride, hipStream_t s) {
-    int blocks = (WLX_N_FRAMES + 63) / 64;
+    int blocks = (WLX_N_FRAMES + 31) / 32;
     hipLaunchKernelGGL(prep_window_kernel, dim3(blocks, items), dim3(256), 0, s, feats0, ld, n_mels, item_stride, w, featT0, featT_stride);
 }
 
