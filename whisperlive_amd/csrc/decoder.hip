@@ -1599,33 +1599,37 @@ void launch_dec_gemv(const GemvParams& p_any, hipStream_t s) {
 // (ancestry -> K / V -> softmax): a step at positions 225..288 (a window conditioned on the reference's full prompt) cost
 // 6.4 us per layer here against 2.9 us at t = 32. Histories of <= 64 positions run exactly as before on wave 0 — the other
 // waves leave at once, and ended waves do not count at the barrier.
-// (Round 6, measured and dropped: twice the waves — one block of 64 positions per wave up to the 448-position context — for passes whose
-// positions pass 256. A step at positions 200 / 300 / 447 costs 398 / 412 / 425 us either way (profiles/r6b_step_by_position.txt): what
-// grows with the history is the K fetch (lane = position: every load instruction touches 64 cache lines), not the second trip.)
+// Round 6: EIGHT waves — one block of 64 positions per wave up to the 448-position context, no wave walks a second block. Measured twice: with
+// the K rows fetched lane = position a step at positions 200 / 300 / 447 cost 398 / 412 / 425 us with 4 or 8 waves (profiles/r6b_*: the K fetch
+// was what grew); with whole-row K fetches 390 / 408 / 411 us with 4 waves and 390 / 396 / 402 with 8 (profiles/r6w_step_by_position_sa8.txt) —
+// now the second dependent trip is what is left. Histories of <= 256 positions are bit-identical to the 4-wave form (same blocks, same merge order).
+// The decode steps (IDENT) run 8 waves; the prompt prefill (<= 228 positions, thousands of workgroups) keeps 4 — with 8 its 224-token pass
+// measured 0.94 against 0.91 ms (four waves per workgroup launched only to leave).
+#define SA_PF_NW 4       // the non-IDENT passes (prompt prefill, teacher-forced rows) and batched steps (> 16 rows)
 #ifndef SA_NW
-#define SA_NW 4          // -DSA_NW=1 (whisperlive_amd/_lib.py build_variant) = the one-wave form, for A/B
+#define SA_NW 8          // -DSA_NW=1 / 4 (whisperlive_amd/_lib.py build_variant) = the one- / four-wave forms of the decode steps, for A/B
 #endif
-template <bool IDENT>
-__global__ __launch_bounds__(64 * SA_NW) void dec_self_attn2_kernel(const half_t* __restrict__ q, long ldq,
+template <bool IDENT, int NW>
+__global__ __launch_bounds__(64 * NW) void dec_self_attn2_kernel(const half_t* __restrict__ q, long ldq,
                                                                     const half_t* __restrict__ Kc,
                                                                     const half_t* __restrict__ Vc, long crs, int d,
                                                                     const int* __restrict__ pos,
                                                                     const int* __restrict__ ancrow,
                                                                     const short* __restrict__ anc,
                                                                     half_t* __restrict__ out, long ldo WLX_TR_PARAM) {
-    __shared__ int crow_s[SA_NW][64];
-    __shared__ float part_s[SA_NW][8][64];
-    __shared__ float ml_s[SA_NW][2];
+    __shared__ int crow_s[NW][64];
+    __shared__ float part_s[NW][8][64];
+    __shared__ float ml_s[NW][2];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = blockIdx.x, h = blockIdx.y;
     WLX_TR_BEGIN();
     // the cache rows of this wave's FIRST block, requested together with the row's position, before anything depends on either
-    // (w * 64 + lane < 64 SA_NW <= 448: always inside the ancestry row, whatever the history length turns out to be) — without it
+    // (clamped to the ancestry row's 448 entries, whatever the history length turns out to be) — without it
     // the waves of the later blocks paid a second dependent round trip (position -> ancestry -> K / V)
     const short* ar = anc + (long)(IDENT ? r : ancrow[r]) * WLX_T_TEXT;
     int cr0 = 0;
-    if constexpr (IDENT) cr0 = ar[w * 64 + lane];
+    if constexpr (IDENT) cr0 = ar[(w * 64 + lane < WLX_T_TEXT) ? w * 64 + lane : WLX_T_TEXT - 1];   // (8 x 64 > 448: the last wave's lanes past the row)
     const int len = pos[r] + 1;
     const int nblk = (len + 63) >> 6;
     if (w >= nblk) return;                                  // (wave 0 always stays: len >= 1)
@@ -1643,7 +1647,7 @@ __global__ __launch_bounds__(64 * SA_NW) void dec_self_attn2_kernel(const half_t
     float mrun = WLX_NEG_INF, lrun = 0.f;
     WLX_TR_MARK(1);
 #pragma unroll 1
-    for (int p0 = w * 64; p0 < len; p0 += 64 * SA_NW) {
+    for (int p0 = w * 64; p0 < len; p0 += 64 * NW) {
         const int p = p0 + lane;
         const bool ok = p < len;
         int cr;
@@ -1706,7 +1710,7 @@ __global__ __launch_bounds__(64 * SA_NW) void dec_self_attn2_kernel(const half_t
         if (lane == 0) { ml_s[w][0] = mrun; ml_s[w][1] = lrun; }
         __syncthreads();                                    // the waves that left at the top do not count
         if (w == 0) {
-            const int nw = nblk < SA_NW ? nblk : SA_NW;
+            const int nw = nblk < NW ? nblk : NW;
             float m = ml_s[0][0];
             for (int k = 1; k < nw; ++k) m = fmaxf(m, ml_s[k][0]);
             float L = 0.f, O = 0.f;
@@ -1725,11 +1729,16 @@ __global__ __launch_bounds__(64 * SA_NW) void dec_self_attn2_kernel(const half_t
 void launch_dec_self_attn(const half_t* q, long ldq, const half_t* Kc, const half_t* Vc, long crs, int d, int H,
                           const RowTables& rt, int rows, half_t* out, long ldo, const int* done, bool ident_ancestry, hipStream_t s) {
     (void)done;   // a step that runs after the search raised `done` only rewrites scratch (engine.hip decoder_pass)
-    if (ident_ancestry)
-        hipLaunchKernelGGL(dec_self_attn2_kernel<true>, dim3(rows, H), dim3(64 * SA_NW), 0, s, q, ldq, Kc, Vc, crs, d, rt.pos,
+    // 8 waves for the steps of one stream (<= 16 rows: up to 16 x H workgroups, the launch is one latency chain long); batched steps (hundreds of
+    // rows x H workgroups) keep 4, like the prefill: their extra waves would only be launched to leave
+    if (ident_ancestry && rows <= 16)
+        hipLaunchKernelGGL((dec_self_attn2_kernel<true, SA_NW>), dim3(rows, H), dim3(64 * SA_NW), 0, s, q, ldq, Kc, Vc, crs, d, rt.pos,
+                           rt.ancrow, rt.anc, out, ldo WLX_TR_ARG("self_attn"));
+    else if (ident_ancestry)
+        hipLaunchKernelGGL((dec_self_attn2_kernel<true, SA_PF_NW>), dim3(rows, H), dim3(64 * SA_PF_NW), 0, s, q, ldq, Kc, Vc, crs, d, rt.pos,
                            rt.ancrow, rt.anc, out, ldo WLX_TR_ARG("self_attn"));
     else
-        hipLaunchKernelGGL(dec_self_attn2_kernel<false>, dim3(rows, H), dim3(64 * SA_NW), 0, s, q, ldq, Kc, Vc, crs, d, rt.pos,
+        hipLaunchKernelGGL((dec_self_attn2_kernel<false, SA_PF_NW>), dim3(rows, H), dim3(64 * SA_PF_NW), 0, s, q, ldq, Kc, Vc, crs, d, rt.pos,
                            rt.ancrow, rt.anc, out, ldo WLX_TR_ARG("self_attn"));
 }
 
