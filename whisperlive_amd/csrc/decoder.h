@@ -175,7 +175,7 @@ void launch_search_update(const SearchParams* sp_dev, int items, const SearchSta
 // beam mode: (chunks x rows) scan workgroups + one merge/update workgroup per item (rule state carried in SearchState::rule)
 void launch_search_scan3(const float* logits, long ldl, int V, const SearchParams* sp_dev, int rows, const SearchState& st,
                          hipStream_t s);
-void launch_search_merge_update3(const float* logits, long ldl, int V, const SearchParams* sp_dev, int items,
+void launch_search_merge_update3(const float* logits, long ldl, int V, const SearchParams* sp_dev, int items, int R,
                                  const SearchState& st, hipStream_t s);
 // zero the per-call search state (step, done, finished counters, per-item / per-row flags, hypothesis lengths)
 void launch_search_reset(const SearchState& st, int items, int rows, hipStream_t s);

@@ -1418,13 +1418,13 @@ static int set_anc_rows(Slot* s, const std::vector<short>& anc_host, int first_r
 
 // token search of one step: beam mode runs the chunked scan + merge/update pair, sampling (T > 0 fallback)
 // the one-workgroup-per-row kernels
-static void launch_search(Engine* e, Slot* s, int rows, int groups, bool sampling) {
+static void launch_search(Engine* e, Slot* s, int rows, int R, int groups, bool sampling) {
     if (sampling || g_decode_v1) {
         launch_search_rows(s->logits, s->d_sp, rows, s->st, s->stream);
         launch_search_update(s->d_sp, groups, s->st, s->stream);
     } else {
         launch_search_scan3(s->logits, s->ldl, e->spec.vocab, s->d_sp, rows, s->st, s->stream);
-        launch_search_merge_update3(s->logits, s->ldl, e->spec.vocab, s->d_sp, groups, s->st, s->stream);
+        launch_search_merge_update3(s->logits, s->ldl, e->spec.vocab, s->d_sp, groups, R, s->st, s->stream);
     }
 }
 
@@ -1441,7 +1441,7 @@ static int get_step_graph(Engine* e, Slot* s, int rows, int R, int groups, bool 
     CK(hipGetLastError());
     CK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
     decoder_pass(e, s, rows, R, groups, true, true);
-    launch_search(e, s, rows, groups, sampling);
+    launch_search(e, s, rows, R, groups, sampling);
     const hipError_t ce = hipStreamEndCapture(s->stream, &graph);
     if (ce != hipSuccess) {
         // An invalidated capture leaves the stream refusing every later operation ("previous error during capture"), so
@@ -1474,7 +1474,7 @@ static int run_step(Engine* e, Slot* s, int rows, int R, int groups, bool sampli
     } else {
         s->busy_variant = device_is_busy(s);
         decoder_pass(e, s, rows, R, groups, true, true);
-        launch_search(e, s, rows, groups, sampling);
+        launch_search(e, s, rows, R, groups, sampling);
         CK(hipGetLastError());
     }
     return WLX_OK;
@@ -1698,7 +1698,7 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
             launch_dec_embed(e->tok_emb16, e->dec_pos, e->spec.d_model, rt, rows, s->xd, nullptr, st);
             CK(hipMemcpy2DAsync(s->logits, (size_t)s->ldl * 4, inj + (size_t)step * rows * V, (size_t)V * 4, (size_t)V * 4, rows,
                                 hipMemcpyHostToDevice, st));
-            launch_search(e, s, rows, batch, sampling);
+            launch_search(e, s, rows, R, batch, sampling);
             CK(hipGetLastError());
         } else {
             const double ta = gen_trace ? now_us() : 0.0;
@@ -2130,7 +2130,7 @@ extern "C" int32_t wlx_debug_trace_step(wlx_engine* e, int32_t slot, int32_t row
       decoder_pass(e, s, rows, tR, tG, true, true); g_trace_seq = seq0; g_trace_buf = b0; }
     CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
     decoder_pass(e, s, rows, tR, tG, true, true);
-    if (with_search) launch_search(e, s, rows, tG, false);
+    if (with_search) launch_search(e, s, rows, tR, tG, false);
     CK(hipStreamEndCapture(st, &graph));
     CK(hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     CK(hipGraphDestroy(graph));

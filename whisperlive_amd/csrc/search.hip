@@ -677,33 +677,43 @@ __global__ __launch_bounds__(SC_THREADS) void search_scan3_kernel(const float* _
     float* cv = st.scan_cv + ((long)r * (SC_MAXCH + 1) + chunk) * WLX_MAX_CAND;
     int* ci = st.scan_ci + ((long)r * (SC_MAXCH + 1) + chunk) * WLX_MAX_CAND;
     {
-        float bv = WLX_NEG_INF; int bi = 0x7fffffff;
+        // every lane's best AND second best of its 8 ids (ids ascend with i: the first maximum is the smallest id). A lane that wins a round
+        // moves its second best up; only a lane that wins AGAIN rescans its ids (round 6: the rescan — ~60 instructions under one lane's exec
+        // mask — ran after every round; 10 winners over 64 lanes mostly come from different lanes)
+        float bv = WLX_NEG_INF, cv2 = WLX_NEG_INF; int bi = 0x7fffffff, ci2 = 0x7fffffff;
 #pragma unroll
         for (int i = 0; i < SC_NPT; ++i) {
             const int id = id0 + i * SC_THREADS + tid;
-            if (w[i] > bv) { bv = w[i]; bi = id; }        // ids ascend with i: first max = smallest id
+            if (w[i] > bv) { cv2 = bv; ci2 = bi; bv = w[i]; bi = id; }
+            else if (w[i] > cv2) { cv2 = w[i]; ci2 = id; }
         }
+        int won = 0;
 #pragma unroll 1
         for (int k = 0; k < sp.ncand; ++k) {
             float gv = bv; int gi = bi;
             s3_wave_argmax(gv, gi);
             if (lane == 0) { wv_s[wave][k] = gv; wi_s[wave][k] = gi; }
             if (gi != 0x7fffffff && ((gi - id0) & (SC_THREADS - 1)) == tid) {
-                // the owner retires the winner and finds its next best: pairwise tree (depth 3) instead of a chain of 8;
-                // a tie keeps the LEFT operand = the smaller id (ids ascend with i)
-                float tv[SC_NPT]; int ti_[SC_NPT];
 #pragma unroll
-                for (int i = 0; i < SC_NPT; ++i) {
-                    const int id = id0 + i * SC_THREADS + tid;
-                    if (id == gi) w[i] = WLX_NEG_INF;
-                    tv[i] = w[i]; ti_[i] = (w[i] > WLX_NEG_INF) ? id : 0x7fffffff;
+                for (int i = 0; i < SC_NPT; ++i)
+                    if (id0 + i * SC_THREADS + tid == gi) w[i] = WLX_NEG_INF;        // the owner retires the winner
+                if (won == 0) { bv = cv2; bi = ci2; }
+                else {
+                    // its next best: pairwise tree (depth 3) instead of a chain of 8; a tie keeps the LEFT operand = the smaller id
+                    float tv[SC_NPT]; int ti_[SC_NPT];
+#pragma unroll
+                    for (int i = 0; i < SC_NPT; ++i) {
+                        const int id = id0 + i * SC_THREADS + tid;
+                        tv[i] = w[i]; ti_[i] = (w[i] > WLX_NEG_INF) ? id : 0x7fffffff;
+                    }
+#pragma unroll
+                    for (int stp = 1; stp < SC_NPT; stp <<= 1)
+#pragma unroll
+                        for (int i = 0; i + stp < SC_NPT; i += 2 * stp)
+                            if (tv[i + stp] > tv[i]) { tv[i] = tv[i + stp]; ti_[i] = ti_[i + stp]; }
+                    bv = tv[0]; bi = ti_[0];
                 }
-#pragma unroll
-                for (int stp = 1; stp < SC_NPT; stp <<= 1)
-#pragma unroll
-                    for (int i = 0; i + stp < SC_NPT; i += 2 * stp)
-                        if (tv[i + stp] > tv[i]) { tv[i] = tv[i + stp]; ti_[i] = ti_[i + stp]; }
-                bv = tv[0]; bi = ti_[0];
+                ++won;
             }
         }
         WLX_TR_MARK(3);
@@ -746,22 +756,45 @@ void launch_search_scan3(const float* logits, long ldl, int V, const SearchParam
 }
 
 #define MU3_THREADS 384
+// Round 6: the kernel was 11 us of ONE workgroup per step — five dependent round trips in front of its first phase (done flag -> parameters ->
+// item state -> lists -> the row's cumulative score), and its bookkeeping as a serial loop of one thread over LDS (profiles/r6i_decode_step_trace.txt:
+// 5.9 us to the end of phase 1, 5.1 us more for the beam merge and the loop). Now R (rows per item: part of the step graph's key) is a launch
+// argument, so every address of the first phase is known at entry: the flag, the parameters, the item state AND the first row's chunk lists,
+// statistics, cumulative score are requested together — one trip; the bookkeeping runs one candidate per lane (the serial loop's counters are
+// prefix counts: ballots), the finished hypotheses' length penalties in parallel.
 __global__ __launch_bounds__(MU3_THREADS) void search_merge_update3_kernel(const float* __restrict__ logits, long ldl, int V,
-                                                                           const SearchParams* __restrict__ spp, SearchState st WLX_TR_PARAM) {
-    if (*st.done) return;
-    WLX_TR_BEGIN();
-    const SearchParams sp = *spp;
+                                                                           const SearchParams* __restrict__ spp, SearchState st, int R WLX_TR_PARAM) {
     const int item = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int NW = MU3_THREADS / 64;
+    constexpr int PQ = 3;                        // list quads requested at entry: 12 candidates (beam <= 6); wider beams fetch the rest below
+    const int r0 = item * R;
+    // ---------------- everything phase 1 needs, requested before anything is used
+    const int done_v = *st.done;
+    const int idone = st.item_done[item];
+    const int plen = st.plen[item];
+    const int p = st.pos[r0];
+    const int n_hyp0 = st.n_hyp[item];
+    const int rp = r0 + (wave < R ? wave : R - 1);          // this wave's first row (the loop below runs it only if wave < beam <= R)
+    const int lc = lane < SC_MAXCH ? lane : SC_MAXCH - 1;   // (lanes past the chunk count: any valid list — masked below)
+    const float4* pso = reinterpret_cast<const float4*>(st.scan_stats + ((long)rp * SC_MAXCH + lc) * SC_NSTAT);
+    const float4 ps0 = pso[0], ps1 = pso[1];
+    const float4* pcv = reinterpret_cast<const float4*>(st.scan_cv + ((long)rp * (SC_MAXCH + 1) + lc) * WLX_MAX_CAND);
+    const int4* pci = reinterpret_cast<const int4*>(st.scan_ci + ((long)rp * (SC_MAXCH + 1) + lc) * WLX_MAX_CAND);
+    float4 pa[PQ]; int4 pb[PQ];
+#pragma unroll
+    for (int k = 0; k < PQ; ++k) { pa[k] = pcv[k]; pb[k] = pci[k]; }
+    const float pcum = st.cum[rp];
+    const int pnsp = st.nsp_row[rp];
+    const SearchParams sp = *spp;
+    if (done_v) return;
+    WLX_TR_BEGIN();
     int step_no = 0;                             // (item 0, thread 0) this launch's number, 1-based (step_mirror)
     if (item == 0 && tid == 0) step_no = atomicAdd(st.step, 1) + 1;
-    if (st.item_done[item]) { if (step_no) step_mirror(st, step_no); return; }
-    const int r0 = item * sp.R;
-    const int plen = st.plen[item];
+    if (idone) { if (step_no) step_mirror(st, step_no); return; }
     int id0_, lim_, nct, nch;
     s3_chunk(0, sp.ts_begin, V, id0_, lim_, nct, nch);
-    constexpr int NW = MU3_THREADS / 64;
 
     __shared__ float cand_s[16][WLX_MAX_CAND];
     __shared__ int cand_t[16][WLX_MAX_CAND];
@@ -776,8 +809,7 @@ __global__ __launch_bounds__(MU3_THREADS) void search_merge_update3_kernel(const
     __shared__ float ord_s[WLX_MAX_CAND];
     __shared__ int4 rule_old[16];
 
-    // the item's ancestry rows (old state) and rule state: requested first, used last
-    const int p = st.pos[r0];
+    // the item's ancestry rows (old state) and rule state: requested now, used last
     for (int i = tid; i < sp.beam * (p + 1); i += MU3_THREADS) {
         const int b = i / (p + 1), q = i - b * (p + 1);
         anc_s[b * WLX_T_TEXT + q] = st.anc[(long)(r0 + b) * WLX_T_TEXT + q];
@@ -790,30 +822,41 @@ __global__ __launch_bounds__(MU3_THREADS) void search_merge_update3_kernel(const
 #pragma unroll 1
     for (int rb = wave; rb < sp.beam; rb += NW) {
         const int r = r0 + rb;
-        float4 s0 = make_float4(WLX_NEG_INF, 0.f, WLX_NEG_INF, 0.f), s1 = make_float4(WLX_NEG_INF, 0.f, 0.f, 0.f);
-        if (lane < nch) {
-            const float4* so = reinterpret_cast<const float4*>(st.scan_stats + ((long)r * SC_MAXCH + lane) * SC_NSTAT);
-            s0 = so[0]; s1 = so[1];
-        }
+        const bool first = rb == wave;           // (wave-uniform) the row whose lists were requested at entry
         const bool have = lane < nch;
-        if (lane < nch) {
-            const int src = lane;
-            const float4* cv = reinterpret_cast<const float4*>(st.scan_cv + ((long)r * (SC_MAXCH + 1) + src) * WLX_MAX_CAND);
-            const int4* ci = reinterpret_cast<const int4*>(st.scan_ci + ((long)r * (SC_MAXCH + 1) + src) * WLX_MAX_CAND);
+        float4 s0 = make_float4(WLX_NEG_INF, 0.f, WLX_NEG_INF, 0.f), s1 = make_float4(WLX_NEG_INF, 0.f, 0.f, 0.f);
+        float cum_r; int nsp_r;
+        {
+            const float4* cv = reinterpret_cast<const float4*>(st.scan_cv + ((long)r * (SC_MAXCH + 1) + lc) * WLX_MAX_CAND);
+            const int4* ci = reinterpret_cast<const int4*>(st.scan_ci + ((long)r * (SC_MAXCH + 1) + lc) * WLX_MAX_CAND);
             float4 a[WLX_MAX_CAND / 4]; int4 b[WLX_MAX_CAND / 4];
+            if (first) {
+#pragma unroll
+                for (int k = 0; k < PQ; ++k) { a[k] = pa[k]; b[k] = pb[k]; }
+#pragma unroll
+                for (int k = PQ; k < WLX_MAX_CAND / 4; ++k)
+                    if (k < nc4) { a[k] = cv[k]; b[k] = ci[k]; }
+                if (have) { s0 = ps0; s1 = ps1; }
+                cum_r = pcum; nsp_r = pnsp;
+            } else {
+#pragma unroll
+                for (int k = 0; k < WLX_MAX_CAND / 4; ++k)
+                    if (k < nc4) { a[k] = cv[k]; b[k] = ci[k]; }
+                const float4* so = reinterpret_cast<const float4*>(st.scan_stats + ((long)r * SC_MAXCH + lc) * SC_NSTAT);
+                const float4 t0 = so[0], t1 = so[1];
+                if (have) { s0 = t0; s1 = t1; }
+                cum_r = st.cum[r]; nsp_r = st.nsp_row[r];
+            }
 #pragma unroll
             for (int k = 0; k < WLX_MAX_CAND / 4; ++k)
-                if (k < nc4) { a[k] = cv[k]; b[k] = ci[k]; }
-#pragma unroll
-            for (int k = 0; k < WLX_MAX_CAND / 4; ++k)
-                if (k < nc4) {
+                if (k < nc4 && have) {
                     *reinterpret_cast<float4*>(&lv[wave][lane][4 * k]) = have ? a[k] : make_float4(WLX_NEG_INF, WLX_NEG_INF, WLX_NEG_INF, WLX_NEG_INF);
                     *reinterpret_cast<int4*>(&li[wave][lane][4 * k]) = have ? b[k] : make_int4(0x7fffffff, 0x7fffffff, 0x7fffffff, 0x7fffffff);
                 }
         }
         const float mt = s0.x, st_ = s0.y, mts = s0.z, sts = s0.w, rm = s1.x, rs = s1.y;
         const float Mtext = s3_wave_max(mt), Mts = s3_wave_max(mts);
-        if (st.nsp_row[r] > 0) {
+        if (nsp_r > 0) {
             const float RM = s3_wave_max(rm);
             const float RS = s3_wave_sum((rm > WLX_NEG_INF) ? rs * __expf(rm - RM) : 0.f);
             if (lane == 0) st.no_speech[item] = __expf(logits[(long)r * ldl + sp.no_speech] - RM) / RS;
@@ -831,7 +874,7 @@ __global__ __launch_bounds__(MU3_THREADS) void search_merge_update3_kernel(const
             lse_sel = mx_all + __logf(s3_wave_sum(a));
         }
         const bool usable = (lane < nch) && (!text_masked || lane >= nct);   // timestamps only: the timestamp chunks
-        const float base = st.cum[r] - lse_sel;
+        const float base = cum_r - lse_sel;
         int hp = 0;
         float hv = usable ? lv[wave][lane][0] : WLX_NEG_INF;
         int hi = usable ? li[wave][lane][0] : 0x7fffffff;
@@ -873,43 +916,49 @@ __global__ __launch_bounds__(MU3_THREADS) void search_merge_update3_kernel(const
             if (lane == 0) ord_b[k] = (kb == 0x7fffffff) ? -1 : kb;
             if (alive && b == kb) { ord_s[k] = cand_s[b][hp]; ord_t[k] = cand_t[b][hp]; ++hp; }
         }
-    }
-    __syncthreads();
-    if (tid == 0) {
-        int n_active = 0, nh_new = 0, n_hyp = st.n_hyp[item];
-        bool top_beam_finished = false;
-        for (int k = 0; k < sp.ncand; ++k) {
-            const int bb = ord_b[k];
-            if (bb < 0) break;
-            const float bs = ord_s[k];
-            const int tok = ord_t[k];
-            if (tok == sp.eot || is_last) {
-                if (k >= sp.beam) continue;
-                if (n_hyp + nh_new < WLX_MAX_HYP && nh_new < 16) {
-                    const int len = ngen + ((tok == sp.eot) ? 0 : 1);
-                    const int slot = n_hyp + nh_new;
-                    hyp_src[nh_new] = bb;
-                    hyp_extra[nh_new] = (tok == sp.eot) ? -1 : tok;
-                    hyp_slot[nh_new] = slot;
-                    st.hyp_len[item * WLX_MAX_HYP + slot] = len;
-                    const float denom = powf((float)(len > 0 ? len : 1), sp.length_penalty);
-                    st.hyp_score[item * WLX_MAX_HYP + slot] = bs / denom;
-                    ++nh_new;
-                }
-                if (k == 0) top_beam_finished = true;
-            } else if (n_active < sp.beam) {
-                parent[n_active] = bb; newtok[n_active] = tok; newcum[n_active] = bs;
-                ++n_active;
-            }
+        // ---------------- bookkeeping, one merged candidate per lane (k < ncand <= 32). The serial statement of it (search_update_kernel): walk
+        // k upwards, stop at the first empty entry; a finished candidate (EOT, or the last step) with k < beam becomes hypothesis number
+        // n_hyp + (finished ones accepted so far) while slots last; any other candidate becomes active row number (others so far) while
+        // fewer than beam are active. Both counters only grow with k, so "so far" is a prefix count over the lanes below.
+        const int k = lane;
+        const bool in_list = k < sp.ncand;
+        const int bb = in_list ? ord_b[k] : -1;                       // (LDS written by this wave's lanes above: same-wave program order)
+        const float bs = in_list ? ord_s[k] : 0.f;
+        const int tok = in_list ? ord_t[k] : 0;
+        const unsigned long long stop = __ballot(!in_list || bb < 0);         // never empty: lane ncand <= 32 is set
+        const bool live = k < (int)__builtin_ctzll(stop);
+        const bool fin_k = live && (tok == sp.eot || is_last);
+        const bool act_k = live && !fin_k;
+        const unsigned long long below = (1ull << k) - 1ull;
+        const unsigned long long finm = __ballot(fin_k && k < sp.beam);
+        const unsigned long long actm = __ballot(act_k);
+        int cap = WLX_MAX_HYP - n_hyp0; cap = cap < 16 ? cap : 16; cap = cap > 0 ? cap : 0;
+        const int hidx = __builtin_popcountll(finm & below), aidx = __builtin_popcountll(actm & below);
+        if (fin_k && k < sp.beam && hidx < cap) {
+            const int len = ngen + ((tok == sp.eot) ? 0 : 1);
+            const int slot = n_hyp0 + hidx;
+            hyp_src[hidx] = bb;
+            hyp_extra[hidx] = (tok == sp.eot) ? -1 : tok;
+            hyp_slot[hidx] = slot;
+            st.hyp_len[item * WLX_MAX_HYP + slot] = len;
+            const float flen = (float)(len > 0 ? len : 1);
+            const float denom = (sp.length_penalty == 1.0f) ? flen : powf(flen, sp.length_penalty);    // (pow(x, 1) = x exactly: the default penalty skips ~200 instructions)
+            st.hyp_score[item * WLX_MAX_HYP + slot] = bs / denom;
         }
-        n_hyp += nh_new;
-        st.n_hyp[item] = n_hyp;
-        hyp_n = nh_new;
-        n_active_s = n_active;
-        bool fin = is_last || n_active == 0;
-        if (sp.allow_early_exit) fin = fin || (top_beam_finished && n_hyp >= sp.num_hyp);
-        else fin = fin || (n_hyp >= sp.max_cand_hyp);
-        finished_s = fin ? 1 : 0;
+        if (act_k && aidx < sp.beam) { parent[aidx] = bb; newtok[aidx] = tok; newcum[aidx] = bs; }
+        if (lane == 0) {
+            int nh_new = __builtin_popcountll(finm); nh_new = nh_new < cap ? nh_new : cap;
+            int n_active = __builtin_popcountll(actm); n_active = n_active < sp.beam ? n_active : sp.beam;
+            const bool top_beam_finished = fin_k;                     // (lane 0 = candidate 0)
+            const int n_hyp = n_hyp0 + nh_new;
+            st.n_hyp[item] = n_hyp;
+            hyp_n = nh_new;
+            n_active_s = n_active;
+            bool fin = is_last || n_active == 0;
+            if (sp.allow_early_exit) fin = fin || (top_beam_finished && n_hyp >= sp.num_hyp);
+            else fin = fin || (n_hyp >= sp.max_cand_hyp);
+            finished_s = fin ? 1 : 0;
+        }
     }
     __syncthreads();
     WLX_TR_MARK(2);
@@ -956,9 +1005,9 @@ __global__ __launch_bounds__(MU3_THREADS) void search_merge_update3_kernel(const
     WLX_TR_END(trc);
 }
 
-void launch_search_merge_update3(const float* logits, long ldl, int V, const SearchParams* sp_dev, int items,
+void launch_search_merge_update3(const float* logits, long ldl, int V, const SearchParams* sp_dev, int items, int R,
                                  const SearchState& st, hipStream_t s) {
-    hipLaunchKernelGGL(search_merge_update3_kernel, dim3(items), dim3(MU3_THREADS), 0, s, logits, ldl, V, sp_dev, st WLX_TR_ARG("search_merge_update3"));
+    hipLaunchKernelGGL(search_merge_update3_kernel, dim3(items), dim3(MU3_THREADS), 0, s, logits, ldl, V, sp_dev, st, R WLX_TR_ARG("search_merge_update3"));
 }
 
 // ------------------------------------------------------------------ per-call reset of the search state (one launch
