@@ -174,7 +174,11 @@ int32_t wlx_encoder_output_get(wlx_engine* e, int32_t slot, int32_t item, float*
 /* Autoregressive decode for items 0..batch-1 (item i uses prompt i). Outputs, per item and
  * hypothesis h < num_hypotheses (best first): generated token ids (prompt and EOT excluded),
  * their count, the CT2-style score (sum of log-probs incl. EOT / len^length_penalty), and per
- * item the no-speech probability (softmax prob. of ids.no_speech at the sot position). */
+ * item the no-speech probability (softmax prob. of ids.no_speech at the sot position).
+ * The call returns when the results are final, which can be BEFORE the slot's stream is idle: the search kernels store the
+ * results in pinned host memory and order them before the "done" word the host polls, so a decode that ends on an end-of-text
+ * does not wait for the one step that was already enqueued behind the finish (~0.4 ms on Whisper-small). Later calls on the
+ * slot are ordered behind it on the stream; wlx_timings_get / wlx_sync wait for it. */
 int32_t wlx_generate(wlx_engine* e, int32_t slot, int32_t batch,
                      const int32_t* prompts, const int32_t* prompt_lens, int32_t prompt_stride,
                      const wlx_gen_opts* opts,
@@ -194,6 +198,7 @@ int32_t wlx_generate_ex(wlx_engine* e, int32_t slot, int32_t batch, const int32_
 int32_t wlx_detect_language(wlx_engine* e, int32_t slot, int32_t batch, int32_t sot,
                             const int32_t* lang_ids, int32_t n_lang, float* probs_out);
 
+/* Device times of the slot's last log-mel / encode / generate (HIP events); waits for whichever of them is still running. */
 int32_t wlx_timings_get(wlx_engine* e, int32_t slot, wlx_timings* out);
 int32_t wlx_sync(wlx_engine* e, int32_t slot);
 

@@ -135,10 +135,12 @@ struct SearchState {            // device pointers, one set per slot
     int* row_done;              // [rows] (sampling mode)
     float* cand_score; int* cand_tok;  // [rows][WLX_MAX_CAND]
     int* samp_tok; float* samp_lp;     // [rows]
-    int* hyp_tokens;            // [items][WLX_MAX_HYP][448]
+    int* hyp_tokens;            // [items][WLX_MAX_HYP][448]  — hyp_tokens, hyp_len, hyp_score, no_speech live in PINNED HOST memory (round 6): written by
+                                // the update kernels, never read on the device; the host reads them when it sees done_host, without waiting for the stream
     int* hyp_len;               // [items][WLX_MAX_HYP]
     float* hyp_score;           // [items][WLX_MAX_HYP]  (normalised)
     int* n_hyp;                 // [items]
+    int* n_hyp_host;            // [items] the same count in the pinned result area (the host reads the results there, see hyp_tokens)
     float* no_speech;           // [items]
     int* nsp_row;               // [rows] 1 if this row's raw distribution defines no_speech_prob (-1 none)
     // row tables (mutable here)

@@ -53,6 +53,7 @@ struct Slot {
     hipEvent_t ev_en0 = nullptr, ev_en1 = nullptr;   // the last encoder pass (wlx_encode does not wait either)
     bool en_pending = false;
     bool lm_pending = false;
+    bool gen_pending = false;                  // the last generate's device time / step count: read in wlx_timings_get, not in wlx_generate
     std::vector<int> lm_items;          // items whose log-mel was requested and not launched yet (engine.hip flush_logmel)
     bool busy_variant = false;          // the decode launches of this slot use the work-saving shapes (three or more live slots on the device; engine.hip device_is_busy)
     std::vector<void*> allocs;
@@ -97,6 +98,8 @@ struct Slot {
     int* h_stage = nullptr; size_t h_stage_ints = 0;
     // pinned staging of wlx_generate: set-up tables in (one async copy each, no synchronisation) and results out
     unsigned char* h_gen = nullptr; size_t h_gen_bytes = 0;
+    int* h_hyp = nullptr;                      // pinned result area the update kernels write: [n_hyp B | hyp_len B*H | hyp_score B*H | no_speech B | hyp_tokens B*H*448]
+    int max_items = 0;                         // B of that layout
     std::vector<int> last_suppress; bool suppress_valid = false;   // the suppress mask on the device was built from this list
     std::map<StepGraphKey, hipGraphExec_t> graphs;
     wlx_timings tm{};

@@ -418,6 +418,7 @@ static void slot_free(Slot* s) {
     for (void* p : s->allocs) (void)hipFree(p);
     if (s->h_stage) (void)hipHostFree(s->h_stage);
     if (s->h_gen) (void)hipHostFree(s->h_gen);
+    if (s->h_hyp) (void)hipHostFree(s->h_hyp);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->ev_lm0) (void)hipEventDestroy(s->ev_lm0);
@@ -710,10 +711,20 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
         CKR(dalloc(s->allocs, &st.cand_score, (size_t)RC * WLX_MAX_CAND));
         CKR(dalloc(s->allocs, &st.cand_tok, (size_t)RC * WLX_MAX_CAND));
         CKR(dalloc(s->allocs, &st.samp_tok, (size_t)RC)); CKR(dalloc(s->allocs, &st.samp_lp, (size_t)RC));
-        CKR(dalloc(s->allocs, &st.hyp_tokens, (size_t)B * WLX_MAX_HYP * WLX_T_TEXT));
-        CKR(dalloc(s->allocs, &st.hyp_len, (size_t)B * WLX_MAX_HYP));
-        CKR(dalloc(s->allocs, &st.hyp_score, (size_t)B * WLX_MAX_HYP));
-        CKR(dalloc(s->allocs, &st.n_hyp, (size_t)B)); CKR(dalloc(s->allocs, &st.no_speech, (size_t)B));
+        // the results of a generate live in pinned host memory (round 6, search.hip finish_item): the update kernels store them there and the host
+        // reads them when it sees the done word — no copies, no wait for the step that is already in flight behind the finish
+        {
+            const size_t ints = (size_t)B * (2 + 2 * WLX_MAX_HYP + (size_t)WLX_MAX_HYP * WLX_T_TEXT);
+            CK(hipHostMalloc(reinterpret_cast<void**>(&s->h_hyp), ints * sizeof(int), hipHostMallocDefault));
+            memset(s->h_hyp, 0, ints * sizeof(int));
+            s->max_items = B;
+            st.n_hyp_host = s->h_hyp;
+            st.hyp_len = st.n_hyp_host + B;
+            st.hyp_score = reinterpret_cast<float*>(st.hyp_len + (size_t)B * WLX_MAX_HYP);
+            st.no_speech = st.hyp_score + (size_t)B * WLX_MAX_HYP;
+            st.hyp_tokens = reinterpret_cast<int*>(st.no_speech + B);
+        }
+        CKR(dalloc(s->allocs, &st.n_hyp, (size_t)B));
         CKR(dalloc(s->allocs, &st.nsp_row, (size_t)RC));
         st.token = s->d_token; st.pos = s->d_pos; st.anc = s->d_anc; st.intok = s->d_intok;
         CKR(dalloc(s->allocs, &st.scan_stats, (size_t)RC * SC_MAXCH * SC_NSTAT));
@@ -816,6 +827,15 @@ extern "C" int32_t wlx_timings_get(wlx_engine* e, int32_t slot, wlx_timings* out
         CK(hipEventSynchronize(s->ev_en1));
         CK(hipEventElapsedTime(&s->tm.encode_ms, s->ev_en0, s->ev_en1));
         s->en_pending = false;
+    }
+    if (s->gen_pending) {                     // the last generate: its results were read from pinned memory without waiting for the stream
+        CK(hipSetDevice(e->device));
+        CK(hipEventSynchronize(s->ev1));
+        CK(hipEventElapsedTime(&s->tm.generate_ms, s->ev0, s->ev1));
+        int steps = 0;
+        CK(hipMemcpy(&steps, s->st.step, 4, hipMemcpyDeviceToHost));
+        s->tm.decode_steps = steps;
+        s->gen_pending = false;
     }
     if (s->lm_pending) {                      // the last log-mel launch: waited for here, not in wlx_logmel_resident
         CK(hipSetDevice(e->device));
@@ -1376,7 +1396,7 @@ static int prefill_tokens(Engine* e, Slot* s, int item, int crow, const int* tok
             p.Y = s->logits; p.ldy = s->ldl; p.qscale = 1.f; p.xsrc = GEMV_X_PLAIN;
             launch_dec_gemv(p, s->stream);
             launch_token_prob(s->logits, s->ldl, e->spec.vocab, 1, nsp_token, s->d_tokprob, s->stream);
-            CK(hipMemcpyAsync(nsp_out, s->d_tokprob, 4, hipMemcpyDeviceToDevice, s->stream));
+            CK(hipMemcpyAsync(nsp_out, s->d_tokprob, 4, hipMemcpyDefault, s->stream));       // (nsp_out: the pinned result area of wlx_generate, or device memory)
             CK(hipGetLastError());
         }
         return WLX_OK;
@@ -1653,7 +1673,7 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
                     p.Y = s->logits; p.ldy = s->ldl; p.qscale = 1.f; p.xsrc = GEMV_X_PLAIN;
                     launch_dec_gemv(p, st);
                     launch_token_prob(s->logits, s->ldl, V, 1, o->ids.no_speech, s->d_tokprob, st);
-                    CK(hipMemcpyAsync(S.no_speech + b, s->d_tokprob, 4, hipMemcpyDeviceToDevice, st));
+                    CK(hipMemcpyAsync(S.no_speech + b, s->d_tokprob, 4, hipMemcpyDefault, st));      // (into the pinned result area)
                 }
                 CK(hipGetLastError());
             }
@@ -1738,24 +1758,21 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
     const double tg2 = now_us();
     if (gen_trace) CK(hipStreamSynchronize(st));             // (only to tell the drain from the readback in the trace line)
     const double tg3 = now_us();
-    // ---- results: into the pinned staging, on the SLOT stream (never the legacy stream: a synchronous hipMemcpy here would
-    // try to order the legacy stream against another slot's stream while that one is capturing its step graph, and fail
-    // both), ONE wait for the decode's tail, the copies and the timing event together
-    int* n_hyp = reinterpret_cast<int*>(h_res);
-    int* hyp_len = n_hyp + batch;
-    float* hyp_score = reinterpret_cast<float*>(hyp_len + (size_t)batch * WLX_MAX_HYP);
-    float* nspv = hyp_score + (size_t)batch * WLX_MAX_HYP;
-    int* step_dev_p = reinterpret_cast<int*>(nspv + batch);
-    int* hyp_tok = step_dev_p + 16;
-    CK(hipMemcpyAsync(n_hyp, S.n_hyp, batch * 4, hipMemcpyDeviceToHost, st));
-    CK(hipMemcpyAsync(hyp_len, S.hyp_len, (size_t)batch * WLX_MAX_HYP * 4, hipMemcpyDeviceToHost, st));
-    CK(hipMemcpyAsync(hyp_score, S.hyp_score, (size_t)batch * WLX_MAX_HYP * 4, hipMemcpyDeviceToHost, st));
-    CK(hipMemcpyAsync(hyp_tok, S.hyp_tokens, (size_t)batch * WLX_MAX_HYP * WLX_T_TEXT * 4, hipMemcpyDeviceToHost, st));
-    CK(hipMemcpyAsync(nspv, S.no_speech, batch * 4, hipMemcpyDeviceToHost, st));
-    CK(hipMemcpyAsync(step_dev_p, S.step, 4, hipMemcpyDeviceToHost, st));
+    // ---- results. Round 6: the update kernels store them in pinned host memory (Slot::h_hyp) and order them before the done word (search.hip
+    // finish_item), so a call that saw the word reads them NOW — the step it had already enqueued behind the finish (scratch-only, ~0.4 ms) is still
+    // running and is not waited for; the next call on the slot queues behind it on the stream. (Until then six copies were enqueued on the slot stream and
+    // one wait covered the tail, the copies and the timing event.) A loop that ended any other way (injected logits, a step budget) waits for the stream.
     CK(hipEventRecord(s->ev1, st));
-    CK(hipStreamSynchronize(st));
-    const int step_dev = *step_dev_p;
+    s->gen_pending = true;
+    if (h_done[0] == 0 || gen_trace) CK(hipStreamSynchronize(st));
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const int MB = s->max_items;
+    const int* n_hyp = S.n_hyp_host;
+    const int* hyp_len = S.hyp_len;
+    const float* hyp_score = S.hyp_score;
+    const float* nspv = S.no_speech;
+    const int* hyp_tok = S.hyp_tokens;
+    (void)MB; (void)h_res;
     const int NH = std::max(1, o->num_hypotheses);
     for (int b = 0; b < batch; ++b) {
         std::vector<int> order(std::min(n_hyp[b], WLX_MAX_HYP));
@@ -1779,11 +1796,12 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
         }
         if (nsp_out) nsp_out[b] = nspv[b];
     }
-    CK(hipEventElapsedTime(&s->tm.generate_ms, s->ev0, s->ev1));
-    s->tm.decode_steps = step_dev;
-    if (gen_trace)
+    if (gen_trace) {
+        float gms = 0.f;
+        CK(hipEventElapsedTime(&gms, s->ev0, s->ev1));
         fprintf(stderr, "[wlx gen] steps %d: setup %.0f us | loop %.0f us (graph launch calls %.0f, event waits %.0f) | drain %.0f us | readback %.0f us | device %.0f us\n",
-                steps_run, tg1 - tg0, tg2 - tg1, tg_launch, tg_wait, tg3 - tg2, now_us() - tg3, 1e3 * s->tm.generate_ms);
+                steps_run, tg1 - tg0, tg2 - tg1, tg_launch, tg_wait, tg3 - tg2, now_us() - tg3, 1e3 * gms);
+    }
     return WLX_OK;
 }
 

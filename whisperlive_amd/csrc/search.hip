@@ -337,6 +337,21 @@ void launch_search_rows(const float* logits, const SearchParams* sp_dev, int row
 __device__ __forceinline__ void step_mirror(const SearchState& st, int step_no) {
     __hip_atomic_store(st.done_host + 1, step_no, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
+// An item is finished (one thread, AFTER a workgroup barrier that follows the workgroup's last result store). The results (hypothesis tokens, lengths,
+// scores, no_speech_prob, counts) are in pinned host memory and the host reads them the moment it sees the done word, while the step it had already
+// enqueued is still running (round 6: the result copies used to queue behind that step on the slot stream, ~0.4 ms per call that ends on an
+// end-of-text). So every result store of every item must happen-before the done word: barrier (this workgroup's stores -> this thread), system-scope
+// fence, the count; the thread that counts the last item fences again (the other items' workgroups fenced before they counted) and releases.
+__device__ __forceinline__ void finish_item(const SearchState& st, int item, int items) {
+    st.item_done[item] = 1;
+    __threadfence_system();
+    const int nf = atomicAdd(st.n_finished, 1) + 1;
+    if (nf >= items) {
+        __threadfence_system();
+        *st.done = 1;
+        __hip_atomic_store(st.done_host, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 
 __global__ __launch_bounds__(256) void search_update_kernel(const SearchParams* __restrict__ spp, SearchState st) {
     if (*st.done) return;
@@ -398,7 +413,7 @@ __global__ __launch_bounds__(256) void search_update_kernel(const SearchParams* 
                 }
             }
             n_hyp += nh_new;
-            st.n_hyp[item] = n_hyp;
+            st.n_hyp[item] = n_hyp; st.n_hyp_host[item] = n_hyp;
             hyp_n = nh_new;
             n_active_s = n_active;
             bool fin = is_last || n_active == 0;
@@ -422,10 +437,9 @@ __global__ __launch_bounds__(256) void search_update_kernel(const SearchParams* 
             if (tid == 0 && hyp_extra[hh] >= 0) dst[ngen] = hyp_extra[hh];
         }
         if (finished_s) {
+            __syncthreads();                             // every thread's hypothesis tokens are stored
             if (tid == 0) {
-                st.item_done[item] = 1;
-                const int nf = atomicAdd(st.n_finished, 1) + 1;
-                if (nf >= sp.items) { *st.done = 1; __hip_atomic_store(st.done_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+                finish_item(st, item, sp.items);
                 if (step_no) step_mirror(st, step_no);   // (as search_merge_update3_kernel: every update kernel stores its step number as it ends)
             }
             return;
@@ -488,10 +502,8 @@ __global__ __launch_bounds__(256) void search_update_kernel(const SearchParams* 
         }
         __syncthreads();
         if (tid == 0 && !alive) {
-            st.n_hyp[item] = sp.num_hyp;
-            st.item_done[item] = 1;
-            const int nf = atomicAdd(st.n_finished, 1) + 1;
-            if (nf >= sp.items) { *st.done = 1; __hip_atomic_store(st.done_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+            st.n_hyp[item] = sp.num_hyp; st.n_hyp_host[item] = sp.num_hyp;
+            finish_item(st, item, sp.items);
         }
     }
     if (step_no) step_mirror(st, step_no);
@@ -951,7 +963,7 @@ __global__ __launch_bounds__(MU3_THREADS) void search_merge_update3_kernel(const
             int n_active = __builtin_popcountll(actm); n_active = n_active < sp.beam ? n_active : sp.beam;
             const bool top_beam_finished = fin_k;                     // (lane 0 = candidate 0)
             const int n_hyp = n_hyp0 + nh_new;
-            st.n_hyp[item] = n_hyp;
+            st.n_hyp[item] = n_hyp; st.n_hyp_host[item] = n_hyp;
             hyp_n = nh_new;
             n_active_s = n_active;
             bool fin = is_last || n_active == 0;
@@ -970,10 +982,9 @@ __global__ __launch_bounds__(MU3_THREADS) void search_merge_update3_kernel(const
         if (tid == 0 && hyp_extra[hh] >= 0) dst[ngen] = hyp_extra[hh];
     }
     if (finished_s) {
+        __syncthreads();                                 // every thread's hypothesis tokens are stored
         if (tid == 0) {
-            st.item_done[item] = 1;
-            const int nf = atomicAdd(st.n_finished, 1) + 1;
-            if (nf >= sp.items) { *st.done = 1; __hip_atomic_store(st.done_host, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
+            finish_item(st, item, sp.items);
             if (step_no) step_mirror(st, step_no);
         }
         return;
@@ -1015,7 +1026,7 @@ void launch_search_merge_update3(const float* logits, long ldl, int V, const Sea
 __global__ __launch_bounds__(256) void search_reset_kernel(SearchState st, int items, int rows) {
     const int t = threadIdx.x;
     if (t == 0) { *st.step = 0; *st.done = 0; *st.n_finished = 0; }
-    for (int i = t; i < items; i += 256) { st.item_done[i] = 0; st.n_hyp[i] = 0; st.no_speech[i] = 0.f; }
+    for (int i = t; i < items; i += 256) { st.item_done[i] = 0; st.n_hyp[i] = 0; st.n_hyp_host[i] = 0; st.no_speech[i] = 0.f; }
     for (int i = t; i < rows; i += 256) st.row_done[i] = 0;
     for (int i = t; i < items * WLX_MAX_HYP; i += 256) st.hyp_len[i] = 0;
 }
