@@ -439,8 +439,8 @@ __global__ __launch_bounds__(256) void search_update_kernel(const SearchParams* 
         if (finished_s) {
             __syncthreads();                             // every thread's hypothesis tokens are stored
             if (tid == 0) {
-                finish_item(st, item, sp.items);
-                if (step_no) step_mirror(st, step_no);   // (as search_merge_update3_kernel: every update kernel stores its step number as it ends)
+                if (step_no) step_mirror(st, step_no);   // (as search_merge_update3_kernel: every update kernel stores its step number as it ends;
+                finish_item(st, item, sp.items);         //  BEFORE the done word: the host may start its next call the moment it sees that one)
             }
             return;
         }
@@ -984,8 +984,8 @@ __global__ __launch_bounds__(MU3_THREADS) void search_merge_update3_kernel(const
     if (finished_s) {
         __syncthreads();                                 // every thread's hypothesis tokens are stored
         if (tid == 0) {
+            if (step_no) step_mirror(st, step_no);       // (before the done word: the host may start its next call the moment it sees that one)
             finish_item(st, item, sp.items);
-            if (step_no) step_mirror(st, step_no);
         }
         return;
     }
@@ -1025,7 +1025,7 @@ void launch_search_merge_update3(const float* logits, long ldl, int V, const Sea
 // instead of eight hipMemsetAsync calls in front of every wlx_generate: ~5 us of host time each)
 __global__ __launch_bounds__(256) void search_reset_kernel(SearchState st, int items, int rows) {
     const int t = threadIdx.x;
-    if (t == 0) { *st.step = 0; *st.done = 0; *st.n_finished = 0; }
+    if (t == 0) { *st.step = 0; *st.done = 0; *st.n_finished = 0; step_mirror(st, 0); }   // (the mirror word too: stream-ordered behind every kernel of the previous call)
     for (int i = t; i < items; i += 256) { st.item_done[i] = 0; st.n_hyp[i] = 0; st.n_hyp_host[i] = 0; st.no_speech[i] = 0.f; }
     for (int i = t; i < rows; i += 256) st.row_done[i] = 0;
     for (int i = t; i < items * WLX_MAX_HYP; i += 256) st.hyp_len[i] = 0;
