@@ -1701,9 +1701,10 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
         CK(hipMemcpyAsync(S.nsp_row, h_nsp, rows * 4, hipMemcpyHostToDevice, st));     // (pinned: no wait needed before the loop)
     }
     // ---- autoregressive loop: one graph replay per step. The host never lets the stream run dry: step k+1 is
-    // enqueued BEFORE the host looks at the done flag copied after step k (double-buffered pinned words, one event
-    // each), so the check costs no GPU idle time; once the flag is set the one extra step already in flight is a
-    // chain of early-exit kernels (every decode kernel tests the flag).
+    // enqueued BEFORE the host knows how step k ended (the update kernels raise a pinned done word and mirror their step
+    // number themselves: no copies, no events), so the check costs no GPU idle time; once the word is set the one extra
+    // step already in flight only rewrites scratch (its search kernels return at once) and nobody waits for it: the
+    // results are read from pinned memory below.
     volatile int* h_done = s->h_stage + (s->h_stage_ints - 4);
     h_done[0] = 0;
     h_done[1] = 0;                                              // the update kernels' step number (search.hip step_mirror)
