@@ -98,6 +98,7 @@ struct Slot {
     int* h_stage = nullptr; size_t h_stage_ints = 0;
     // pinned staging of wlx_generate: set-up tables in (one async copy each, no synchronisation) and results out
     unsigned char* h_gen = nullptr; size_t h_gen_bytes = 0;
+    int* h_pf = nullptr; bool h_pf_used = false;   // pinned staging of the one-pass prompt prefill's row tables (its own: no wait for the stream before the first prefill of a call)
     int* h_hyp = nullptr;                      // pinned result area the update kernels write: [n_hyp B | hyp_len B*H | hyp_score B*H | no_speech B | hyp_tokens B*H*448]
     int max_items = 0;                         // B of that layout
     std::vector<int> last_suppress; bool suppress_valid = false;   // the suppress mask on the device was built from this list

@@ -419,6 +419,7 @@ static void slot_free(Slot* s) {
     if (s->h_stage) (void)hipHostFree(s->h_stage);
     if (s->h_gen) (void)hipHostFree(s->h_gen);
     if (s->h_hyp) (void)hipHostFree(s->h_hyp);
+    if (s->h_pf) (void)hipHostFree(s->h_pf);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->ev_lm0) (void)hipEventDestroy(s->ev_lm0);
@@ -718,6 +719,7 @@ extern "C" int32_t wlx_slot_create(wlx_engine* e, int32_t max_batch, int32_t max
             CK(hipHostMalloc(reinterpret_cast<void**>(&s->h_hyp), ints * sizeof(int), hipHostMallocDefault));
             memset(s->h_hyp, 0, ints * sizeof(int));
             s->max_items = B;
+            CK(hipHostMalloc(reinterpret_cast<void**>(&s->h_pf), (size_t)(5 * WLX_T_TEXT + 64) * sizeof(int), hipHostMallocDefault));
             st.n_hyp_host = s->h_hyp;
             st.hyp_len = st.n_hyp_host + B;
             st.hyp_score = reinterpret_cast<float*>(st.hyp_len + (size_t)B * WLX_MAX_HYP);
@@ -1372,9 +1374,12 @@ static int prefill_tokens(Engine* e, Slot* s, int item, int crow, const int* tok
     const bool one_pass = [] { const char* v = getenv("WLX_PREFILL_ONE_PASS"); return !(v && v[0] == '0'); }();   // (read per call: the A/B test toggles it)
     if (one_pass && s->pf_ok && !logits_host && !s->align && !s->prof && n > 48 && n <= WLX_T_TEXT && !g_decode_v1) {
         const int rows = n, groups = (rows + 15) / 16;
-        if ((size_t)(4 * rows + groups) > s->h_stage_ints - 8) return fail(WLX_ERR_ARG, "prompt too long");
-        CK(hipStreamSynchronize(s->stream));                       // the shared staging may still feed an earlier pass's copies
-        int* h = s->h_stage;
+        // its own pinned staging (round 6): the shared one needed a wait for the stream first — "may still feed an earlier pass's copies" — which
+        // let the GPU idle between the encoder's end and this pass while the host built and uploaded the tables. Only a SECOND one-pass prefill of
+        // the same call (a batch of long prompts) has to wait: wlx_generate clears the flag, and a call returns after its own uploads were consumed.
+        if (s->h_pf_used) CK(hipStreamSynchronize(s->stream));
+        s->h_pf_used = true;
+        int* h = s->h_pf;
         for (int i = 0; i < rows; ++i) { h[i] = tokens[i]; h[rows + i] = pos0 + i; h[2 * rows + i] = crow; h[3 * rows + i] = crow; }
         for (int g = 0; g < groups; ++g) h[4 * rows + g] = item;
         const Slot::DecBufs& b = s->pf;
@@ -1566,6 +1571,7 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
     auto now_us = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double tg0 = now_us();
     double tg_launch = 0.0, tg_wait = 0.0;
+    s->h_pf_used = false;
     const bool sampling = (o->sampling_temperature > 0.f || o->beam_size <= 1);
     const int R = sampling ? std::max(1, o->num_hypotheses) : o->beam_size;
     const int rows = batch * R, V = e->spec.vocab;
