@@ -270,6 +270,14 @@ int32_t wlx_ring_state(wlx_ring* r, int64_t* base_out, int64_t* resident_out);
  * host side asks for the same count, so the two paths segment identically). `v` and `r` must live on the same device. */
 int32_t wlx_vad_probs_resident(wlx_vad* v, wlx_ring* r, int64_t start, int64_t n, int32_t extra_zero_windows,
                                float* probs_out, int32_t cap, int32_t* n_windows_out, float* device_ms_out);
+/* Host only (no device work): the hysteresis segmentation of per-window speech probabilities into padded sample ranges —
+ * faster_whisper.vad.get_speech_timestamps' loop (reference call site: transcriber_faster_whisper.py:825-852), statement for
+ * statement whisperlive_amd/vad.py speech_segments_from_probs. It runs between the VAD launch and the log-mel launch, with the
+ * GPU waiting. thr / neg: the thresholds rounded to float32; the durations in samples as the Python code computes them
+ * (max_speech may be +inf). start_end_out: [cap][2]. */
+int32_t wlx_vad_segments(const float* probs, int32_t n_windows, int64_t n_samples, double thr, double neg, double min_speech,
+                         double pad, double max_speech, double min_silence, double min_silence_at_max,
+                         int64_t* start_end_out, int32_t cap, int32_t* n_out);
 /* log-mel of the CONCATENATION of `n_ranges` ring ranges [ranges[2 i], ranges[2 i + 1]) (absolute positions, ascending,
  * <= 256 of them) into item `item` of the slot: identical features to wlx_logmel on the concatenated samples. The launch
  * is issued at once (it reads the ring, which the socket thread may trim later). */

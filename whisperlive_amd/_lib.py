@@ -19,7 +19,7 @@ EXPORTS = [
     "wlx_slot_create", "wlx_slot_destroy", "wlx_logmel", "wlx_pcm_put", "wlx_logmel_resident", "wlx_features_get", "wlx_features_set", "wlx_encode",
     "wlx_encoder_output_get", "wlx_generate", "wlx_generate_ex", "wlx_detect_language", "wlx_align", "wlx_timings_get", "wlx_sync",
     "wlx_vad_create", "wlx_vad_destroy", "wlx_vad_probs",
-    "wlx_ring_create", "wlx_ring_destroy", "wlx_ring_append", "wlx_ring_state", "wlx_vad_probs_resident", "wlx_logmel_ring",
+    "wlx_ring_create", "wlx_ring_destroy", "wlx_ring_append", "wlx_ring_state", "wlx_vad_probs_resident", "wlx_vad_segments", "wlx_logmel_ring",
     "wlx_debug_logits_get", "wlx_debug_decode_logits", "wlx_debug_search", "wlx_debug_time_decode_step", "wlx_debug_profile_step", "wlx_debug_trace_step",
 ]
 
@@ -229,6 +229,7 @@ def load() -> C.CDLL:
     lib.wlx_ring_append.argtypes = [vp, f32p, i64, i64, i64, i64p, i64p, i64p]
     lib.wlx_ring_state.argtypes = [vp, i64p, i64p]
     lib.wlx_vad_probs_resident.argtypes = [vp, vp, i64, i64, i32, f32p, i32, i32p, f32p]
+    lib.wlx_vad_segments.argtypes = [f32p, i32, i64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, i64p, i32, i32p]
     lib.wlx_logmel_ring.argtypes = [vp, i32, i32, vp, i64p, i32, i32p]
     lib.wlx_debug_logits_get.argtypes = [vp, i32, f32p, i32, i64]
     lib.wlx_debug_decode_logits.argtypes = [vp, i32, i32p, i32, f32p]

@@ -499,3 +499,78 @@ extern "C" int32_t wlx_vad_probs_resident(wlx_vad* v, wlx_ring* r, int64_t start
     if (device_ms_out) VCK(hipEventElapsedTime(device_ms_out, v->ev0, v->ev1));
     return WLX_OK;
 }
+
+// ------------------------------------------------------------------ host: hysteresis segmentation of the probabilities
+// whisperlive_amd/vad.py speech_segments_from_probs (= faster_whisper.vad.get_speech_timestamps' loop, as the reference calls it at
+// whisper_live/transcriber/transcriber_faster_whisper.py:825-852) statement for statement, in C: the loop runs on the host BETWEEN the VAD launch
+// and the log-mel launch — the GPU waits for it — and costs 36 us for the 250 windows of an 8 s chunk and 136 us for 30 s in Python, ~2 us here
+// (round 6). The thresholds arrive as doubles already rounded to float32 (numpy compares a float32 probability with a Python float in float32);
+// the durations are the Python code's floats (max_speech may be +inf); positions are integers. Python's `gap // 2` floors.
+extern "C" int32_t wlx_vad_segments(const float* probs, int32_t n_windows, int64_t n_samples, double thr, double neg, double min_speech, double pad,
+                                    double max_speech, double min_silence, double min_silence_at_max, int64_t* start_end_out, int32_t cap,
+                                    int32_t* n_out) {
+    if (!probs || n_windows < 0 || !start_end_out || !n_out || cap < 0) return set_error(WLX_ERR_ARG, "wlx_vad_segments: bad argument");
+    const int64_t W = 512;
+    int32_t ns = 0;
+    auto push = [&](int64_t a, int64_t b) -> bool { if (ns >= cap) return false; start_end_out[2 * ns] = a; start_end_out[2 * ns + 1] = b; ++ns; return true; };
+    bool have_cur = false, active = false;
+    int64_t cur_start = 0, silence_from = 0, cut_at = 0, resume_at = 0;
+    for (int32_t i = 0; i < n_windows; ++i) {
+        const double p = (double)probs[i];
+        const int64_t pos = W * i;
+        if (p >= thr && silence_from) {
+            silence_from = 0;
+            if (resume_at < cut_at) resume_at = pos;
+        }
+        if (p >= thr && !active) { active = true; cur_start = pos; have_cur = true; continue; }
+        if (active && (double)(pos - cur_start) > max_speech) {
+            if (cut_at) {
+                if (!push(cur_start, cut_at)) return set_error(WLX_ERR_ARG, "wlx_vad_segments: more segments than the output holds");
+                have_cur = false;
+                if (resume_at < cut_at) active = false;
+                else { cur_start = resume_at; have_cur = true; }
+                cut_at = resume_at = silence_from = 0;
+            } else {
+                if (!push(cur_start, pos)) return set_error(WLX_ERR_ARG, "wlx_vad_segments: more segments than the output holds");
+                have_cur = false;
+                cut_at = resume_at = silence_from = 0;
+                active = false;
+                continue;
+            }
+        }
+        if (p < neg && active) {
+            if (!silence_from) silence_from = pos;
+            if ((double)(pos - silence_from) > min_silence_at_max) cut_at = silence_from;
+            if ((double)(pos - silence_from) < min_silence) continue;
+            if ((double)(silence_from - cur_start) > min_speech) { if (!push(cur_start, silence_from)) return set_error(WLX_ERR_ARG, "wlx_vad_segments: more segments than the output holds"); }
+            have_cur = false;
+            cut_at = resume_at = silence_from = 0;
+            active = false;
+        }
+    }
+    if (have_cur && (double)(n_samples - cur_start) > min_speech) { if (!push(cur_start, n_samples)) return set_error(WLX_ERR_ARG, "wlx_vad_segments: more segments than the output holds"); }
+    auto floordiv2 = [](int64_t g) -> int64_t { return (g >= 0) ? g / 2 : -((-g + 1) / 2); };
+    auto clamp0 = [](double v) -> int64_t { return (int64_t)(v > 0.0 ? v : 0.0); };
+    for (int32_t i = 0; i < ns; ++i) {
+        int64_t& s_ = start_end_out[2 * i]; int64_t& e_ = start_end_out[2 * i + 1];
+        if (i == 0) s_ = clamp0((double)s_ - pad);
+        if (i != ns - 1) {
+            int64_t& s2 = start_end_out[2 * i + 2];
+            const int64_t gap = s2 - e_;
+            if ((double)gap < 2.0 * pad) {
+                e_ += floordiv2(gap);
+                const int64_t t = s2 - floordiv2(gap);
+                s2 = t > 0 ? t : 0;
+            } else {
+                const double ee = (double)e_ + pad;
+                e_ = (int64_t)(ee < (double)n_samples ? ee : (double)n_samples);
+                s2 = clamp0((double)s2 - pad);
+            }
+        } else {
+            const double ee = (double)e_ + pad;
+            e_ = (int64_t)(ee < (double)n_samples ? ee : (double)n_samples);
+        }
+    }
+    *n_out = ns;
+    return WLX_OK;
+}

@@ -297,6 +297,14 @@ def speech_segments_from_probs(probs: Sequence[float], n_samples: int, opt: VadO
     min_silence = sampling_rate * opt.min_silence_duration_ms / 1000
     min_silence_at_max = sampling_rate * 98 / 1000
 
+    # The loop below runs on the host between the VAD launch and the log-mel launch — the GPU waits for it. Iterating a float32 array
+    # yields numpy scalars (82 us for the 250 windows of an 8 s chunk, 218 us for 30 s); the same values as Python floats, compared
+    # against the thresholds ROUNDED TO float32 — which is what numpy's float32-scalar >= python-float comparison does (NEP 50) —
+    # give the same decisions in a third of the time.
+    if isinstance(probs, np.ndarray) and probs.dtype == np.float32:
+        thr, neg = float(np.float32(thr)), float(np.float32(neg))
+        probs = probs.tolist()
+
     speeches: List[Dict[str, int]] = []
     cur: Dict[str, int] = {}
     active = False
@@ -363,12 +371,37 @@ def speech_segments_from_probs(probs: Sequence[float], n_samples: int, opt: VadO
     return speeches
 
 
+def speech_segments_from_probs_native(probs: np.ndarray, n_samples: int, opt: VadOptions, sampling_rate: int = 16000) -> List[Dict[str, int]]:
+    """`speech_segments_from_probs` through libwlx.so (include/wlx.h wlx_vad_segments: the same loop in C, ~2 us instead of 36-136 us of host
+    time that the GPU spends waiting between the gate and the log-mel). Used on the GPU gate's path (the library is loaded there anyway);
+    tests/test_vad_segments_native.py holds it to the Python statement case by case."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    p = np.ascontiguousarray(probs, dtype=np.float32)
+    thr = opt.threshold
+    neg = opt.neg_threshold if opt.neg_threshold is not None else max(thr - 0.15, 0.01)
+    pad = sampling_rate * opt.speech_pad_ms / 1000
+    cap = p.shape[0] + 2
+    out = np.empty((cap, 2), np.int64)
+    n_out = C.c_int32(0)
+    _lib.check(lib.wlx_vad_segments(p.ctypes.data_as(C.POINTER(C.c_float)), int(p.shape[0]), int(n_samples),
+                                    float(np.float32(thr)), float(np.float32(neg)), float(sampling_rate * opt.min_speech_duration_ms / 1000),
+                                    float(pad), float(sampling_rate * opt.max_speech_duration_s - WINDOW - 2 * pad),
+                                    float(sampling_rate * opt.min_silence_duration_ms / 1000), float(sampling_rate * 98 / 1000),
+                                    out.ctypes.data_as(C.POINTER(C.c_int64)), cap, C.byref(n_out)))
+    return [{"start": int(a), "end": int(b)} for a, b in out[: n_out.value].tolist()]
+
+
 def get_speech_timestamps(audio: np.ndarray, vad_options: Optional[VadOptions] = None, sampling_rate: int = 16000,
                           model: Optional[Callable[[np.ndarray], np.ndarray]] = None) -> List[Dict[str, int]]:
     opt = vad_options or VadOptions()
     n = int(audio.shape[0])
     padded = np.pad(audio.astype(np.float32, copy=False), (0, WINDOW - n % WINDOW))
-    probs = (model or get_default_model())(padded)
+    model = model or get_default_model()
+    probs = model(padded)
+    if isinstance(model, SileroHIPModel) and isinstance(probs, np.ndarray) and probs.dtype == np.float32:
+        return speech_segments_from_probs_native(probs, n, opt, sampling_rate)
     return speech_segments_from_probs(probs, n, opt, sampling_rate)
 
 
@@ -378,7 +411,7 @@ def get_speech_timestamps_resident(ring, start: int, n: int, vad_options: Option
     (anything else has no device path: the caller falls back to the host audio)."""
     opt = vad_options or VadOptions()
     probs = model.probs_resident(ring, start, n)
-    return speech_segments_from_probs(probs, int(n), opt, sampling_rate)
+    return speech_segments_from_probs_native(probs, int(n), opt, sampling_rate)
 
 
 def collect_chunks(audio: np.ndarray, chunks: List[Dict[str, int]], sampling_rate: int = 16000,
