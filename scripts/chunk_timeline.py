@@ -13,6 +13,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def run():
+    import torch  # noqa: F401 — FIRST: libwlx.so then binds to the HIP runtime torch bundles; under the image's own ROCm 7.2 runtime rocprofv3 segfaults
+    #              inside hipGraphLaunch after ~170 graph launches (scripts/rocprof_graph_probe.py; bench.py imports torch and is not affected)
     import numpy as np
     from bench import make_bench_transcriber, stream_pcm, token_ids
     from whisperlive_amd import vad
@@ -25,12 +27,12 @@ def run():
     vm = vad.SileroHIPModel(energy_following_vad_weights(3), device=eng.device)
     tr = make_bench_transcriber(eng, spec, token_ids(spec.vocab), 16, vad_model=vm)
     pcm = stream_pcm(8.0, 77)
-    for i in range(int(os.environ.get("CALLS", "6"))):
+    for i in range(int(os.environ.get("CALLS", "12"))):
         t0 = time.perf_counter()
         segs, info = tr.transcribe(pcm, language="en", vad_filter=True, initial_prompt=None)
         list(segs)
         print("call", i, "wall %.3f ms" % (1e3 * (time.perf_counter() - t0)), flush=True)
-        time.sleep(0.02)                       # calls are separated by > 10 ms on the GPU timeline
+        time.sleep(float(os.environ.get("PAUSE", "0.02")))   # calls are separated by > 10 ms on the GPU timeline
     del tr
     vm.close(); eng.close()
 
