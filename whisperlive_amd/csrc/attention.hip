@@ -20,17 +20,7 @@ namespace wlx {
 // (The first two forms — one wave per 16 x QT query rows reading K / V straight from L2, then the same with three rotating
 // tile register sets — were the A/B references of round 2; measured, superseded by the LDS forms below and removed from the
 // library in round 5: DESIGN.md "Encoder attention".)
-__device__ __forceinline__ float rows4_max(float v) {
-    // rows (16-lane groups) r0..r3 of a wave: after the first swap a = {r0,r0,r2,r2}, b = {r1,r1,r3,r3}; after the second
-    // a = {lo,lo}, b = {hi,hi}. Written as asm with BOTH operands read-write: the builtin with two identical operands is
-    // folded by hipcc (ROCm 7.2) as if it returned its input twice, which silently drops the max.
-    float a = v, b = v;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    a = fmaxf(a, b);
-    b = a;
-    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-    return fmaxf(a, b);
-}
+// (rows4_max / rows4_sum: common.h)
 
 // ------------------------------------------------------------------------------------------------------------------
 // Third form (round 2): K / V^T tiles SHARED by the four waves of a workgroup through an LDS ring filled by LDS-DMA.

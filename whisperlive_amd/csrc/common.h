@@ -54,6 +54,28 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+__device__ __forceinline__ float rows4_max(float v) {
+    // rows (16-lane groups) r0..r3 of a wave: after the first swap a = {r0,r0,r2,r2}, b = {r1,r1,r3,r3}; after the second
+    // a = {lo,lo}, b = {hi,hi}. Written as asm with BOTH operands read-write: the builtin with two identical operands is
+    // folded by hipcc (ROCm 7.2) as if it returned its input twice, which silently drops the max.
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a = fmaxf(a, b);
+    b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return fmaxf(a, b);
+}
+// the same exchange as a sum: the two additions are those of `v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);` with the operands of some
+// rows swapped — fp32 addition commutes, so the result is bit-identical to that form, without its two ds_bpermute round trips
+__device__ __forceinline__ float rows4_sum(float v) {
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    a = a + b;
+    b = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+    return a + b;
+}
+
 // erf GELU — Whisper's activation (HF configuration_whisper.py: activation_function="gelu", the erf form, not tanh).
 // erf by Abramowitz-Stegun 7.1.26 evaluated in fp32: |error| <= 6.1e-7 over the reals (checked against scipy on 2M
 // points; torch's own fp32 GELU is 1.2e-6 from the exact value), i.e. far below the fp16 the result is rounded to.

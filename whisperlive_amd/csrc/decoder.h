@@ -35,6 +35,12 @@ enum GemvOut : int { GEMV_OUT_F16 = 0, GEMV_OUT_GELU_F16 = 1, GEMV_OUT_F32 = 2, 
 //          (nobody materialises the sum until the next residual update writes it back);
 //   EMBED  token embedding + position (layer 0: the separate embedding launch folded into the first projection's prologue).
 enum GemvXsrc : int { GEMV_X_PLAIN = 0, GEMV_X_SLABS = 1, GEMV_X_EMBED = 2 };
+#ifndef WLX_CQ_GB_LDS
+#define WLX_CQ_GB_LDS 1       // dec_cq_cross_attn_kernel: LayerNorm gamma / beta requested once per workgroup and shared through LDS (0 = once per wave: A/B)
+#endif
+#ifndef WLX_CQ_SWAP
+#define WLX_CQ_SWAP 1         // dec_cq_cross_attn_kernel: softmax max / sum over the four lane rows by v_permlane swaps (0 = ds_bpermute: A/B)
+#endif
 #ifndef WLX_FC2_KS
 #define WLX_FC2_KS 2          // K slices of the lean MLP output projection (compile time: the consumers unroll over the slabs)
 #endif

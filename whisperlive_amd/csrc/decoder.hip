@@ -1805,14 +1805,14 @@ __global__ __launch_bounds__(XA_TPS * 64) void dec_cross_attn_kernel(const half_
             pv[s2 * 4 + r] = v;
             tmax = fmaxf(tmax, v);
         }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    if constexpr (WLX_CQ_SWAP != 0) tmax = rows4_max(tmax);   // (v_permlane swaps instead of ds_bpermute round trips: see dec_cq_cross_attn_kernel)
+    else { tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64)); tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)); }
     const float msafe = (tmax == WLX_NEG_INF) ? 0.f : tmax;      // a fully masked tile: every p = exp(-inf) = 0
     float psum = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { pv[i] = __expf(pv[i] - msafe); psum += pv[i]; }
-    psum += __shfl_xor(psum, 16, 64);
-    psum += __shfl_xor(psum, 32, 64);
+    if constexpr (WLX_CQ_SWAP != 0) psum = rows4_sum(psum);
+    else { psum += __shfl_xor(psum, 16, 64); psum += __shfl_xor(psum, 32, 64); }
     const f16x8 pf = {(half_t)pv[0], (half_t)pv[1], (half_t)pv[2], (half_t)pv[3],
                       (half_t)pv[4], (half_t)pv[5], (half_t)pv[6], (half_t)pv[7]};
 #pragma unroll
@@ -1903,8 +1903,20 @@ __global__ __launch_bounds__(XA_TPS * 64) void dec_cq_cross_attn_kernel(
 #pragma unroll
         for (int j = 0; j < LNV; ++j) x0[j] = x4[64 * j];
     }
+    // gamma / beta (round 6, WLX_CQ_GB_LDS; -DWLX_CQ_GB_LDS=0 = every wave loads all of both, for A/B): ONE KiB piece of [gamma | beta] per wave
+    // (six waves, 2 x 3 pieces), shared through LDS before the first row is normalised — 30 of the workgroup's 204 wave-level loads less in front
+    // of its weights and K / V, and this launch is bound by exactly that count (a CU retires one per ~11 ns, L1 hit or not). Same values into the
+    // same arithmetic: bit-identical. In-kernel timeline (profiles/r6ad_*): rows normalised 0.26 us LATER (the exchange's barrier), query tile
+    // ready 0.35 us earlier, workgroup 5.06 -> 4.76 us. The same exchange in dec_gemv2_kernel's LayerNorm prologues measured the other way — first
+    // projection 2.04 -> 2.27 us, first MLP projection 1.90 -> 2.31 us per workgroup, step graph +11 us: there the weights are 24 of 72-120 loads
+    // and a wave's normalisation waited for nobody else's loads (scripts/patches/r6ad_*.diff) — so it is used here only.
     float4 gq[LNV], bq[LNV];
-    {
+    float4 gbp = make_float4(0.f, 0.f, 0.f, 0.f);
+    if constexpr (WLX_CQ_GB_LDS != 0) {
+        static_assert(WLX_CQ_GB_LDS == 0 || 2 * LNV == TPS, "one [gamma | beta] piece per wave");
+        const float* src = (wave < LNV) ? gamma + wave * 256 : beta + (wave - LNV) * 256;
+        gbp = reinterpret_cast<const float4*>(src)[lane];
+    } else {
         const float4* g4 = reinterpret_cast<const float4*>(gamma) + lane;
         const float4* b4 = reinterpret_cast<const float4*>(beta) + lane;
 #pragma unroll
@@ -1918,6 +1930,8 @@ __global__ __launch_bounds__(XA_TPS * 64) void dec_cq_cross_attn_kernel(
     for (int j = 0; j < KPW; ++j)
 #pragma unroll
         for (int i = 0; i < 4; ++i) wf[j][i] = ld_nt_f16x8(wp + (long)i * KT * 512 + j * 512);
+    // (Tried: consuming this scalar load through an asm barrier placed here, so that the wave does not wait for it between the LayerNorm operands'
+    // requests and the weights' — hipcc then sinks the ROW loads behind the weights: the order the round-2 reordering removed. Left alone.)
     const int item = group_item[grp];
     const int tile = sp * TPS + wave;
     const int key0 = tile * 32;
@@ -1952,6 +1966,13 @@ __global__ __launch_bounds__(XA_TPS * 64) void dec_cq_cross_attn_kernel(
                 if (keep) *reinterpret_cast<f16x4*>(dst + 256 * j) = hv;
             }
         };
+        if constexpr (WLX_CQ_GB_LDS != 0) {
+            float4* gbs4 = reinterpret_cast<float4*>(qs + 16 * 72);       // [2 LNV][64] float4 behind the query tile
+            gbs4[wave * 64 + lane] = gbp;
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < LNV; ++j) { gq[j] = gbs4[j * 64 + lane]; bq[j] = gbs4[(LNV + j) * 64 + lane]; }
+        }
         // first trip: straight-line and UNCONDITIONAL (a wave without a row normalises the clamped row it loaded and
         // keeps nothing): inside an `if (wave < nrow)` hipcc sinks the row loads into the branch, behind the weights
         ln_row(x0, (wave < nrow) ? wave : nrow - 1, wave < nrow);
@@ -2020,14 +2041,16 @@ __global__ __launch_bounds__(XA_TPS * 64) void dec_cq_cross_attn_kernel(
             pv[s2 * 4 + r] = v;
             tmax = fmaxf(tmax, v);
         }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+    // (max / sum over the four 16-lane rows by v_permlane16/32_swap, round 6: the ds_bpermute form cost four dependent LDS round trips in the tail
+    // of the launch; same values — max is exact, the sum's additions commute — WLX_CQ_SWAP=0 = the ds_bpermute form, for A/B)
+    if constexpr (WLX_CQ_SWAP != 0) tmax = rows4_max(tmax);
+    else { tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64)); tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)); }
     const float msafe = (tmax == WLX_NEG_INF) ? 0.f : tmax;
     float psum = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { pv[i] = __expf(pv[i] - msafe); psum += pv[i]; }
-    psum += __shfl_xor(psum, 16, 64);
-    psum += __shfl_xor(psum, 32, 64);
+    if constexpr (WLX_CQ_SWAP != 0) psum = rows4_sum(psum);
+    else { psum += __shfl_xor(psum, 16, 64); psum += __shfl_xor(psum, 32, 64); }
     const f16x8 pf = {(half_t)pv[0], (half_t)pv[1], (half_t)pv[2], (half_t)pv[3],
                       (half_t)pv[4], (half_t)pv[5], (half_t)pv[6], (half_t)pv[7]};
 #pragma unroll
@@ -2068,7 +2091,7 @@ bool dec_cq_cross_attn_eligible(int d, int H, int R) {
     static const bool off = [] { const char* e = wlx_ab("WLX_NO_FUSED_CQ"); return e && e[0] == '1'; }();
     if (off || g_decode_v1 || d != 768 || H * 64 != d || R < 1 || R > 16) return false;
     const size_t xs_floats = (size_t)((R * (d + 8) * 2 + 15) / 16) * 4;
-    const size_t shm = sizeof(float) * (xs_floats + (size_t)XA_TPS * 16 * 68 + XA_TPS * 16 * 2) + 16 * 72 * sizeof(half_t);
+    const size_t shm = sizeof(float) * (xs_floats + (size_t)XA_TPS * 16 * 68 + XA_TPS * 16 * 2) + 16 * 72 * sizeof(half_t) + (WLX_CQ_GB_LDS != 0 ? 6 * 1024 : 0);
     return shm <= 64 * 1024;
 }
 void launch_dec_cq_cross_attn(const float* X, long ldx, const float* gamma, const float* beta, const half_t* Wp, const float* bias,
@@ -2076,7 +2099,7 @@ void launch_dec_cq_cross_attn(const float* X, long ldx, const float* gamma, cons
                               int rows, const int* group_item, half_t* part_o, float* part_ml, hipStream_t s) {
     const int KT = d / 32;
     const size_t xs_floats = (size_t)((R * (d + 8) * 2 + 15) / 16) * 4;
-    const size_t shm = sizeof(float) * (xs_floats + (size_t)XA_TPS * 16 * 68 + XA_TPS * 16 * 2) + 16 * 72 * sizeof(half_t);
+    const size_t shm = sizeof(float) * (xs_floats + (size_t)XA_TPS * 16 * 68 + XA_TPS * 16 * 2) + 16 * 72 * sizeof(half_t) + (WLX_CQ_GB_LDS != 0 ? 6 * 1024 : 0);
     hipLaunchKernelGGL((dec_cq_cross_attn_kernel<3, 4>), dim3(H * WLX_XSPLIT * groups), dim3(XA_TPS * 64), shm, s, X, ldx, gamma, beta,
                        Wp, bias, qscale, KT, Kp, Vp, item_stride, H, R, rows, group_item, part_o, part_ml WLX_TR_ARG("cq_cross_attn"));
 }
