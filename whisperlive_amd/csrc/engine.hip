@@ -1453,9 +1453,24 @@ static void launch_search(Engine* e, Slot* s, int rows, int R, int groups, bool 
     }
 }
 
-static int get_step_graph(Engine* e, Slot* s, int rows, int R, int groups, bool sampling, hipGraphExec_t* out) {
+// Steps per graph launch (round 6). The boundary between two step graphs is 8.6-8.9 us of idle GPU against 1.45 us between two kernels of one graph
+// (profiles/r6ab_chunk_timeline_under_rocprof.txt): with TWO decode steps per graph every second boundary is an ordinary kernel boundary, -3.6 us per
+// step. The price is how far a decode can run past its end: the host enqueues graph g + 1 when the LAST step of graph g has started (the update kernels
+// mirror their step number to pinned memory), so an end of text in the first step of a graph leaves one scratch-only step behind it and one in the second
+// step leaves two — 1.5 on average against 1 with one step per graph. The call itself returns at the done word either way (the results are in pinned
+// memory); only work queued behind it on the same stream sees the extra 0.2 ms. So two steps are used where latency is what counts and the GPU has
+// room — ONE live slot on the device, one stream's rows (<= 16) — and one step everywhere else (several clients' slots, batched rows).
+// WLX_GRAPH_STEPS=1 forces one step per graph (A/B).
+static int graph_steps_for(const Slot* s, int rows) {
+    static const int env = [] { const char* v = wlx_ab("WLX_GRAPH_STEPS"); const int n = v ? atoi(v) : 2; return (n == 1 || n == 2) ? n : 2; }();
+    if (env == 1 || rows > 16) return 1;
+    const bool alone = s->device_of >= 0 && s->device_of < 64 && g_slots_live[s->device_of].load(std::memory_order_relaxed) <= 1;
+    return alone ? 2 : 1;
+}
+
+static int get_step_graph(Engine* e, Slot* s, int rows, int R, int groups, bool sampling, int nsteps, hipGraphExec_t* out) {
     s->busy_variant = device_is_busy(s);
-    StepGraphKey key{rows, R, groups * 4 + (s->busy_variant ? 2 : 0) + (sampling ? 1 : 0)};
+    StepGraphKey key{rows, R, groups * 8 + (nsteps == 2 ? 4 : 0) + (s->busy_variant ? 2 : 0) + (sampling ? 1 : 0)};
     auto it = s->graphs.find(key);
     if (it != s->graphs.end()) { *out = it->second; return WLX_OK; }
     hipGraph_t graph;
@@ -1465,8 +1480,10 @@ static int get_step_graph(Engine* e, Slot* s, int rows, int R, int groups, bool 
     decoder_pass(e, s, rows, R, groups, true, true);
     CK(hipGetLastError());
     CK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-    decoder_pass(e, s, rows, R, groups, true, true);
-    launch_search(e, s, rows, R, groups, sampling);
+    for (int k = 0; k < nsteps; ++k) {
+        decoder_pass(e, s, rows, R, groups, true, true);
+        launch_search(e, s, rows, R, groups, sampling);
+    }
     const hipError_t ce = hipStreamEndCapture(s->stream, &graph);
     if (ce != hipSuccess) {
         // An invalidated capture leaves the stream refusing every later operation ("previous error during capture"), so
@@ -1491,15 +1508,18 @@ static int get_step_graph(Engine* e, Slot* s, int rows, int R, int groups, bool 
     return WLX_OK;
 }
 
-static int run_step(Engine* e, Slot* s, int rows, int R, int groups, bool sampling) {
+// `nsteps` decode steps (1 or 2): one graph launch, or the same launches eagerly
+static int run_step(Engine* e, Slot* s, int rows, int R, int groups, bool sampling, int nsteps = 1) {
     if (e->use_graph) {
         hipGraphExec_t exec;
-        CKR(get_step_graph(e, s, rows, R, groups, sampling, &exec));
+        CKR(get_step_graph(e, s, rows, R, groups, sampling, nsteps, &exec));
         CK(hipGraphLaunch(exec, s->stream));
     } else {
         s->busy_variant = device_is_busy(s);
-        decoder_pass(e, s, rows, R, groups, true, true);
-        launch_search(e, s, rows, R, groups, sampling);
+        for (int k = 0; k < nsteps; ++k) {
+            decoder_pass(e, s, rows, R, groups, true, true);
+            launch_search(e, s, rows, R, groups, sampling);
+        }
         CK(hipGetLastError());
     }
     return WLX_OK;
@@ -1717,7 +1737,9 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
     const double tg1 = now_us();
     int steps_run = 0;
     bool finished = false;
-    for (int step = 0; step < max_steps && !finished; ++step) {
+    const int gsteps = (injected_logits || !e->use_graph) ? 1 : graph_steps_for(s, rows);
+    for (int step = 0; step < max_steps && !finished;) {
+        int n_this = 1;
         if (injected_logits) {
             if (step >= inj_steps) break;
             // test hook: logits come from the caller; the embed kernel still records the fed tokens
@@ -1729,10 +1751,12 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
             CK(hipGetLastError());
         } else {
             const double ta = gen_trace ? now_us() : 0.0;
-            CKR(run_step(e, s, rows, R, batch, sampling));
+            n_this = std::min(gsteps, max_steps - step);            // (an odd step budget ends on a one-step graph)
+            CKR(run_step(e, s, rows, R, batch, sampling, n_this));
             if (gen_trace) tg_launch += now_us() - ta;
         }
-        ++steps_run;
+        steps_run += n_this;
+        step += n_this;                                             // = steps enqueued so far
         // The search kernel of the step that finishes the last item stores 1 to the pinned word h_done itself, and every update kernel
         // stores its step number to the pinned word next to it as it ends (search.hip step_mirror): the host reads how far the stream got
         // from that word. Step k+1 is enqueued BEFORE the host waits for step k-1 to have ended, so the stream never runs dry; at most two
@@ -1743,10 +1767,11 @@ static int generate_impl(Engine* e, Slot* s, int batch, const int32_t* prompts, 
         if (injected_logits) {
             CK(hipStreamSynchronize(st));
             finished = h_done[0] != 0;
-        } else if (step >= 1) {
+        } else if (step >= 2) {
             const double ta = gen_trace ? now_us() : 0.0;
             int spins = 0, rounds = 0;
-            while (h_done[1] < step && h_done[0] == 0) {      // update kernel number `step` (= decode step `step - 1`) has not ended yet
+            // wait until all but the LAST enqueued step have ended, i.e. the last one has started: the next launch then lands while it runs
+            while (h_done[1] < step - 1 && h_done[0] == 0) {  // update kernel number `step - 1` (1-based) has not ended yet
                 // a short pure spin (the word usually moves within one step, 0.1-0.4 ms for one stream), then the core is offered to
                 // other runnable threads between polls (every decoding thread — batch lanes, client threads — used to burn a
                 // core for the whole generate). No sleep: a timer sleep (>= 50 us of slack) could let a 113 us tiny.en step's stream run dry.
