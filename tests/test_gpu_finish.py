@@ -91,3 +91,43 @@ def test_batch_whose_items_finish_at_different_steps(tiny):
                 assert abs(got[i].scores[0] - want[i].scores[0]) < 1e-3, (n, i)
     finally:
         single.close(); batch.close()
+
+
+def test_two_steps_per_graph_equal_one_step_per_graph(tiny):
+    """One live slot on the device decodes two steps per graph launch, two or more live slots one step per launch (engine.hip graph_steps_for): the
+    same calls give the same tokens, scores and step counts either way — end of text in an even step, in an odd step, odd and even step budgets
+    (an odd budget ends on a one-step graph), and back to back without a pause."""
+    spec, eng, pcm_of = tiny
+    ids = H.engine_ids(H.token_ids_for(spec.vocab))
+    sup = H.default_suppress(ids)
+    eot_only = [i for i in range(spec.vocab) if i != ids.eot]
+    cases = _cases(spec, ids) + [
+        ([ids.sot], dict(beam_size=5, max_length=1 + n, suppress_tokens=sup)) for n in (1, 2, 7, 8)
+    ] + [([ids.sot], dict(beam_size=1, max_length=1 + 9, suppress_tokens=sup)),
+         ([ids.sot, ids.no_timestamps], dict(beam_size=2, max_length=30, suppress_tokens=eot_only, suppress_blank=False))]
+    pcm = pcm_of(20.0, seed=5)
+
+    def run_all(slot):
+        T = slot.logmel(pcm)
+        slot.encode(1, seek=[0], seg=[T - 1])
+        out = []
+        for rep in range(3):                                   # (three rounds back to back: every call starts behind the previous one's tail)
+            for prompt, kw in cases:
+                r = slot.generate([prompt], ids, **kw)[0]
+                out.append((r.sequences_ids, r.scores, r.no_speech_prob))
+        steps = slot.timings()["decode_steps"]
+        return out, steps
+
+    alone = eng.create_slot(1, 5)
+    try:
+        got2, steps2 = run_all(alone)                          # the only live slot: two steps per graph
+    finally:
+        alone.close()
+    a = eng.create_slot(1, 5)
+    b = eng.create_slot(1, 5)                                  # a second live slot: one step per graph from here on
+    try:
+        got1, steps1 = run_all(a)
+    finally:
+        a.close(); b.close()
+    assert got2 == got1
+    assert steps2 == steps1
