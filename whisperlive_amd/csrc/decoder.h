@@ -41,6 +41,9 @@ enum GemvXsrc : int { GEMV_X_PLAIN = 0, GEMV_X_SLABS = 1, GEMV_X_EMBED = 2 };
 #ifndef WLX_CQ_SWAP
 #define WLX_CQ_SWAP 1         // dec_cq_cross_attn_kernel: softmax max / sum over the four lane rows by v_permlane swaps (0 = ds_bpermute: A/B)
 #endif
+#ifndef WLX_STAGE_WAVE
+#define WLX_STAGE_WAVE 1      // dec_gemv2_kernel, fp16 rows in: every wave stages its own K slice of the rows, no workgroup barrier before the MFMAs (0 = cooperative copy + barrier: A/B)
+#endif
 #ifndef WLX_FC2_KS
 #define WLX_FC2_KS 2          // K slices of the lean MLP output projection (compile time: the consumers unroll over the slabs)
 #endif

@@ -421,6 +421,38 @@ __device__ __forceinline__ void stage_rows_f16(const half_t* __restrict__ X, lon
     }
 }
 
+// The same for ONE WAVE's own K slice (round 6, WLX_STAGE_WAVE): wave w copies columns [0, K) of the M rows of ITS slice (X and xs already point at
+// the slice) with its 64 lanes — the same number of load instructions per workgroup as the cooperative copy — and is the only reader of what it wrote,
+// so the workgroup barrier between the staging and the MFMAs goes: a wave's LDS operations execute in order, and a wave starts its MFMAs when ITS
+// loads have landed instead of when the slowest wave's have.
+template <class F>
+__device__ __forceinline__ void stage_rows_f16_wave(const half_t* __restrict__ X, long ldx, int M, int K, half_t* xs, int ldxs, int lane,
+                                                    F&& after_first_loads) {
+    const int kv8 = K >> 3, total = M * kv8;
+    {
+        const int u0 = (lane < total) ? lane : total - 1;
+        const int u1 = (u0 + 64 < total) ? u0 + 64 : u0;
+        const int m0 = u0 / kv8, k0 = u0 - m0 * kv8;
+        const int m1 = u1 / kv8, k1 = u1 - m1 * kv8;
+        const f16x8 v0 = ld_f16x8(X + (long)m0 * ldx + k0 * 8);
+        const f16x8 v1 = ld_f16x8(X + (long)m1 * ldx + k1 * 8);
+        after_first_loads();
+        *reinterpret_cast<f16x8*>(xs + m0 * ldxs + k0 * 8) = v0;
+        *reinterpret_cast<f16x8*>(xs + m1 * ldxs + k1 * 8) = v1;
+    }
+#pragma unroll 1
+    for (int u0 = lane + 128; u0 < total; u0 += 128) {
+        const int u1 = u0 + 64;
+        const int m0 = u0 / kv8, k0 = u0 - m0 * kv8;
+        const int uc = (u1 < total) ? u1 : u0;
+        const int m1 = uc / kv8, k1 = uc - m1 * kv8;
+        const f16x8 v0 = ld_f16x8(X + (long)m0 * ldx + k0 * 8);
+        const f16x8 v1 = ld_f16x8(X + (long)m1 * ldx + k1 * 8);
+        *reinterpret_cast<f16x8*>(xs + m0 * ldxs + k0 * 8) = v0;
+        *reinterpret_cast<f16x8*>(xs + m1 * ldxs + k1 * 8) = v1;
+    }
+}
+
 // (Tried and dropped: a quarter-tile variant for fc2 — each 16-column tile shared by four workgroups, weights re-packed so
 // a 1 KiB load holds four rows x four k-tiles, four MFMAs per load into per-lane-group accumulators, no cross-workgroup
 // reduction. Numerically exact (all parity tests green) and it cuts the weight-load instructions per CU from 96 to 24, but
@@ -568,9 +600,18 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
             // as the weights; a CU retires one per ~11 ns), the cooperative copy M * K / 8 / 64 = 30.
             const int Ks = (OUT == GEMV_OUT_SLAB) ? p.KTS * 32 : p.K;      // columns of the rows this workgroup multiplies
             const int ldxs = Ks + 8;
+            if constexpr (WLX_STAGE_WAVE != 0) {
+                // every wave stages and reads only its own K slice: no workgroup barrier (stage_rows_f16_wave)
+                stage_rows_f16_wave(p.Xh + (ks0 + kx0) * 32, p.ldxh, p.M, p.KTW * 32, xs + kx0 * 32, ldxs, lane, [&]() { if (WLX_X_FIRST) load_weights(); });
+                WLX_TR_MARK(1);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            } else {
             stage_rows_f16(p.Xh + ks0 * 32, p.ldxh, p.M, Ks, xs, ldxs, [&]() { if (WLX_X_FIRST) load_weights(); });
             WLX_TR_MARK(1);
             __syncthreads();
+            }
             xr[0] = xs + crow[0] * ldxs + kx0 * 32 + g * 8;                 // lanes of rows >= M re-read a valid row (never stored)
             xstep = 32;
         } else {
