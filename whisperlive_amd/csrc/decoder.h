@@ -44,6 +44,9 @@ enum GemvXsrc : int { GEMV_X_PLAIN = 0, GEMV_X_SLABS = 1, GEMV_X_EMBED = 2 };
 #ifndef WLX_STAGE_WAVE
 #define WLX_STAGE_WAVE 1      // dec_gemv2_kernel, fp16 rows in: every wave stages its own K slice of the rows, no workgroup barrier before the MFMAs (0 = cooperative copy + barrier: A/B)
 #endif
+#ifndef WLX_XCOMB_WAVE
+#define WLX_XCOMB_WAVE 1      // dec_gemv2_kernel, cross-attention output projection: every wave combines the split partials of its own K slice, no helper waves, no barrier (0 = cooperative combine: A/B)
+#endif
 #ifndef WLX_FC2_KS
 #define WLX_FC2_KS 2          // K slices of the lean MLP output projection (compile time: the consumers unroll over the slabs)
 #endif

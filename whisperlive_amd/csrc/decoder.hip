@@ -472,7 +472,7 @@ __device__ __forceinline__ void stage_rows_f16_wave(const half_t* __restrict__ X
 template <int CH, int LNV, int IN, int OUT, int NTB, int MT, int XS>
 // (<= 8 waves wherever the kernel holds more than one row tile of fragments: 256 VGPRs per lane — at 16 waves the
 // two- and three-tile residual projections spilled, 36-180 bytes of scratch per lane)
-__global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1) ? 512 : 1024) void dec_gemv2_kernel(GemvParams p_in) {
+__global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1 || (IN == GEMV_IN_XATTN && WLX_XCOMB_WAVE != 0)) ? 512 : 1024) void dec_gemv2_kernel(GemvParams p_in) {
     // Row chunks (prompt prefill, round 3): a pass over up to 448 rows runs every projection as ONE launch whose grid.z walks
     // chunks of 48 rows (three MFMA row tiles, the widest this kernel holds); a chunk is this kernel on rebased row pointers.
     // Decode steps launch with Mtot = 0 and skip the block (a scalar branch).
@@ -903,12 +903,81 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
                               (half_t)(num[4] * inv), (half_t)(num[5] * inv), (half_t)(num[6] * inv), (half_t)(num[7] * inv)};
             if (it0 < n_it) *reinterpret_cast<f16x8*>(xs + m * ldxs + hh * 64 + q8 * 8) = hv;
         };
+        if constexpr (WLX_XCOMB_WAVE != 0 && MT == 1) {
+            // Round 6 (WLX_XCOMB_WAVE; 0 = the cooperative form below, for A/B): every wave combines exactly the columns of ITS K slice — items
+            // (row, 8-dim group) of columns [c0, c0 + W) — and is their only reader, so neither the helper waves nor the workgroup barrier between
+            // the combine and the MFMAs are needed (the launcher starts nw waves): a wave goes on when ITS partials have landed. The first two
+            // items of a lane are requested together, the weights right behind them (5 rows x 192 columns = 120 items: one round trip).
+            const int W = p.KTW * 32, c0 = kx0 * 32, wg8 = W >> 3;
+            const int n_w = p.M * wg8;
+            const float rG = 1.0f / (float)wg8;
+            auto item_ptrs = [&](int u, const float4*& mlp, const half_t*& op, int& m, int& col) {
+                const int uu = (u < n_w) ? u : n_w - 1;
+                m = (int)(((float)uu + 0.5f) * rG);                         // uu / wg8 (exact: small integers)
+                col = c0 + (uu - m * wg8) * 8;
+                const int hh = col >> 6, q8 = (col >> 3) & 7;
+                const int item = (int)(((float)m + 0.5f) * rR), qi = m - item * p.R;
+                const long ih = (long)item * p.H + hh;
+                mlp = reinterpret_cast<const float4*>(p.part_ml + (ih * 16 + qi) * (WLX_XSPLIT * 2));
+                op = p.part_o + (ih * WLX_XSPLIT * 16 + qi) * 64 + q8 * 8;
+            };
+            auto finish = [&](const float4 (&ml)[WLX_XSPLIT / 2], const f16x8 (&ov)[WLX_XSPLIT], int m, int col, bool keep) {
+                float mmax = fmaxf(ml[0].x, ml[0].z);
+#pragma unroll
+                for (int sp = 1; sp < WLX_XSPLIT / 2; ++sp) mmax = fmaxf(mmax, fmaxf(ml[sp].x, ml[sp].z));
+                float den = 0.f;
+                float num[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int sp = 0; sp < WLX_XSPLIT; ++sp) {                   // (the arithmetic and its order are the cooperative form's: identical rows)
+                    const float mm = (sp & 1) ? ml[sp >> 1].z : ml[sp >> 1].x, ll = (sp & 1) ? ml[sp >> 1].w : ml[sp >> 1].y;
+                    const float w = __expf(mm - mmax) * ll;
+                    den += w;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) num[e] += w * (float)ov[sp][e];
+                }
+                const float inv = 1.0f / den;
+                const f16x8 hv = {(half_t)(num[0] * inv), (half_t)(num[1] * inv), (half_t)(num[2] * inv), (half_t)(num[3] * inv),
+                                  (half_t)(num[4] * inv), (half_t)(num[5] * inv), (half_t)(num[6] * inv), (half_t)(num[7] * inv)};
+                if (keep) *reinterpret_cast<f16x8*>(xs + m * ldxs + col) = hv;
+            };
+            {
+                const float4 *mlpa, *mlpb; const half_t *opa, *opb; int ma, mb, cola, colb;
+                item_ptrs(lane, mlpa, opa, ma, cola);
+                item_ptrs(lane + 64, mlpb, opb, mb, colb);
+                float4 mla[WLX_XSPLIT / 2], mlb[WLX_XSPLIT / 2];
+                f16x8 ova[WLX_XSPLIT], ovb[WLX_XSPLIT];
+#pragma unroll
+                for (int sp = 0; sp < WLX_XSPLIT / 2; ++sp) { mla[sp] = mlpa[sp]; mlb[sp] = mlpb[sp]; }
+#pragma unroll
+                for (int sp = 0; sp < WLX_XSPLIT; ++sp) { ova[sp] = ld_f16x8(opa + sp * 1024); ovb[sp] = ld_f16x8(opb + sp * 1024); }
+                if (WLX_X_FIRST) load_weights();
+                finish(mla, ova, ma, cola, lane < n_w);
+                finish(mlb, ovb, mb, colb, lane + 64 < n_w);
+            }
+#pragma unroll 1
+            for (int u = lane + 128; u < n_w; u += 64) {                    // more than 128 items per wave (batched rows up to 16)
+                const float4* mlp; const half_t* op; int m, col;
+                item_ptrs(u, mlp, op, m, col);
+                float4 ml[WLX_XSPLIT / 2];
+                f16x8 ov[WLX_XSPLIT];
+#pragma unroll
+                for (int sp = 0; sp < WLX_XSPLIT / 2; ++sp) ml[sp] = mlp[sp];
+#pragma unroll
+                for (int sp = 0; sp < WLX_XSPLIT; ++sp) ov[sp] = ld_f16x8(op + sp * 1024);
+                finish(ml, ov, m, col, true);
+            }
+            WLX_TR_MARK(1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
         combine(tid, true);
 #pragma unroll 1
         for (int it0 = tid + blockDim.x; it0 < n_it; it0 += blockDim.x) combine(it0, false);
         WLX_TR_MARK(1);
         __syncthreads();
         if (!streams) return;                                               // helper waves are done (no later barrier needs them: ended waves leave the barrier count)
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const half_t* xr = xs + crow[mt] * ldxs + kx0 * 32 + g * 8;
@@ -1196,7 +1265,7 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
         grid.x = ((grid.x + 7) / 8) * 8 * p.rt_nz;
         grid.z = 1;
     }
-    if (p.in_mode == GEMV_IN_XATTN) {      // helper waves for the combine: one thread per (row, head, 4-float group), <= 1024
+    if (p.in_mode == GEMV_IN_XATTN && !(WLX_XCOMB_WAVE != 0 && c.MT == 1)) {      // helper waves for the combine: one thread per (row, head, 4-float group), <= 1024
         const int want = (p.M * p.H * 8 + 63) / 64;
         block.x = 64 * std::max(c.nw, std::min(c.MT > 1 ? 8 : 16, want));
     }
