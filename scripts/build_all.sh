@@ -7,6 +7,8 @@ from whisperlive_amd import _lib
 _lib.build(force=True); _lib.build_trace()
 for v in sys.argv[1:]:
     name, *defs = v.split(":")
+    if not (name.startswith("libwlx_") and name.endswith(".so")):
+        sys.exit(f"build_all.sh: variant '{v}' must be libwlx_<name>.so:DEFINE[:DEFINE...] (a bare name would write a file nobody loads)")
     _lib.build_variant(name, defs)
 print("build ok")
 PY

@@ -425,23 +425,28 @@ __device__ __forceinline__ void stage_rows_f16(const half_t* __restrict__ X, lon
 // the slice) with its 64 lanes — the same number of load instructions per workgroup as the cooperative copy — and is the only reader of what it wrote,
 // so the workgroup barrier between the staging and the MFMAs goes: a wave's LDS operations execute in order, and a wave starts its MFMAs when ITS
 // loads have landed instead of when the slowest wave's have.
-template <class F>
+template <int P, class F>
 __device__ __forceinline__ void stage_rows_f16_wave(const half_t* __restrict__ X, long ldx, int M, int K, half_t* xs, int ldxs, int lane,
                                                     F&& after_first_loads) {
+    // P units per lane are requested together before anything is stored (P = what five rows of the slice need: one round trip); a unit index past
+    // the end is clamped to the lane's previous unit, which is then stored twice with its own value
     const int kv8 = K >> 3, total = M * kv8;
     {
-        const int u0 = (lane < total) ? lane : total - 1;
-        const int u1 = (u0 + 64 < total) ? u0 + 64 : u0;
-        const int m0 = u0 / kv8, k0 = u0 - m0 * kv8;
-        const int m1 = u1 / kv8, k1 = u1 - m1 * kv8;
-        const f16x8 v0 = ld_f16x8(X + (long)m0 * ldx + k0 * 8);
-        const f16x8 v1 = ld_f16x8(X + (long)m1 * ldx + k1 * 8);
+        int m_[P], k_[P];
+        f16x8 v_[P];
+#pragma unroll
+        for (int q = 0; q < P; ++q) {
+            int u = lane + 64 * q;
+            if (u >= total) u = (q == 0) ? total - 1 : (lane + 64 * (q - 1) < total ? lane + 64 * (q - 1) : total - 1);
+            m_[q] = u / kv8; k_[q] = u - m_[q] * kv8;
+            v_[q] = ld_f16x8(X + (long)m_[q] * ldx + k_[q] * 8);
+        }
         after_first_loads();
-        *reinterpret_cast<f16x8*>(xs + m0 * ldxs + k0 * 8) = v0;
-        *reinterpret_cast<f16x8*>(xs + m1 * ldxs + k1 * 8) = v1;
+#pragma unroll
+        for (int q = 0; q < P; ++q) *reinterpret_cast<f16x8*>(xs + m_[q] * ldxs + k_[q] * 8) = v_[q];
     }
 #pragma unroll 1
-    for (int u0 = lane + 128; u0 < total; u0 += 128) {
+    for (int u0 = lane + 64 * P; u0 < total; u0 += 128) {
         const int u1 = u0 + 64;
         const int m0 = u0 / kv8, k0 = u0 - m0 * kv8;
         const int uc = (u1 < total) ? u1 : u0;
@@ -472,7 +477,7 @@ __device__ __forceinline__ void stage_rows_f16_wave(const half_t* __restrict__ X
 template <int CH, int LNV, int IN, int OUT, int NTB, int MT, int XS>
 // (<= 8 waves wherever the kernel holds more than one row tile of fragments: 256 VGPRs per lane — at 16 waves the
 // two- and three-tile residual projections spilled, 36-180 bytes of scratch per lane)
-__global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1 || (IN == GEMV_IN_XATTN && WLX_XCOMB_WAVE != 0)) ? 512 : 1024) void dec_gemv2_kernel(GemvParams p_in) {
+__global__ __launch_bounds__(CH > 12 ? 256 : (IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1 || CH > 6 || (IN == GEMV_IN_XATTN && WLX_XCOMB_WAVE != 0)) ? 512 : 1024) void dec_gemv2_kernel(GemvParams p_in) {
     // Row chunks (prompt prefill, round 3): a pass over up to 448 rows runs every projection as ONE launch whose grid.z walks
     // chunks of 48 rows (three MFMA row tiles, the widest this kernel holds); a chunk is this kernel on rebased row pointers.
     // Decode steps launch with Mtot = 0 and skip the block (a scalar branch).
@@ -602,7 +607,7 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
             const int ldxs = Ks + 8;
             if constexpr (WLX_STAGE_WAVE != 0) {
                 // every wave stages and reads only its own K slice: no workgroup barrier (stage_rows_f16_wave)
-                stage_rows_f16_wave(p.Xh + (ks0 + kx0) * 32, p.ldxh, p.M, p.KTW * 32, xs + kx0 * 32, ldxs, lane, [&]() { if (WLX_X_FIRST) load_weights(); });
+                stage_rows_f16_wave<(CH * 4 * 5 + 63) / 64>(p.Xh + (ks0 + kx0) * 32, p.ldxh, p.M, p.KTW * 32, xs + kx0 * 32, ldxs, lane, [&]() { if (WLX_X_FIRST) load_weights(); });
                 WLX_TR_MARK(1);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
@@ -941,21 +946,27 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
                 if (keep) *reinterpret_cast<f16x8*>(xs + m * ldxs + col) = hv;
             };
             {
-                const float4 *mlpa, *mlpb; const half_t *opa, *opb; int ma, mb, cola, colb;
-                item_ptrs(lane, mlpa, opa, ma, cola);
-                item_ptrs(lane + 64, mlpb, opb, mb, colb);
-                float4 mla[WLX_XSPLIT / 2], mlb[WLX_XSPLIT / 2];
-                f16x8 ova[WLX_XSPLIT], ovb[WLX_XSPLIT];
+                // NPL items per lane requested together (what five rows of the slice need: 2 for six k-tiles per wave, 3 for eight — one round trip)
+                constexpr int NPL = (CH * 4 * 5 + 63) / 64 < 2 ? 2 : (CH * 4 * 5 + 63) / 64;
+                const float4* mlpq[NPL]; const half_t* opq[NPL]; int mq[NPL], colq[NPL];
+                float4 mlq[NPL][WLX_XSPLIT / 2];
+                f16x8 ovq[NPL][WLX_XSPLIT];
 #pragma unroll
-                for (int sp = 0; sp < WLX_XSPLIT / 2; ++sp) { mla[sp] = mlpa[sp]; mlb[sp] = mlpb[sp]; }
+                for (int q = 0; q < NPL; ++q) item_ptrs(lane + 64 * q, mlpq[q], opq[q], mq[q], colq[q]);
 #pragma unroll
-                for (int sp = 0; sp < WLX_XSPLIT; ++sp) { ova[sp] = ld_f16x8(opa + sp * 1024); ovb[sp] = ld_f16x8(opb + sp * 1024); }
+                for (int sp = 0; sp < WLX_XSPLIT / 2; ++sp)
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) mlq[q][sp] = mlpq[q][sp];
+#pragma unroll
+                for (int sp = 0; sp < WLX_XSPLIT; ++sp)
+#pragma unroll
+                    for (int q = 0; q < NPL; ++q) ovq[q][sp] = ld_f16x8(opq[q] + sp * 1024);
                 if (WLX_X_FIRST) load_weights();
-                finish(mla, ova, ma, cola, lane < n_w);
-                finish(mlb, ovb, mb, colb, lane + 64 < n_w);
+#pragma unroll
+                for (int q = 0; q < NPL; ++q) finish(mlq[q], ovq[q], mq[q], colq[q], lane + 64 * q < n_w);
             }
 #pragma unroll 1
-            for (int u = lane + 128; u < n_w; u += 64) {                    // more than 128 items per wave (batched rows up to 16)
+            for (int u = lane + 64 * ((CH * 4 * 5 + 63) / 64 < 2 ? 2 : (CH * 4 * 5 + 63) / 64); u < n_w; u += 64) {   // more items per wave than the peeled ones (batched rows up to 16)
                 const float4* mlp; const half_t* op; int m, col;
                 item_ptrs(u, mlp, op, m, col);
                 float4 ml[WLX_XSPLIT / 2];
@@ -1133,16 +1144,32 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
             best_nch = 1; c.nw = KTf / CH; c.CH = CH; c.NCH = 1;
             break;
         }
-    } else      // (the split combine as 8 weight-streaming waves instead of 4 + helpers measured equal, profiles/r2h_*: not instantiated any more)
-    for (int CH = 6; CH >= 4; --CH) {
+    } else {     // (the split combine as 8 weight-streaming waves instead of 4 + helpers measured equal, profiles/r2h_*: not instantiated any more)
+    // Fewer waves with longer K slices (log G5, round 6): once no workgroup barrier stands in front of the MFMAs (wave-local staging, log G2) a wave's
+    // cost is its fixed part (row loads, LDS reduction leg, epilogue share) more than its k-tiles — K = 768 as two waves of twelve k-tiles instead of
+    // four of six (+0.8 % on the headline), 1024 as four of eight (medium.en +2.9 %), 512 as two of eight (+0.3 %). Measured and left alone: K = 1280
+    // (five waves of eight: uneven over the four SIMDs; four of ten: both 1 % slower than eight of five — large-v3 keeps eight), and the row tiles of
+    // a batched step (Mtot > 0: 12 windows per decode -1.8 %). Wide chunks stay within their launch bound (512 threads) and on SIMD-even wave counts.
+    // WLX_G2_CHMAX (A/B builds): the widest chunk tried, 4..12 (6 = the pick until log G5).
+    static const int chmax_env = [] { const char* e = wlx_ab("WLX_G2_CHMAX"); const int v = e ? atoi(e) : 12; return (v >= 4 && v <= 24) ? v : 12; }();
+    // (8 / 12 k-tiles per wave: fp16 rows in only, staged rows (one row tile) — the split combine peels two items per lane for six k-tiles)
+    // WLX_G2_XCHMAX (A/B builds): the same for the split combine (cross-attention output projection), whose waves then peel three / four items per lane
+    static const int xchmax_env = [] { const char* e = wlx_ab("WLX_G2_XCHMAX"); const int v = e ? atoi(e) : 6; return (v >= 4 && v <= 12) ? v : 6; }();
+    const int chmax = (p.M <= 16 && p.Mtot == 0 && p.in_mode == GEMV_IN_F16) ? chmax_env
+                    : (p.M <= 16 && p.Mtot == 0 && p.in_mode == GEMV_IN_XATTN && WLX_XCOMB_WAVE != 0) ? xchmax_env : std::min(chmax_env, 6);
+    for (int CH = chmax; CH >= 4; --CH) {
+        if (CH != 24 && CH != 16 && CH != 12 && CH != 8 && CH > 6) continue;
+        if (CH > 12 && p.in_mode != GEMV_IN_F16) continue;
         if (KTf % CH) continue;
         const int q = KTf / CH;                     // = nw * NCH
-        for (int nw = std::min(cap, q); nw >= 1; --nw) {
+        for (int nw = std::min(CH > 12 ? 4 : CH > 6 ? std::min(cap, 8) : cap, q); nw >= 1; --nw) {
             if (q % nw) continue;
+            if (CH > 6 && nw > 4 && (nw & 3)) break;
             const int nch = q / nw;
             if (nch < best_nch) { best_nch = nch; c.nw = nw; c.CH = CH; c.NCH = nch; }
             break;
         }
+    }
     }
     if (p.in_mode == GEMV_IN_LN && p.K == 384) {
         // d_model 384 (tiny / tiny.en, round 5): 12 k-tiles as six waves of two, so that six waves share the LayerNorm of the rows
@@ -1248,6 +1275,15 @@ static bool gemv2_launch_other(const GemvParams& p, const Gemv2Cfg& c, dim3 grid
     } else g2_launch<CH, 1, GEMV_IN_XATTN, GEMV_OUT_RESID, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p);
     return true;
 }
+// sixteen / twenty-four k-tiles per wave (log G5): fp16 rows in, one row tile, one column tile
+template <int CH>
+static bool gemv2_launch_wide(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, dim3 block, hipStream_t s) {
+    if (c.NTB != 1) return false;
+    if (p.out_mode == GEMV_OUT_SLAB) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_SLAB, 1, 1, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
+    if (p.xsrc == GEMV_X_SLABS) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, 1, GEMV_X_SLABS>(grid, block, c.shm, s, p); return true; }
+    g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, 1, GEMV_X_PLAIN>(grid, block, c.shm, s, p);
+    return true;
+}
 // the (CH, LNV) pairs of the Whisper family: d_model 512 (4,2), 768 (6,3), 1024 (4,4), 1280 (5,5)
 static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s) {
     GemvParams p = p0;
@@ -1289,6 +1325,10 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
         return false;
     }
     switch (c.CH) {
+        case 24: return c.MT == 1 && p.in_mode == GEMV_IN_F16 ? gemv2_launch_wide<24>(p, c, grid, block, s) : false;
+        case 16: return c.MT == 1 && p.in_mode == GEMV_IN_F16 ? gemv2_launch_wide<16>(p, c, grid, block, s) : false;
+        case 12: return c.MT == 1 ? gemv2_launch_other<12, 1>(p, c, grid, block, s) : false;
+        case 8: return c.MT == 1 ? gemv2_launch_other<8, 1>(p, c, grid, block, s) : false;
         case 6: return WLX_G2_OT(6);
         case 5: return WLX_G2_OT(5);
         default: return WLX_G2_OT(4);
