@@ -477,7 +477,7 @@ __device__ __forceinline__ void stage_rows_f16_wave(const half_t* __restrict__ X
 template <int CH, int LNV, int IN, int OUT, int NTB, int MT, int XS>
 // (<= 8 waves wherever the kernel holds more than one row tile of fragments: 256 VGPRs per lane — at 16 waves the
 // two- and three-tile residual projections spilled, 36-180 bytes of scratch per lane)
-__global__ __launch_bounds__(CH > 12 ? 256 : (IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1 || CH > 6 || (IN == GEMV_IN_XATTN && WLX_XCOMB_WAVE != 0)) ? 512 : 1024) void dec_gemv2_kernel(GemvParams p_in) {
+__global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1 || CH > 6 || (IN == GEMV_IN_XATTN && WLX_XCOMB_WAVE != 0)) ? 512 : 1024) void dec_gemv2_kernel(GemvParams p_in) {
     // Row chunks (prompt prefill, round 3): a pass over up to 448 rows runs every projection as ONE launch whose grid.z walks
     // chunks of 48 rows (three MFMA row tiles, the widest this kernel holds); a chunk is this kernel on rebased row pointers.
     // Decode steps launch with Mtot = 0 and skip the block (a scalar branch).
@@ -1146,23 +1146,23 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
         }
     } else {     // (the split combine as 8 weight-streaming waves instead of 4 + helpers measured equal, profiles/r2h_*: not instantiated any more)
     // Fewer waves with longer K slices (log G5, round 6): once no workgroup barrier stands in front of the MFMAs (wave-local staging, log G2) a wave's
-    // cost is its fixed part (row loads, LDS reduction leg, epilogue share) more than its k-tiles — K = 768 as two waves of twelve k-tiles instead of
-    // four of six (+0.8 % on the headline), 1024 as four of eight (medium.en +2.9 %), 512 as two of eight (+0.3 %). Measured and left alone: K = 1280
-    // (five waves of eight: uneven over the four SIMDs; four of ten: both 1 % slower than eight of five — large-v3 keeps eight), and the row tiles of
-    // a batched step (Mtot > 0: 12 windows per decode -1.8 %). Wide chunks stay within their launch bound (512 threads) and on SIMD-even wave counts.
-    // WLX_G2_CHMAX (A/B builds): the widest chunk tried, 4..12 (6 = the pick until log G5).
-    static const int chmax_env = [] { const char* e = wlx_ab("WLX_G2_CHMAX"); const int v = e ? atoi(e) : 12; return (v >= 4 && v <= 24) ? v : 12; }();
+    // cost is its fixed part (row loads, LDS reduction leg, its place at the epilogue's barrier) more than its k-tiles — K = 768 as two waves of twelve
+    // k-tiles instead of four of six (step graph 367.9 -> 363.6 us, headline +0.8 %), 1024 as four of eight instead of eight of four (medium.en
+    // +2.9 %), 512 as two of eight (+0.3 %). Measured and left alone (profiles/r6as_*, r6ao_*): ONE wave of 24 k-tiles for K = 768 (-2.0 %: one wave
+    // cannot keep 24 KiB of loads in flight AND the chain of 24 dependent MFMAs is 0.4 us), two waves of sixteen for K = 1024 (equal), K = 1280 as five
+    // waves of eight (uneven over the four SIMDs: -1 %; large-v3 keeps eight of five), the row tiles of a batched step (12 windows per decode -1.8 %:
+    // Mtot > 0 keeps the narrow slices), the split combine of the cross-attention output projection as three waves of eight / two of twelve with
+    // three / four items peeled per lane (-1.5 % / -10 %: its waves are bound by the partials they gather, not by their count). Wide slices stay
+    // within their launch bound (512 threads: an instantiation bound to 512 launched with 1024 is 'unspecified launch failure') and on SIMD-even counts.
+    // WLX_G2_CHMAX (A/B builds): the widest chunk tried, 4..12 (6 = the pick until log G5). scripts/gemv_pick_probe.cpp prints the picks on the host.
+    static const int chmax_env = [] { const char* e = wlx_ab("WLX_G2_CHMAX"); const int v = e ? atoi(e) : 12; return (v >= 4 && v <= 12) ? v : 12; }();
     // (8 / 12 k-tiles per wave: fp16 rows in only, staged rows (one row tile) — the split combine peels two items per lane for six k-tiles)
-    // WLX_G2_XCHMAX (A/B builds): the same for the split combine (cross-attention output projection), whose waves then peel three / four items per lane
-    static const int xchmax_env = [] { const char* e = wlx_ab("WLX_G2_XCHMAX"); const int v = e ? atoi(e) : 6; return (v >= 4 && v <= 12) ? v : 6; }();
-    const int chmax = (p.M <= 16 && p.Mtot == 0 && p.in_mode == GEMV_IN_F16) ? chmax_env
-                    : (p.M <= 16 && p.Mtot == 0 && p.in_mode == GEMV_IN_XATTN && WLX_XCOMB_WAVE != 0) ? xchmax_env : std::min(chmax_env, 6);
+    const int chmax = (p.in_mode == GEMV_IN_F16 && p.M <= 16 && p.Mtot == 0) ? chmax_env : std::min(chmax_env, 6);
     for (int CH = chmax; CH >= 4; --CH) {
-        if (CH != 24 && CH != 16 && CH != 12 && CH != 8 && CH > 6) continue;
-        if (CH > 12 && p.in_mode != GEMV_IN_F16) continue;
+        if (CH != 12 && CH != 8 && CH > 6) continue;
         if (KTf % CH) continue;
         const int q = KTf / CH;                     // = nw * NCH
-        for (int nw = std::min(CH > 12 ? 4 : CH > 6 ? std::min(cap, 8) : cap, q); nw >= 1; --nw) {
+        for (int nw = std::min(CH > 6 ? std::min(cap, 8) : cap, q); nw >= 1; --nw) {
             if (q % nw) continue;
             if (CH > 6 && nw > 4 && (nw & 3)) break;
             const int nch = q / nw;
@@ -1275,15 +1275,6 @@ static bool gemv2_launch_other(const GemvParams& p, const Gemv2Cfg& c, dim3 grid
     } else g2_launch<CH, 1, GEMV_IN_XATTN, GEMV_OUT_RESID, 1, MT, GEMV_X_PLAIN>(grid, block, c.shm, s, p);
     return true;
 }
-// sixteen / twenty-four k-tiles per wave (log G5): fp16 rows in, one row tile, one column tile
-template <int CH>
-static bool gemv2_launch_wide(const GemvParams& p, const Gemv2Cfg& c, dim3 grid, dim3 block, hipStream_t s) {
-    if (c.NTB != 1) return false;
-    if (p.out_mode == GEMV_OUT_SLAB) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_SLAB, 1, 1, GEMV_X_PLAIN>(grid, block, c.shm, s, p); return true; }
-    if (p.xsrc == GEMV_X_SLABS) { g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, 1, GEMV_X_SLABS>(grid, block, c.shm, s, p); return true; }
-    g2_launch<CH, 1, GEMV_IN_F16, GEMV_OUT_RESID, 1, 1, GEMV_X_PLAIN>(grid, block, c.shm, s, p);
-    return true;
-}
 // the (CH, LNV) pairs of the Whisper family: d_model 512 (4,2), 768 (6,3), 1024 (4,4), 1280 (5,5)
 static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s) {
     GemvParams p = p0;
@@ -1325,10 +1316,8 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
         return false;
     }
     switch (c.CH) {
-        case 24: return c.MT == 1 && p.in_mode == GEMV_IN_F16 ? gemv2_launch_wide<24>(p, c, grid, block, s) : false;
-        case 16: return c.MT == 1 && p.in_mode == GEMV_IN_F16 ? gemv2_launch_wide<16>(p, c, grid, block, s) : false;
-        case 12: return c.MT == 1 ? gemv2_launch_other<12, 1>(p, c, grid, block, s) : false;
-        case 8: return c.MT == 1 ? gemv2_launch_other<8, 1>(p, c, grid, block, s) : false;
+        case 12: return c.MT == 1 && p.in_mode == GEMV_IN_F16 ? gemv2_launch_other<12, 1>(p, c, grid, block, s) : false;
+        case 8: return c.MT == 1 && p.in_mode == GEMV_IN_F16 ? gemv2_launch_other<8, 1>(p, c, grid, block, s) : false;
         case 6: return WLX_G2_OT(6);
         case 5: return WLX_G2_OT(5);
         default: return WLX_G2_OT(4);
