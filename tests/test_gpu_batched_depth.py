@@ -95,14 +95,26 @@ def test_eight_items_batched_beam5_equal_singles_and_oracle(lv3):
     kw = dict(beam_size=5, patience=1.0, max_length=1 + STEPS, suppress_tokens=H.default_suppress(ids))
     res = sb.generate([[ids.sot]] * N_ITEMS, H.engine_ids(ids), **kw)
     # singles on the GPU: the same encoder rows (enc_items), one item per decode = the 5-row kernels
+    opts = odec.GenOptions(ids=ids, **kw)
+    near_ties = 0
     for i in range(N_ITEMS):
         one = sb.generate([[ids.sot]], H.engine_ids(ids), enc_items=[i], **kw)[0]
-        assert one.sequences_ids == res[i].sequences_ids, ("batched != single", i, _prefix(one.sequences_ids[0], res[i].sequences_ids[0]))
+        if one.sequences_ids != res[i].sequences_ids:
+            # Round 6 (log G5): one stream's step sums K = 1280 in four slices of ten k-tiles, the row tiles of a batched step in eight of five —
+            # another association of the same sum. A difference between the two GPU decodes is excused only by a near-tie that is SHOWN: the
+            # ORACLE's cumulative log-probabilities of the two token sequences (teacher-forced, decoding rules applied) lie within 2 x NOISE_AMP,
+            # the noise criterion's own definition of a near-tie (tests/helpers.py check_decode) — and at most one of the eight items may need it.
+            a, b = one.sequences_ids[0], res[i].sequences_ids[0]
+            la = H.oracle_sequence_logprob(oracle, encs[i], ids, [ids.sot], a, opts, f"single item {i}")
+            lb = H.oracle_sequence_logprob(oracle, encs[i], ids, [ids.sot], b, opts, f"batched item {i}")
+            print("large-v3 batched item", i, "differs from its single decode after", _prefix(a, b), "tokens; oracle log-probabilities", la, lb)
+            assert len(one.sequences_ids) == len(res[i].sequences_ids) and abs(la - lb) <= 2 * NOISE_AMP, ("batched != single", i, _prefix(a, b), la, lb)
+            near_ties += 1
         # (scores: the 40-row step and the 5-row step reduce the MLP output projection differently since round 4 — one launch for
         # batched rows, K-split partial sums for a single stream — so the summed log-probabilities differ by fp16-operand
         # rounding: measured 1.05e-3 on the length-normalised score, against 5e-3 allowed versus the oracle)
         assert abs(one.scores[0] - res[i].scores[0]) <= 2e-3
-    opts = odec.GenOptions(ids=ids, **kw)
+    assert near_ties <= 1, near_ties
     exact = 0
     for i in (0, 3, 7):
         ref = odec.generate(H.NetProvider(oracle, encs[i]), [ids.sot], opts)

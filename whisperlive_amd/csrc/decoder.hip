@@ -1136,7 +1136,10 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     const int cap = (p.in_mode == GEMV_IN_F16 && p.out_mode != GEMV_OUT_SLAB && p.M <= 16) ? 16 : 8;
     // exact factorisation KTf = nw * CH * NCH, CH in {6, 5, 4}: fewest chunks first, then the widest chunk
     int best_nch = 1 << 30;
-    if (p.in_mode == GEMV_IN_LN && p.xsrc != GEMV_X_PLAIN) {
+    // WLX_G2_LN_ONE_TRIP=1 (A/B builds, log G7): the LayerNorm-fronted projections of one stream's step on PLAIN rows (first MLP projection) with one
+    // row per wave as well — K = 768 as six waves of four k-tiles instead of four of six, whose fifth row is a second, dependent round trip
+    static const bool ln_one_trip = [] { const char* e = wlx_ab("WLX_G2_LN_ONE_TRIP"); return e && e[0] == '1'; }();
+    if (p.in_mode == GEMV_IN_LN && (p.xsrc != GEMV_X_PLAIN || (ln_one_trip && p.K == 768 && p.M <= 8 && p.Mtot == 0))) {
         // slab / embedding rows: one row per wave, so at least min(M, 8) waves, each streaming CH >= 2 k-tiles
         const int want = std::min(p.M, 8);
         for (int CH = 6; CH >= 2; --CH) {
@@ -1150,16 +1153,20 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     // k-tiles instead of four of six (step graph 367.9 -> 363.6 us, headline +0.8 %), 1024 as four of eight instead of eight of four (medium.en
     // +2.9 %), 512 as two of eight (+0.3 %). Measured and left alone (profiles/r6as_*, r6ao_*): ONE wave of 24 k-tiles for K = 768 (-2.0 %: one wave
     // cannot keep 24 KiB of loads in flight AND the chain of 24 dependent MFMAs is 0.4 us), two waves of sixteen for K = 1024 (equal), K = 1280 as five
-    // waves of eight (uneven over the four SIMDs: -1 %; large-v3 keeps eight of five), the row tiles of a batched step (12 windows per decode -1.8 %:
+    // waves of eight (uneven over the four SIMDs: -1 %; it runs as four of ten, below), the row tiles of a batched step (12 windows per decode -1.8 %:
     // Mtot > 0 keeps the narrow slices), the split combine of the cross-attention output projection as three waves of eight / two of twelve with
     // three / four items peeled per lane (-1.5 % / -10 %: its waves are bound by the partials they gather, not by their count). Wide slices stay
     // within their launch bound (512 threads: an instantiation bound to 512 launched with 1024 is 'unspecified launch failure') and on SIMD-even counts.
     // WLX_G2_CHMAX (A/B builds): the widest chunk tried, 4..12 (6 = the pick until log G5). scripts/gemv_pick_probe.cpp prints the picks on the host.
     static const int chmax_env = [] { const char* e = wlx_ab("WLX_G2_CHMAX"); const int v = e ? atoi(e) : 12; return (v >= 4 && v <= 12) ? v : 12; }();
     // (8 / 12 k-tiles per wave: fp16 rows in only, staged rows (one row tile) — the split combine peels two items per lane for six k-tiles)
+    // K = 1280 as four waves of ten k-tiles instead of eight of five (large-v3 step graph 1300 -> 1288 us, +1.1 %: profiles/r6au_*); WLX_G2_CH10=0
+    // (A/B builds) = eight of five
+    static const bool ch10 = [] { const char* e = wlx_ab("WLX_G2_CH10"); return !(e && e[0] == '0'); }();
     const int chmax = (p.in_mode == GEMV_IN_F16 && p.M <= 16 && p.Mtot == 0) ? chmax_env : std::min(chmax_env, 6);
     for (int CH = chmax; CH >= 4; --CH) {
-        if (CH != 12 && CH != 8 && CH > 6) continue;
+        if (CH != 12 && CH != 10 && CH != 8 && CH > 6) continue;
+        if (CH == 10 && !ch10) continue;
         if (KTf % CH) continue;
         const int q = KTf / CH;                     // = nw * NCH
         for (int nw = std::min(CH > 6 ? std::min(cap, 8) : cap, q); nw >= 1; --nw) {
@@ -1309,6 +1316,7 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
     }
     if (p.in_mode == GEMV_IN_LN) {
         if (c.CH == 6 && c.LNV == 3) return WLX_G2_LN(6, 3);
+        if (c.CH == 4 && c.LNV == 3) return c.MT == 1 ? gemv2_launch_ln<4, 3, 1>(p, c, grid, block, s) : false;
         if (c.CH == 5 && c.LNV == 5) return WLX_G2_LN(5, 5);
         if (c.CH == 4 && c.LNV == 2) return WLX_G2_LN(4, 2);
         if (c.CH == 4 && c.LNV == 4) return WLX_G2_LN(4, 4);
@@ -1317,6 +1325,7 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
     }
     switch (c.CH) {
         case 12: return c.MT == 1 && p.in_mode == GEMV_IN_F16 ? gemv2_launch_other<12, 1>(p, c, grid, block, s) : false;
+        case 10: return c.MT == 1 && p.in_mode == GEMV_IN_F16 ? gemv2_launch_other<10, 1>(p, c, grid, block, s) : false;
         case 8: return c.MT == 1 && p.in_mode == GEMV_IN_F16 ? gemv2_launch_other<8, 1>(p, c, grid, block, s) : false;
         case 6: return WLX_G2_OT(6);
         case 5: return WLX_G2_OT(5);
@@ -1334,6 +1343,7 @@ static bool gemv2_ok(const GemvParams& p, Gemv2Cfg* out) {
         if (!pair) return false;
     } else if (p.in_mode == GEMV_IN_LN) {
         const bool pair = (c.CH == 6 && c.LNV == 3) || (c.CH == 5 && c.LNV == 5) || (c.CH == 4 && c.LNV == 2) || (c.CH == 4 && c.LNV == 4) ||
+                          (c.CH == 4 && c.LNV == 3 && c.MT == 1) ||
                           (c.CH == 2 && c.LNV == 15 && c.MT == 1);
         if (!pair) return false;
     }
