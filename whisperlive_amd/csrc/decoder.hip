@@ -1136,10 +1136,7 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     const int cap = (p.in_mode == GEMV_IN_F16 && p.out_mode != GEMV_OUT_SLAB && p.M <= 16) ? 16 : 8;
     // exact factorisation KTf = nw * CH * NCH, CH in {6, 5, 4}: fewest chunks first, then the widest chunk
     int best_nch = 1 << 30;
-    // WLX_G2_LN_ONE_TRIP=1 (A/B builds, log G7): the LayerNorm-fronted projections of one stream's step on PLAIN rows (first MLP projection) with one
-    // row per wave as well — K = 768 as six waves of four k-tiles instead of four of six, whose fifth row is a second, dependent round trip
-    static const bool ln_one_trip = [] { const char* e = wlx_ab("WLX_G2_LN_ONE_TRIP"); return e && e[0] == '1'; }();
-    if (p.in_mode == GEMV_IN_LN && (p.xsrc != GEMV_X_PLAIN || (ln_one_trip && p.K == 768 && p.M <= 8 && p.Mtot == 0))) {
+    if (p.in_mode == GEMV_IN_LN && p.xsrc != GEMV_X_PLAIN) {
         // slab / embedding rows: one row per wave, so at least min(M, 8) waves, each streaming CH >= 2 k-tiles
         const int want = std::min(p.M, 8);
         for (int CH = 6; CH >= 2; --CH) {
@@ -1316,7 +1313,6 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
     }
     if (p.in_mode == GEMV_IN_LN) {
         if (c.CH == 6 && c.LNV == 3) return WLX_G2_LN(6, 3);
-        if (c.CH == 4 && c.LNV == 3) return c.MT == 1 ? gemv2_launch_ln<4, 3, 1>(p, c, grid, block, s) : false;
         if (c.CH == 5 && c.LNV == 5) return WLX_G2_LN(5, 5);
         if (c.CH == 4 && c.LNV == 2) return WLX_G2_LN(4, 2);
         if (c.CH == 4 && c.LNV == 4) return WLX_G2_LN(4, 4);
@@ -1343,7 +1339,6 @@ static bool gemv2_ok(const GemvParams& p, Gemv2Cfg* out) {
         if (!pair) return false;
     } else if (p.in_mode == GEMV_IN_LN) {
         const bool pair = (c.CH == 6 && c.LNV == 3) || (c.CH == 5 && c.LNV == 5) || (c.CH == 4 && c.LNV == 2) || (c.CH == 4 && c.LNV == 4) ||
-                          (c.CH == 4 && c.LNV == 3 && c.MT == 1) ||
                           (c.CH == 2 && c.LNV == 15 && c.MT == 1);
         if (!pair) return false;
     }
