@@ -26,6 +26,15 @@ int main() {
         {"medium fc2 slab M5", GEMV_IN_F16, GEMV_OUT_SLAB, 5, 4096, 1024, GEMV_X_PLAIN, WLX_FC2_KS},
         {"medium fc2 resid M16", GEMV_IN_F16, GEMV_OUT_RESID, 16, 4096, 1024, GEMV_X_PLAIN, 0},
         {"base o-proj M5", GEMV_IN_F16, GEMV_OUT_RESID, 5, 512, 512, GEMV_X_PLAIN, 0},
+        {"small mlp-up M5", GEMV_IN_LN, GEMV_OUT_GELU_F16, 5, 768, 3072, GEMV_X_PLAIN, 0},
+        {"small mlp-up M16", GEMV_IN_LN, GEMV_OUT_GELU_F16, 16, 768, 3072, GEMV_X_PLAIN, 0},
+        {"small mlp-up M60", GEMV_IN_LN, GEMV_OUT_GELU_F16, 60, 768, 3072, GEMV_X_PLAIN, 0},
+        {"small q-proj M5", GEMV_IN_LN, GEMV_OUT_F16, 5, 768, 768, GEMV_X_PLAIN, 0},
+        {"large mlp-up M5", GEMV_IN_LN, GEMV_OUT_GELU_F16, 5, 1280, 5120, GEMV_X_PLAIN, 0},
+        {"large q-proj M5", GEMV_IN_LN, GEMV_OUT_F16, 5, 1280, 1280, GEMV_X_PLAIN, 0},
+        {"large mlp-up M16", GEMV_IN_LN, GEMV_OUT_GELU_F16, 16, 1280, 5120, GEMV_X_PLAIN, 0},
+        {"medium mlp-up M5", GEMV_IN_LN, GEMV_OUT_GELU_F16, 5, 1024, 4096, GEMV_X_PLAIN, 0},
+        {"medium q-proj M5", GEMV_IN_LN, GEMV_OUT_F16, 5, 1024, 1024, GEMV_X_PLAIN, 0},
         {"tiny o-proj M5", GEMV_IN_F16, GEMV_OUT_RESID, 5, 384, 384, GEMV_X_PLAIN, 0},
     };
     for (auto& c : cases) {

@@ -39,3 +39,5 @@ echo "== large-v3"; timeout 400 $B --model large-v3 --steps 5 --warmup 2 > "$OUT
 echo "== config 5 max-batch 16"; timeout 600 python bench.py --config 5 --steps 2 --warmup 1 --max-batch 16 --no-pmc > "$OUT/bench_config5_mb16.json" 2> "$OUT/e9.err"; line "$OUT/bench_config5_mb16.json"
 rm -f "$OUT"/e?.err
 echo "total $(( $(date +%s) - t0 )) s"
+echo "== in-kernel timeline of one decode step (libwlx_trace.so)"; WLX_LIB=whisperlive_amd/libwlx_trace.so timeout 300 python scripts/trace_step.py --model small.en --t 33 > "$OUT/decode_step_trace.txt" 2>&1; sed -n 1,9p "$OUT/decode_step_trace.txt" | cut -c1-170
+echo "total $(( $(date +%s) - t0 )) s"

@@ -1160,10 +1160,15 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     // K = 1280 as four waves of ten k-tiles instead of eight of five (large-v3 step graph 1300 -> 1288 us, +1.1 %: profiles/r6au_*); WLX_G2_CH10=0
     // (A/B builds) = eight of five
     static const bool ch10 = [] { const char* e = wlx_ab("WLX_G2_CH10"); return !(e && e[0] == '0'); }();
-    const int chmax = (p.in_mode == GEMV_IN_F16 && p.M <= 16 && p.Mtot == 0) ? chmax_env : std::min(chmax_env, 6);
+    // WLX_G2_LN_WIDE=1 (A/B builds, log G8): the LayerNorm-fronted projections on PLAIN rows of one stream's step (cross-attention query where it is
+    // not fused, first MLP projection) as four waves instead of eight for K = 1024 / 1280 — 8 / 10 k-tiles per wave, five rows in two row trips
+    static const bool ln_wide = [] { const char* e = wlx_ab("WLX_G2_LN_WIDE"); return e && e[0] == '1'; }();
+    const bool ln_wide_here = ln_wide && p.in_mode == GEMV_IN_LN && p.xsrc == GEMV_X_PLAIN && p.M <= 8 && p.Mtot == 0 && (p.K == 1024 || p.K == 1280);
+    const int chmax = (p.in_mode == GEMV_IN_F16 && p.M <= 16 && p.Mtot == 0) ? chmax_env : ln_wide_here ? 10 : std::min(chmax_env, 6);
     for (int CH = chmax; CH >= 4; --CH) {
         if (CH != 12 && CH != 10 && CH != 8 && CH > 6) continue;
-        if (CH == 10 && !ch10) continue;
+        if (CH == 10 && !ch10 && !ln_wide_here) continue;
+        if (ln_wide_here && CH > 6 && CH * 128 != p.K) continue;
         if (KTf % CH) continue;
         const int q = KTf / CH;                     // = nw * NCH
         for (int nw = std::min(CH > 6 ? std::min(cap, 8) : cap, q); nw >= 1; --nw) {
@@ -1314,6 +1319,8 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
     if (p.in_mode == GEMV_IN_LN) {
         if (c.CH == 6 && c.LNV == 3) return WLX_G2_LN(6, 3);
         if (c.CH == 5 && c.LNV == 5) return WLX_G2_LN(5, 5);
+        if (c.CH == 10 && c.LNV == 5) return c.MT == 1 ? gemv2_launch_ln<10, 5, 1>(p, c, grid, block, s) : false;
+        if (c.CH == 8 && c.LNV == 4) return c.MT == 1 ? gemv2_launch_ln<8, 4, 1>(p, c, grid, block, s) : false;
         if (c.CH == 4 && c.LNV == 2) return WLX_G2_LN(4, 2);
         if (c.CH == 4 && c.LNV == 4) return WLX_G2_LN(4, 4);
         if (c.CH == 2 && c.LNV == 15) return c.MT == 1 ? gemv2_launch_ln<2, 15, 1>(p, c, grid, block, s) : false;   // (one row tile: batched rows run as row tiles)
@@ -1339,6 +1346,7 @@ static bool gemv2_ok(const GemvParams& p, Gemv2Cfg* out) {
         if (!pair) return false;
     } else if (p.in_mode == GEMV_IN_LN) {
         const bool pair = (c.CH == 6 && c.LNV == 3) || (c.CH == 5 && c.LNV == 5) || (c.CH == 4 && c.LNV == 2) || (c.CH == 4 && c.LNV == 4) ||
+                          (c.CH == 10 && c.LNV == 5 && c.MT == 1) || (c.CH == 8 && c.LNV == 4 && c.MT == 1) ||
                           (c.CH == 2 && c.LNV == 15 && c.MT == 1);
         if (!pair) return false;
     }
