@@ -35,6 +35,11 @@ int main() {
         {"large mlp-up M16", GEMV_IN_LN, GEMV_OUT_GELU_F16, 16, 1280, 5120, GEMV_X_PLAIN, 0},
         {"medium mlp-up M5", GEMV_IN_LN, GEMV_OUT_GELU_F16, 5, 1024, 4096, GEMV_X_PLAIN, 0},
         {"medium q-proj M5", GEMV_IN_LN, GEMV_OUT_F16, 5, 1024, 1024, GEMV_X_PLAIN, 0},
+        {"small qkv slabs M5", GEMV_IN_LN, GEMV_OUT_QKV, 5, 768, 2304, GEMV_X_SLABS, 0},
+        {"small qkv embed M5", GEMV_IN_LN, GEMV_OUT_QKV, 5, 768, 2304, GEMV_X_EMBED, 0},
+        {"medium qkv slabs M5", GEMV_IN_LN, GEMV_OUT_QKV, 5, 1024, 3072, GEMV_X_SLABS, 0},
+        {"large qkv slabs M5", GEMV_IN_LN, GEMV_OUT_QKV, 5, 1280, 3840, GEMV_X_SLABS, 0},
+        {"large qkv slabs M16", GEMV_IN_LN, GEMV_OUT_QKV, 16, 1280, 3840, GEMV_X_SLABS, 0},
         {"tiny o-proj M5", GEMV_IN_F16, GEMV_OUT_RESID, 5, 384, 384, GEMV_X_PLAIN, 0},
     };
     for (auto& c : cases) {

@@ -1160,10 +1160,11 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     // K = 1280 as four waves of ten k-tiles instead of eight of five (large-v3 step graph 1300 -> 1288 us, +1.1 %: profiles/r6au_*); WLX_G2_CH10=0
     // (A/B builds) = eight of five
     static const bool ch10 = [] { const char* e = wlx_ab("WLX_G2_CH10"); return !(e && e[0] == '0'); }();
-    // WLX_G2_LN_WIDE=1 (A/B builds, log G8): the LayerNorm-fronted projections on PLAIN rows of one stream's step (cross-attention query where it is
-    // not fused, first MLP projection) as four waves instead of eight for K = 1024 / 1280 — 8 / 10 k-tiles per wave, five rows in two row trips
-    static const bool ln_wide = [] { const char* e = wlx_ab("WLX_G2_LN_WIDE"); return e && e[0] == '1'; }();
-    const bool ln_wide_here = ln_wide && p.in_mode == GEMV_IN_LN && p.xsrc == GEMV_X_PLAIN && p.M <= 8 && p.Mtot == 0 && (p.K == 1024 || p.K == 1280);
+    // Log G8 (round 6): the LayerNorm-fronted projections on PLAIN rows of one stream's step (cross-attention query where it is not fused, first MLP
+    // projection) as four waves instead of eight for K = 1024 / 1280 — 8 / 10 k-tiles per wave, five rows in two row trips: large-v3 step graph
+    // 1287 -> 1250 us (+3.5 %), medium.en 859 -> 832 us (+2.9 %), profiles/r6aw_*. WLX_G2_LN_WIDE=0 (A/B builds) = eight waves.
+    static const bool ln_wide = [] { const char* e = wlx_ab("WLX_G2_LN_WIDE"); return !(e && e[0] == '0'); }();
+    const bool ln_wide_here = ln_wide && p.in_mode == GEMV_IN_LN && p.M <= 8 && p.Mtot == 0 && (p.K == 1024 || p.K == 1280) && p.xsrc == GEMV_X_PLAIN;
     const int chmax = (p.in_mode == GEMV_IN_F16 && p.M <= 16 && p.Mtot == 0) ? chmax_env : ln_wide_here ? 10 : std::min(chmax_env, 6);
     for (int CH = chmax; CH >= 4; --CH) {
         if (CH != 12 && CH != 10 && CH != 8 && CH > 6) continue;
