@@ -34,11 +34,12 @@ EXPECTED = {
     "medium mlp-up M5": "dec_gemv2_kernel<8, 4, 0, 1, 1, 1, 0>",
     "large mlp-up M5": "dec_gemv2_kernel<10, 5, 0, 1, 2, 1, 0>",
     "large q-proj M5": "dec_gemv2_kernel<10, 5, 0, 0, 1, 1, 0>",
-    # a layer's first projection (rows + slabs / embedding rows): one row per wave (G9)
+    # a layer's first projection (rows + slabs / embedding rows): one row per wave for K = 768, four waves with both rows of a wave
+    # requested together for K = 1024 / 1280 (G9)
     "small qkv slabs M5": "dec_gemv2_kernel<4, 3, 0, 4, 1, 1, 1>",
     "small qkv embed M5": "dec_gemv2_kernel<4, 3, 0, 4, 1, 1, 2>",
-    "medium qkv slabs M5": "dec_gemv2_kernel<4, 4, 0, 4, 1, 1, 1>",
-    "large qkv slabs M5": "dec_gemv2_kernel<5, 5, 0, 4, 1, 1, 1>",
+    "medium qkv slabs M5": "dec_gemv2_kernel<8, 4, 0, 4, 1, 1, 1>",
+    "large qkv slabs M5": "dec_gemv2_kernel<10, 5, 0, 4, 1, 1, 1>",
     # batched rows (row tiles, Mtot > 0) and 9..16 rows of the LayerNorm-fronted launches keep the narrow slices
     "small o-proj M60": "dec_gemv2_kernel<6, 1, 1, 3, 1, 1, 0>",
     "small fc2 slab M60": "dec_gemv2_kernel<6, 1, 1, 5, 1, 1, 0>",

@@ -655,8 +655,9 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
         }
     } else if constexpr (IN == GEMV_IN_LN && XS != GEMV_X_PLAIN) {
         // rows from slabs or the embedding tables: ONE row per wave in the first trip (its pieces are 3-5x the registers of a
-        // plain row, so no second row is prefetched; the host picks a K split with at least as many waves as rows, all of them
-        // streaming weights — helper waves with clamped dummy loads were measured 0.6 us SLOWER per launch, profiles/r2f_*).
+        // plain row; the host picks a K split with at least as many waves as rows, all of them streaming weights — helper waves
+        // with clamped dummy loads were measured 0.6 us SLOWER per launch, profiles/r2f_*) — except the four-wave shapes of
+        // round 6 (PF2 below: K = 1024 / 1280), which request the wave's second row together with its first.
         // wave w normalises rows w, w + nw, ...; a row = LNV float4 per lane (d_model = 256 LNV).
         const int nwl = nw;
         constexpr int NSL = (XS == GEMV_X_SLABS) ? WLX_FC2_KS : 1;
@@ -709,6 +710,15 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
         };
         const int ra = (wave < p.M) ? wave : p.M - 1;
         request_row(ra, x, sl, te, tok0, pos0);
+        // The four-wave shapes of one stream's step (log G9: (CH, LNV) = (6, 3), (8, 4), (10, 5) — instantiated for nothing else) have fewer waves than
+        // rows: the wave's SECOND row is requested together with its first, as the PLAIN-rows prologue below does — a clamped row for the waves that
+        // have none (every wave issues the same loads: no branch around a request)
+        constexpr bool PF2 = MT == 1 && ((CH == 6 && LNV == 3) || (CH == 8 && LNV == 4) || (CH == 10 && LNV == 5));
+        float4 xb[NV], slb[NSL][NV];
+        f16x4 teb[NV];
+        int tokb = 0, posb = 0;
+        const int rb = (wave + nwl < p.M) ? wave + nwl : p.M - 1;
+        if constexpr (PF2) request_row(rb, xb, slb, teb, tokb, posb);
         const float4* g4 = reinterpret_cast<const float4*>(p.gamma) + lane;
         const float4* b4 = reinterpret_cast<const float4*>(p.beta) + lane;
         float4 gq[NV], bq[NV];
@@ -745,9 +755,13 @@ __global__ __launch_bounds__((IN == GEMV_IN_LN || OUT == GEMV_OUT_SLAB || MT > 1
         // NEWEST request of either, so the first trip would wait for the weight stream it is meant to overlap.
         combine_row(ra, wave < p.M, x, sl, te, tok0, pos0);
         ln_row(x, ra, wave < p.M);
+        if constexpr (PF2) {
+            combine_row(rb, wave + nwl < p.M, xb, slb, teb, tokb, posb);
+            ln_row(xb, rb, wave + nwl < p.M);
+        }
         if constexpr (MT == 1) {
 #pragma unroll 1
-            for (int r = wave + nwl; r < p.M; r += nwl) {                   // more rows than waves (9..16 rows)
+            for (int r = wave + (PF2 ? 2 : 1) * nwl; r < p.M; r += nwl) {   // more rows than waves (9..16 rows)
                 float4 x2[NV], sl2[NSL][NV];
                 f16x4 te2[NV];
                 int tok2 = 0, pos2 = 0;
@@ -1136,7 +1150,14 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     const int cap = (p.in_mode == GEMV_IN_F16 && p.out_mode != GEMV_OUT_SLAB && p.M <= 16) ? 16 : 8;
     // exact factorisation KTf = nw * CH * NCH, CH in {6, 5, 4}: fewest chunks first, then the widest chunk
     int best_nch = 1 << 30;
-    if (p.in_mode == GEMV_IN_LN && p.xsrc != GEMV_X_PLAIN) {
+    // Log G9 (round 6): a layer's FIRST projection (rows + slabs / embedding rows) of one stream's step as FOUR waves for K = 1024 / 1280 (8 / 10 k-tiles
+    // per wave instead of eight waves of 4 / 5), the wave's second row requested together with its first (PF2 in the kernel: without that prefetch
+    // the four-wave shape LOST 0.6-1 %): large-v3 +1.6 %, medium.en +0.9 %, profiles/r6az_*. K = 768 keeps one row per wave (six waves of four: the
+    // four-wave shape measured +0.1 %, inside the spread). WLX_G2_XS_FEW (A/B builds): 0 = one row per wave everywhere, 2 = K = 768 as four waves too.
+    static const int xs_few = [] { const char* e = wlx_ab("WLX_G2_XS_FEW"); const int v = e ? atoi(e) : 1; return (v >= 0 && v <= 2) ? v : 1; }();
+    const bool xs_few_here = xs_few && p.in_mode == GEMV_IN_LN && p.xsrc != GEMV_X_PLAIN && p.out_mode == GEMV_OUT_QKV && p.M <= 8 && p.Mtot == 0 &&
+                             (p.K == 1024 || p.K == 1280 || (xs_few == 2 && p.K == 768));
+    if (p.in_mode == GEMV_IN_LN && p.xsrc != GEMV_X_PLAIN && !xs_few_here) {
         // slab / embedding rows: one row per wave, so at least min(M, 8) waves, each streaming CH >= 2 k-tiles
         const int want = std::min(p.M, 8);
         for (int CH = 6; CH >= 2; --CH) {
@@ -1164,7 +1185,7 @@ static Gemv2Cfg gemv2_cfg(const GemvParams& p) {
     // projection) as four waves instead of eight for K = 1024 / 1280 — 8 / 10 k-tiles per wave, five rows in two row trips: large-v3 step graph
     // 1287 -> 1250 us (+3.5 %), medium.en 859 -> 832 us (+2.9 %), profiles/r6aw_*. WLX_G2_LN_WIDE=0 (A/B builds) = eight waves.
     static const bool ln_wide = [] { const char* e = wlx_ab("WLX_G2_LN_WIDE"); return !(e && e[0] == '0'); }();
-    const bool ln_wide_here = ln_wide && p.in_mode == GEMV_IN_LN && p.M <= 8 && p.Mtot == 0 && (p.K == 1024 || p.K == 1280) && p.xsrc == GEMV_X_PLAIN;
+    const bool ln_wide_here = ln_wide && p.in_mode == GEMV_IN_LN && p.M <= 8 && p.Mtot == 0 && (p.K == 1024 || p.K == 1280) && (p.xsrc == GEMV_X_PLAIN || xs_few_here);
     const int chmax = (p.in_mode == GEMV_IN_F16 && p.M <= 16 && p.Mtot == 0) ? chmax_env : ln_wide_here ? 10 : std::min(chmax_env, 6);
     for (int CH = chmax; CH >= 4; --CH) {
         if (CH != 12 && CH != 10 && CH != 8 && CH > 6) continue;
@@ -1315,6 +1336,9 @@ static bool gemv2_launch(const GemvParams& p0, const Gemv2Cfg& c, hipStream_t s)
         if (c.CH == 2 && c.LNV == 15) return c.MT == 1 ? gemv2_launch_qkv_xs_mt<2, 15, 1>(p, c, grid, block, s) : false;
         if (c.CH == 4 && c.LNV == 4) return gemv2_launch_qkv_xs<4, 4>(p, c, grid, block, s);
         if (c.CH == 5 && c.LNV == 5) return gemv2_launch_qkv_xs<5, 5>(p, c, grid, block, s);
+        if (c.CH == 6 && c.LNV == 3) return c.MT == 1 ? gemv2_launch_qkv_xs_mt<6, 3, 1>(p, c, grid, block, s) : false;
+        if (c.CH == 8 && c.LNV == 4) return c.MT == 1 ? gemv2_launch_qkv_xs_mt<8, 4, 1>(p, c, grid, block, s) : false;
+        if (c.CH == 10 && c.LNV == 5) return c.MT == 1 ? gemv2_launch_qkv_xs_mt<10, 5, 1>(p, c, grid, block, s) : false;
         return false;
     }
     if (p.in_mode == GEMV_IN_LN) {
@@ -1343,6 +1367,7 @@ static bool gemv2_ok(const GemvParams& p, Gemv2Cfg* out) {
     if (!c.ok) return false;
     if (p.in_mode == GEMV_IN_LN && p.xsrc != GEMV_X_PLAIN) {
         const bool pair = (c.CH == 4 && c.LNV == 3) || (c.CH == 3 && c.LNV == 3) || (c.CH == 2 && c.LNV == 2) || (c.CH == 4 && c.LNV == 4) || (c.CH == 5 && c.LNV == 5) ||
+                          (c.MT == 1 && ((c.CH == 6 && c.LNV == 3) || (c.CH == 8 && c.LNV == 4) || (c.CH == 10 && c.LNV == 5))) ||
                           (c.CH == 2 && c.LNV == 15 && c.MT == 1);
         if (!pair) return false;
     } else if (p.in_mode == GEMV_IN_LN) {
